@@ -1,0 +1,211 @@
+/* oracle/ref_harness.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Flat-array wrappers around the *reference's own* functions so that Python
+ * (ctypes) can drive them when generating golden vectors and when validating
+ * the CPU restatement in oracle/nabwa_oracle.c.  Compiled by oracle/Makefile
+ * against the reference headers in /root/reference (never copied).  Every
+ * wrapper only marshals arguments; all arithmetic is the reference's.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "bwt.h"
+#include "bwtaln.h"
+#include "bwtgap.h"
+#include "bwase.h"
+#include "bntseq.h"
+#include "stdaln.h"
+
+typedef struct {
+	bwt_t *bwt[2];
+	bntseq_t *bns;
+	ubyte_t *pac;
+} ref_index_t;
+
+extern int g_log_n[256];
+void bwase_initialize();
+
+ref_index_t *ref_index_load(const char *prefix, int with_sa)
+{
+	ref_index_t *ix = (ref_index_t*)calloc(1, sizeof(ref_index_t));
+	char *s = (char*)calloc(strlen(prefix) + 16, 1);
+	strcpy(s, prefix); strcat(s, ".bwt");  ix->bwt[0] = bwt_restore_bwt(s, 0);
+	strcpy(s, prefix); strcat(s, ".rbwt"); ix->bwt[1] = bwt_restore_bwt(s, 0);
+	if (with_sa) {
+		strcpy(s, prefix); strcat(s, ".sa");  bwt_restore_sa(s, ix->bwt[0], 0);
+		strcpy(s, prefix); strcat(s, ".rsa"); bwt_restore_sa(s, ix->bwt[1], 0);
+	}
+	ix->bns = bns_restore(prefix);
+	ix->pac = bwt_restore_pac(ix->bns, 0);
+	bwase_initialize();
+	free(s);
+	return ix;
+}
+
+void ref_index_free(ref_index_t *ix)
+{
+	if (!ix) return;
+	bwt_destroy(ix->bwt[0]); bwt_destroy(ix->bwt[1]);
+	bwt_destroy_pac(ix->pac, ix->bns);
+	bns_destroy(ix->bns);
+	free(ix);
+}
+
+uint32_t ref_seq_len(ref_index_t *ix, int which) { return ix->bwt[which]->seq_len; }
+uint32_t ref_primary(ref_index_t *ix, int which) { return ix->bwt[which]->primary; }
+uint32_t ref_seed(ref_index_t *ix) { return ix->bns->seed; }
+
+/* rank primitives (reference bwt.c:92-216) */
+uint32_t ref_occ(ref_index_t *ix, int which, uint32_t k, int c) { return bwt_occ(ix->bwt[which], k, c); }
+void ref_occ4(ref_index_t *ix, int which, uint32_t k, uint32_t cnt[4]) { bwt_occ4(ix->bwt[which], k, cnt); }
+void ref_2occ(ref_index_t *ix, int which, uint32_t k, uint32_t l, int c, uint32_t *ok, uint32_t *ol)
+{ bwt_2occ(ix->bwt[which], k, l, c, ok, ol); }
+void ref_2occ4(ref_index_t *ix, int which, uint32_t k, uint32_t l, uint32_t ck[4], uint32_t cl[4])
+{ bwt_2occ4(ix->bwt[which], k, l, ck, cl); }
+uint32_t ref_sa(ref_index_t *ix, int which, uint32_t k) { return bwt_sa(ix->bwt[which], k); }
+int ref_maxdiff(int l, double err, double thres) { return bwa_cal_maxdiff(l, err, thres); }
+
+void ref_default_opt(gap_opt_t *o) { gap_opt_t *d = gap_init_opt(); *o = *d; free(d); }
+
+/* bwa_cal_sa_reg_gap (reference bwtaln.c:93) over a flat batch.
+ * seq/rseq: concatenated bwa_seq_t.seq / .rseq byte codes; off[i]..off[i+1] delimit read i.
+ * per_read != 0 -> one call per read (what bam2bam.c:616 does), else one call for the batch
+ * (what bwa aln does, bwtaln.c:235).  Output: n_aln[i], aln rows appended to aln_out
+ * (4 x u32 per row: packed{n_mm,n_gapo,n_gape,a}, k, l, score), max_entries[i].
+ * Returns total rows, or -1 if aln_cap is too small. */
+long ref_cal_sa_reg_gap(ref_index_t *ix, const gap_opt_t *opt, int n, const int64_t *off,
+						const uint8_t *seq, const uint8_t *rseq, int per_read,
+						int32_t *n_aln, uint32_t *aln_out, long aln_cap, int32_t *max_entries)
+{
+	bwa_seq_t *s = (bwa_seq_t*)calloc(n, sizeof(bwa_seq_t));
+	long tot = 0; int i;
+	for (i = 0; i < n; ++i) {
+		s[i].len = s[i].full_len = s[i].clip_len = (int)(off[i+1] - off[i]);
+		s[i].seq = (ubyte_t*)(seq + off[i]);
+		s[i].rseq = (ubyte_t*)(rseq + off[i]);
+	}
+	if (per_read) for (i = 0; i < n; ++i) bwa_cal_sa_reg_gap(ix->bwt, 1, s + i, opt);
+	else bwa_cal_sa_reg_gap(ix->bwt, n, s, opt);
+	for (i = 0; i < n; ++i) {
+		n_aln[i] = s[i].n_aln;
+		max_entries[i] = s[i].max_entries;
+		if (tot + s[i].n_aln > aln_cap) { tot = -1; break; }
+		if (s[i].n_aln) memcpy(aln_out + 4 * tot, s[i].aln, 16 * (size_t)s[i].n_aln);
+		tot += s[i].n_aln;
+	}
+	for (i = 0; i < n; ++i) free(s[i].aln);
+	free(s);
+	return tot;
+}
+
+/* hit choice + position + mapQ for one SE read, in call order (global drand48 stream):
+ * bwa_aln2seq_core (bwase.c:19) then bwa_cal_pac_pos_core (bwase.c:139) and the multi-hit
+ * positions as bam2bam.c:629-637 / bwase.c:166-181 do.
+ * out[0..11] = type,strand,n_mm,n_gapo,n_gape,score,sa,c1,c2,pos,mapQ,n_multi;
+ * multi_out rows: pos(after SA lookup), gap, mm, strand. */
+void ref_seed48(long seed) { srand48(seed); }
+void ref_aln2pos_se(ref_index_t *ix, const gap_opt_t *opt, int len, int n_aln, const uint32_t *aln,
+					int n_occ, int64_t *out, int64_t *multi_out)
+{
+	bwa_seq_t s; int j;
+	memset(&s, 0, sizeof(s));
+	s.len = s.full_len = s.clip_len = len;
+	bwa_aln2seq_core(n_aln, (const bwt_aln1_t*)aln, &s, 1, n_occ);
+	bwa_cal_pac_pos_core(ix->bwt[0], ix->bwt[1], &s, opt->max_diff, opt->fnr);
+	for (j = 0; j < s.n_multi; ++j) {
+		bwt_multi1_t *q = s.multi + j;
+		if (q->strand) q->pos = bwt_sa(ix->bwt[0], q->pos);
+		else q->pos = ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], q->pos) + s.len);
+		multi_out[4*j] = q->pos; multi_out[4*j+1] = q->gap; multi_out[4*j+2] = q->mm; multi_out[4*j+3] = q->strand;
+	}
+	out[0] = s.type; out[1] = s.strand; out[2] = s.n_mm; out[3] = s.n_gapo; out[4] = s.n_gape;
+	out[5] = s.score; out[6] = s.sa; out[7] = s.c1; out[8] = s.c2; out[9] = s.pos; out[10] = s.mapQ;
+	out[11] = s.n_multi;
+	free(s.multi);
+}
+
+/* aln_global_core (stdaln.c:345) with an explicit parameter block.
+ * matrix: row*row ints.  Returns score; cigar32 (len<<4|op) in cig_out, count in *n_cig;
+ * path (i,j,ctype triples) in path_out if non-NULL. */
+int ref_global(const uint8_t *s1, int l1, const uint8_t *s2, int l2, int gap_open, int gap_ext, int gap_end,
+			   const int *matrix, int row, int band, uint32_t *cig_out, int *n_cig, int32_t *path_out, int *path_len)
+{
+	AlnParam ap; path_t *path; int score, i; uint32_t *c;
+	ap.gap_open = gap_open; ap.gap_ext = gap_ext; ap.gap_end = gap_end;
+	ap.matrix = (int*)matrix; ap.row = row; ap.band_width = band;
+	path = (path_t*)calloc(l1 + l2 + 2, sizeof(path_t));
+	score = aln_global_core((unsigned char*)s1, l1, (unsigned char*)s2, l2, &ap, path, path_len);
+	c = aln_path2cigar32(path, *path_len, n_cig);
+	for (i = 0; i < *n_cig; ++i) cig_out[i] = c[i];
+	if (path_out) for (i = 0; i <= *path_len; ++i) {
+		path_out[3*i] = path[i].i; path_out[3*i+1] = path[i].j; path_out[3*i+2] = path[i].ctype;
+	}
+	free(c); free(path);
+	return score;
+}
+
+/* aln_local_core (stdaln.c:529) / aln_extend_core (stdaln.c:862), same marshalling. */
+int ref_local(const uint8_t *s1, int l1, const uint8_t *s2, int l2, int gap_open, int gap_ext, int gap_end,
+			  const int *matrix, int row, int band, int thres, uint32_t *cig_out, int *n_cig,
+			  int32_t *path_out, int *path_len, int *subo)
+{
+	AlnParam ap; path_t *path; int score, i; uint32_t *c;
+	ap.gap_open = gap_open; ap.gap_ext = gap_ext; ap.gap_end = gap_end;
+	ap.matrix = (int*)matrix; ap.row = row; ap.band_width = band;
+	path = (path_t*)calloc(l1 + l2 + 2, sizeof(path_t));
+	score = aln_local_core((unsigned char*)s1, l1, (unsigned char*)s2, l2, &ap, path, path_len, thres, subo);
+	c = aln_path2cigar32(path, *path_len, n_cig);
+	for (i = 0; i < *n_cig; ++i) cig_out[i] = c[i];
+	if (path_out) for (i = 0; i < *path_len; ++i) {
+		path_out[3*i] = path[i].i; path_out[3*i+1] = path[i].j; path_out[3*i+2] = path[i].ctype;
+	}
+	free(c); free(path);
+	return score;
+}
+
+int ref_extend(const uint8_t *s1, int l1, const uint8_t *s2, int l2, int gap_open, int gap_ext, int gap_end,
+			   const int *matrix, int row, int band, int G0, uint32_t *cig_out, int *n_cig,
+			   int32_t *path_out, int *path_len)
+{
+	AlnParam ap; path_t *path; int score, i; uint32_t *c;
+	ap.gap_open = gap_open; ap.gap_ext = gap_ext; ap.gap_end = gap_end;
+	ap.matrix = (int*)matrix; ap.row = row; ap.band_width = band;
+	path = (path_t*)calloc(l1 + l2 + 2, sizeof(path_t));
+	score = aln_extend_core((unsigned char*)s1, l1, (unsigned char*)s2, l2, &ap, path, path_len, G0, 0);
+	c = aln_path2cigar32(path, *path_len, n_cig);
+	for (i = 0; i < *n_cig; ++i) cig_out[i] = c[i];
+	if (path_out) for (i = 0; i < *path_len; ++i) {
+		path_out[3*i] = path[i].i; path_out[3*i+1] = path[i].j; path_out[3*i+2] = path[i].ctype;
+	}
+	free(c); free(path);
+	return score;
+}
+
+/* bwa_refine_gapped (bwase.c:356) for one positioned SE read without multi hits.
+ * seq/rseq as produced by bam1_to_seq (seq reversed; the function un-reverses it).
+ * in:  strand,n_gapo,n_gape,pos,type ; out: pos', n_cigar, cigar u16[], nm, md (NUL-terminated). */
+void ref_refine_one(ref_index_t *ix, int len, const uint8_t *seq, const uint8_t *rseq, int type, int strand,
+					int n_mm, int n_gapo, int n_gape, uint32_t pos,
+					uint32_t *pos_out, int *n_cigar, uint16_t *cigar_out, int *nm, char *md_out, int md_cap)
+{
+	bwa_seq_t s;
+	memset(&s, 0, sizeof(s));
+	s.len = s.full_len = s.clip_len = len;
+	s.seq = (ubyte_t*)malloc(len + 1); memcpy(s.seq, seq, len);
+	s.rseq = (ubyte_t*)malloc(len + 1); memcpy(s.rseq, rseq, len);
+	s.type = type; s.strand = strand; s.n_mm = n_mm; s.n_gapo = n_gapo; s.n_gape = n_gape; s.pos = pos;
+	bwa_refine_gapped(ix->bns, 1, &s, ix->pac, 0);
+	*pos_out = s.pos; *n_cigar = s.n_cigar; *nm = s.nm;
+	if (s.cigar) memcpy(cigar_out, s.cigar, 2 * s.n_cigar);
+	md_out[0] = 0;
+	if (s.md) { strncpy(md_out, s.md, md_cap - 1); md_out[md_cap - 1] = 0; }
+	free(s.seq); free(s.rseq); free(s.cigar); free(s.md);
+}
+
+int ref_pac2real(ref_index_t *ix, int64_t pac_coor, int len, int32_t *seqid, int64_t *offset)
+{
+	int nn = bns_coor_pac2real(ix->bns, pac_coor, len, seqid);
+	*offset = ix->bns->anns[*seqid].offset;
+	return nn;
+}

@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs oracle/_ref built by `make -C oracle ref`,
+which compiles the reference's own sources in place from /root/reference).
+Everything written here is *data*: a seeded synthetic genome, its index files as
+written by the reference's `index` command, seeded synthetic reads, and the
+reference's outputs for them (.sai from `aln`, SAM from `samse`, and function-level
+vectors for the rank / SA / DP primitives).  No reference source text is stored.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "bwa_ref")
+REFLIB = os.path.join(ROOT, "oracle", "_ref", "libbwaref.so")
+PREFIX = os.path.join(HERE, "toy")
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def make_genome(rng):
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    c1 = list(rnd(60000))
+    # exact 5 kb duplicate inside chr1, and a diverged (1 %) copy on chr2
+    dup = c1[5000:10000]
+    c1[30000:35000] = dup
+    c2 = list(rnd(40000))
+    div = list(dup[:2000])
+    for p in rng.choice(2000, 20, replace=False):
+        div[p] = "ACGT"[("ACGT".index(div[p]) + 1 + rng.integers(0, 3)) % 4]
+    c2[8000:10000] = div
+    # N run, short N, tandem repeats, homopolymer
+    c1[45000:45200] = "N" * 200
+    c1[52000:52003] = "NNN"
+    c1[20000:20300] = list("ACG" * 100)
+    c2[20000:20080] = "A" * 80
+    c2[25000:25400] = list("ACGTTGCA" * 50)
+    c2[30000:30001] = "N"
+    # a short third contig so that contig-bridging alignments exist
+    c3 = list(rnd(3000))
+    return [("chr1", "".join(c1)), ("chr2", "".join(c2)), ("chr3", "".join(c3))]
+
+
+def mutate(rng, s, n_sub=0, ins=0, dele=0, n_n=0, margin=8):
+    s = list(s)
+    L = len(s)
+    pos = rng.choice(np.arange(margin, L - margin), size=n_sub + n_n + (1 if ins else 0) + (1 if dele else 0),
+                     replace=False)
+    pos = list(pos)
+    for _ in range(n_sub):
+        p = pos.pop()
+        if s[p] in "ACGT":
+            s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + rng.integers(0, 3)) % 4]
+    for _ in range(n_n):
+        s[pos.pop()] = "N"
+    if ins:
+        p = pos.pop()
+        s[p:p] = list("".join("ACGT"[i] for i in rng.integers(0, 4, ins)))
+    if dele:
+        p = pos.pop()
+        del s[p:p + dele]
+    return "".join(s)
+
+
+def make_reads(rng, contigs):
+    g = {n: s for n, s in contigs}
+    cat = "".join(s for _, s in contigs)
+    reads = []
+
+    def sample(L, lo=0, hi=None, contig=None):
+        src = g[contig] if contig else cat
+        hi = (len(src) - L) if hi is None else hi
+        while True:
+            p = int(rng.integers(lo, hi))
+            w = src[p:p + L + 8]
+            if "N" not in w:
+                return w
+
+    def add(tag, s, qual=None):
+        if rng.integers(0, 2):
+            s = revcomp(s)
+            if qual:
+                qual = qual[::-1]
+        reads.append(("r%04d_%s" % (len(reads), tag), s, qual or "I" * len(s)))
+
+    for L, n in ((100, 60), (150, 12), (76, 12), (50, 12), (36, 8), (32, 6), (20, 4), (250, 4)):
+        for _ in range(n):
+            add("exact%d" % L, sample(L)[:L])
+    for k in (1, 2, 3, 4, 5, 6):
+        for _ in range(20):
+            add("sub%d" % k, mutate(rng, sample(100)[:100], n_sub=k))
+    for k in (1, 2, 3):
+        for _ in range(10):
+            add("sub%d_76" % k, mutate(rng, sample(76)[:76], n_sub=k))
+            add("sub%d_50" % k, mutate(rng, sample(50)[:50], n_sub=k))
+    for ins in (1, 2, 3, 5):
+        for _ in range(12):
+            add("ins%d" % ins, mutate(rng, sample(100)[:100], ins=ins, margin=12)[:100])
+    for d in (1, 2, 3, 5, 7):
+        for _ in range(12):
+            add("del%d" % d, mutate(rng, sample(100)[:100 + d], dele=d, margin=12))
+    for _ in range(20):
+        add("indelsub", mutate(rng, sample(100)[:101], n_sub=int(rng.integers(1, 3)), dele=1, margin=12))
+        add("inssub", mutate(rng, sample(100)[:100], n_sub=int(rng.integers(1, 3)), ins=1, margin=12)[:100])
+    for k in (1, 2, 3, 6):
+        for _ in range(6):
+            add("N%d" % k, mutate(rng, sample(100)[:100], n_n=k))
+    add("allN", "N" * 60)
+    add("halfN", "N" * 30 + sample(40)[:40])
+    # repeats: the exact duplicate, the diverged copy, tandem repeats, homopolymer
+    for _ in range(20):
+        p = int(rng.integers(5000, 9900))
+        add("dup", g["chr1"][p:p + 100])
+        add("dupsub", mutate(rng, g["chr1"][p:p + 100], n_sub=1))
+    for _ in range(10):
+        p = int(rng.integers(8000, 9900))
+        add("div", g["chr2"][p:p + 100])
+    for _ in range(6):
+        p = int(rng.integers(19950, 20250))
+        add("tandem3", g["chr1"][p:p + 100])
+        p = int(rng.integers(24950, 25350))
+        add("tandem8", g["chr2"][p:p + 100])
+        add("tandem8gap", mutate(rng, g["chr2"][25000 + int(rng.integers(0, 200)):][:101], dele=1, margin=20))
+    for _ in range(4):
+        p = int(rng.integers(19960, 20050))
+        add("polyA", g["chr2"][p:p + 60])
+    add("polyA70", "A" * 70)
+    # contig bridging, ends of the concatenated text, N-run overlap
+    l1 = len(g["chr1"])
+    for off in (50, 30, 70, 99, 1):
+        add("bridge", cat[l1 - off:l1 - off + 100])
+    add("start", cat[:100])
+    add("end", cat[-100:])
+    add("endsub", mutate(rng, cat[-100:], n_sub=2))
+    for off in (40, 80, 95):
+        add("nrun", g["chr1"][45000 - off:45000 - off + 100].replace("N", "A"))
+    # unmappable
+    for L in (100, 50, 36):
+        for _ in range(10):
+            add("random%d" % L, "".join("ACGT"[i] for i in rng.integers(0, 4, L)))
+    # low-quality tails for the trimming option set (-q 20)
+    for _ in range(20):
+        s = mutate(rng, sample(100)[:100], n_sub=int(rng.integers(0, 3)))
+        t = int(rng.integers(5, 50))
+        s = s[:100 - t] + "".join("ACGT"[i] for i in rng.integers(0, 4, t))
+        q = "I" * (100 - t) + "".join(chr(33 + int(x)) for x in rng.integers(2, 15, t))
+        reads.append(("r%04d_lowq%d" % (len(reads), t), s, q))
+    return reads
+
+
+OPTION_SETS = {
+    # name: (aln args, run samse?)
+    "default": ([], True),
+    "adna": (["-n", "0.01", "-o", "2", "-l", "16500"], True),
+    "n3": (["-n", "3"], False),
+    "e3": (["-e", "3", "-o", "2"], False),
+    "loggap": (["-L", "-o", "2", "-e", "8", "-d", "3"], False),
+    "k1R5": (["-k", "1", "-R", "5", "-l", "25"], False),
+    "i2": (["-i", "2", "-M", "2", "-O", "7", "-E", "3"], False),
+    "q20": (["-q", "20"], True),
+    "m64": (["-m", "64"], False),
+}
+NONSTOP_SUBSET = 120  # -N is slow; run it on the first reads only
+
+
+def run(cmd, stdout):
+    with open(stdout, "wb") as fo:
+        subprocess.run(cmd, check=True, stdout=fo, stderr=subprocess.DEVNULL)
+
+
+def main():
+    if not (os.path.exists(REFBIN) and os.path.exists(REFLIB)):
+        sys.exit("build the reference oracle first: make -C oracle ref")
+    rng = np.random.default_rng(20261004)
+    contigs = make_genome(rng)
+    with open(PREFIX + ".fa", "w") as f:
+        for n, s in contigs:
+            f.write(">%s synthetic\n" % n)
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+    subprocess.run([REFBIN, "index", "-a", "is", "-p", PREFIX, PREFIX + ".fa"], check=True,
+                   stderr=subprocess.DEVNULL)
+    for ext in (".rpac",):
+        if os.path.exists(PREFIX + ext):
+            os.remove(PREFIX + ext)
+    reads = make_reads(rng, contigs)
+    fq = os.path.join(HERE, "reads_se.fq")
+    with open(fq, "w") as f:
+        for n, s, q in reads:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, q))
+    fqn = os.path.join(HERE, "reads_se_head.fq")
+    with open(fqn, "w") as f:
+        for n, s, q in reads[:NONSTOP_SUBSET]:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, q))
+    for name, (args, sam) in OPTION_SETS.items():
+        sai = os.path.join(HERE, "se_%s.sai" % name)
+        run([REFBIN, "aln"] + args + [PREFIX, fq], sai)
+        if sam:
+            run([REFBIN, "samse", PREFIX, sai, fq], os.path.join(HERE, "se_%s.sam" % name))
+    run([REFBIN, "aln", "-N", PREFIX, fqn], os.path.join(HERE, "se_nonstop.sai"))
+
+    # ---- function-level vectors through the ctypes harness -------------------------------
+    lib = C.CDLL(REFLIB)
+    lib.ref_index_load.restype = C.c_void_p
+    lib.ref_index_load.argtypes = [C.c_char_p, C.c_int]
+    ix = C.c_void_p(lib.ref_index_load(PREFIX.encode(), 1))
+    lib.ref_seq_len.restype = C.c_uint32
+    lib.ref_seq_len.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_primary.restype = C.c_uint32
+    lib.ref_primary.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_occ.restype = C.c_uint32
+    lib.ref_occ.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
+    lib.ref_occ4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    lib.ref_2occ4.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.ref_sa.restype = C.c_uint32
+    lib.ref_sa.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    out = {}
+    for which in (0, 1):
+        n = lib.ref_seq_len(ix, which)
+        prim = lib.ref_primary(ix, which)
+        ks = np.concatenate([
+            np.array([0, 1, 2, 126, 127, 128, 129, 255, 256, prim - 1, prim, prim + 1, n - 2, n - 1, n,
+                      0xFFFFFFFF], dtype=np.uint64),
+            rng.integers(0, n + 1, 400).astype(np.uint64)]).astype(np.uint32)
+        occ = np.zeros((len(ks), 4), np.uint32)
+        occ4 = np.zeros((len(ks), 4), np.uint32)
+        buf = (C.c_uint32 * 4)()
+        for i, k in enumerate(ks):
+            for c in range(4):
+                occ[i, c] = lib.ref_occ(ix, which, int(k), c)
+            if k != n or True:
+                lib.ref_occ4(ix, which, int(k), buf)
+                occ4[i] = list(buf)
+        # pairs (k-1, l) as the search issues them, incl. k-1 == -1 and same-bucket cases
+        kk = rng.integers(0, n, 300).astype(np.uint64)
+        ll = np.minimum(kk + rng.integers(0, 300, 300).astype(np.uint64), n).astype(np.uint32)
+        km1 = (kk - 1).astype(np.uint32)  # wraps 0 -> 0xffffffff
+        ck = np.zeros((300, 4), np.uint32)
+        cl = np.zeros((300, 4), np.uint32)
+        b2 = (C.c_uint32 * 4)()
+        for i in range(300):
+            lib.ref_2occ4(ix, which, int(km1[i]), int(ll[i]), buf, b2)
+            ck[i] = list(buf)
+            cl[i] = list(b2)
+        sak = np.concatenate([np.array([1, 2, 31, 32, 33, prim, n], np.uint64),
+                              rng.integers(1, n + 1, 300).astype(np.uint64)]).astype(np.uint32)
+        sav = np.array([lib.ref_sa(ix, which, int(k)) for k in sak], np.uint32)
+        out.update({"occ_k%d" % which: ks, "occ_v%d" % which: occ, "occ4_v%d" % which: occ4,
+                    "p_k%d" % which: km1, "p_l%d" % which: ll, "p_ck%d" % which: ck, "p_cl%d" % which: cl,
+                    "sa_k%d" % which: sak, "sa_v%d" % which: sav,
+                    "seq_len%d" % which: np.uint32(n), "primary%d" % which: np.uint32(prim)})
+    lib.ref_maxdiff.restype = C.c_int
+    lib.ref_maxdiff.argtypes = [C.c_int, C.c_double, C.c_double]
+    Ls = np.arange(1, 400)
+    out["maxdiff_004"] = np.array([lib.ref_maxdiff(int(l), 0.02, 0.04) for l in Ls], np.int32)
+    out["maxdiff_001"] = np.array([lib.ref_maxdiff(int(l), 0.02, 0.01) for l in Ls], np.int32)
+
+    # ---- DP vectors: aln_global_core under aln_param_bwa-like and blast-like blocks ------
+    lib.ref_global.restype = C.c_int
+    sm_maq = np.array([11, -19, -19, -19, -13, -19, 11, -19, -19, -13, -19, -19, 11, -19, -13,
+                       -19, -19, -19, 11, -13, -13, -13, -13, -13, -13], np.int32)
+    sm_blast = np.array([1, -3, -3, -3, -2, -3, 1, -3, -3, -2, -3, -3, 1, -3, -2,
+                         -3, -3, -3, 1, -2, -2, -2, -2, -2, -2], np.int32)
+    params = [(26, 9, 5, sm_maq, 50), (26, 9, -1, sm_maq, 50), (5, 2, 2, sm_blast, 50),
+              (26, 9, 5, sm_maq, 6), (8, 2, 2, sm_blast, 3)]
+    dp_rows = []
+    cases = []
+    for t in range(260):
+        l2 = int(rng.integers(1, 140))
+        q = rng.integers(0, 4, l2).astype(np.uint8)
+        r = list(q)
+        # derive the reference window from the query with a few edits
+        for _ in range(int(rng.integers(0, 4))):
+            if len(r) > 2:
+                r[int(rng.integers(0, len(r)))] = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 6))
+        if kind == 1 and len(r) > 12:
+            p = int(rng.integers(4, len(r) - 4)); d = int(rng.integers(1, 8)); del r[p:p + d]
+        elif kind == 2:
+            p = int(rng.integers(0, len(r) + 1)); d = int(rng.integers(1, 8))
+            r[p:p] = list(rng.integers(0, 4, d))
+        elif kind == 3:
+            r = list(rng.integers(0, 4, int(rng.integers(1, 150))))
+        elif kind == 4:
+            r = r + list(rng.integers(0, 4, int(rng.integers(1, 70))))
+        if not r:
+            r = [0]
+        if rng.integers(0, 8) == 0:
+            r[int(rng.integers(0, len(r)))] = 4
+        if rng.integers(0, 8) == 0:
+            q[int(rng.integers(0, l2))] = 4
+        r = np.array(r, np.uint8)
+        cases.append((r, q, params[t % len(params)], t % len(params)))
+    cig = (C.c_uint32 * 1024)()
+    ncig = C.c_int()
+    plen = C.c_int()
+    for r, q, (go, ge, gend, sm, band), pid in cases:
+        sc = lib.ref_global(r.ctypes.data_as(C.c_void_p), len(r), q.ctypes.data_as(C.c_void_p), len(q),
+                            go, ge, gend, sm.ctypes.data_as(C.c_void_p), 5, band, cig, C.byref(ncig), None,
+                            C.byref(plen))
+        dp_rows.append((r, q, pid, sc, np.array(cig[:ncig.value], np.uint32)))
+    out["dp_n"] = np.int32(len(dp_rows))
+    out["dp_ref"] = np.concatenate([x[0] for x in dp_rows])
+    out["dp_ref_off"] = np.cumsum([0] + [len(x[0]) for x in dp_rows]).astype(np.int64)
+    out["dp_qry"] = np.concatenate([x[1] for x in dp_rows])
+    out["dp_qry_off"] = np.cumsum([0] + [len(x[1]) for x in dp_rows]).astype(np.int64)
+    out["dp_pid"] = np.array([x[2] for x in dp_rows], np.int32)
+    out["dp_score"] = np.array([x[3] for x in dp_rows], np.int32)
+    out["dp_cig"] = np.concatenate([x[4] for x in dp_rows])
+    out["dp_cig_off"] = np.cumsum([0] + [len(x[4]) for x in dp_rows]).astype(np.int64)
+    out["dp_params"] = np.array([[p[0], p[1], p[2], p[4], 0 if p[3] is sm_maq else 1] for p in params], np.int32)
+    np.savez_compressed(os.path.join(HERE, "vectors.npz"), **out)
+    print("golden fixtures written to", HERE, "reads:", len(reads))
+
+
+if __name__ == "__main__":
+    main()
