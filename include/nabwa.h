@@ -1,0 +1,114 @@
+/* include/nabwa.h -- C ABI of libnabwa.so: the MI355X-native per-read alignment hot path of
+ * mpieva/network-aware-bwa, as a drop-in behind the functions `bwa bam2bam` / `bwa worker`
+ * call per record.  Plain pointers and sizes only.
+ *
+ * All entry points return 0 on success or a negative NABWA_E* code; none falls back to a
+ * CPU implementation: without a usable GPU they fail with NABWA_ENODEV.
+ *
+ * The reference has no FFI/plugin layer (it is one static binary), so the "binding" a
+ * maintainer adds is a direct call from bam2bam.c -- shown in INTEGRATION.md.
+ */
+#ifndef NABWA_H
+#define NABWA_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NABWA_OK        0
+#define NABWA_ENODEV   -1   /* no HIP device / HIP call failed (message via nabwa_last_error) */
+#define NABWA_EINVAL   -2   /* bad argument or unsupported option block */
+#define NABWA_EIO      -3   /* index file missing / malformed */
+#define NABWA_ENOMEM   -4
+#define NABWA_ECAP     -5   /* caller-provided output capacity too small */
+
+/* gap_opt_t -- identical layout to the reference's (bwtaln.h:143-153, 64 bytes); it is the
+ * block `bwa worker` receives over the wire (bam2bam.c:1260-1263). */
+typedef struct {
+	int s_mm, s_gapo, s_gape;
+	int mode;
+	int indel_end_skip, max_del_occ, max_entries;
+	float fnr;
+	int max_diff, max_gapo, max_gape;
+	int max_seed_diff, seed_len;
+	int n_threads;
+	int max_top2;
+	int trim_qual;
+} nabwa_gap_opt_t;
+
+#define NABWA_MODE_GAPE     0x01   /* BWA_MODE_* bits, bwtaln.h:132-141 */
+#define NABWA_MODE_COMPREAD 0x02
+#define NABWA_MODE_LOGGAP   0x04
+#define NABWA_MODE_NONSTOP  0x10
+
+/* bwt_aln1_t -- identical layout (bwtaln.h:41-45, 16 bytes): {n_mm:8,n_gapo:8,n_gape:8,a:1}, k, l, score */
+typedef struct { uint32_t info; uint32_t k, l; int32_t score; } nabwa_aln1_t;
+
+typedef struct nabwa_index nabwa_index_t;   /* both FM-indexes (+SA, +pac) resident in HBM */
+
+const char *nabwa_last_error(void);
+int nabwa_device_count(void);
+
+/* gap_init_opt (bwtaln.c:19-35) */
+void nabwa_gap_init_opt(nabwa_gap_opt_t *opt);
+/* bwa_cal_maxdiff (bwtaln.c:37-49); host-side floating point, kept bit-compatible */
+int nabwa_cal_maxdiff(int len, double err, double thres);
+
+/* Replaces init_genome_index (bam2bam.c:844-858): reads <prefix>.bwt/.rbwt (and .sa/.rsa when
+ * with_sa, .pac when with_pac) in the reference's on-disk format (bwtio.c:161-204), uploads them
+ * to `device` and re-packs the Occ arrays into 64-byte buckets there. */
+int nabwa_index_load(const char *prefix, int device, int with_sa, int with_pac, nabwa_index_t **out);
+
+/* Same, from arrays already in memory (is_device != 0: device pointers on `device`).
+ * bwt0/bwt1: the content of a .bwt/.rbwt file as u32 words (5 header words + Occ-interleaved BWT).
+ * sa0/sa1: content of .sa/.rsa files as u32 words (7 header words + samples), or NULL. */
+int nabwa_index_from_arrays(int device, int is_device, const uint32_t *bwt0, uint64_t n_words0,
+							const uint32_t *bwt1, uint64_t n_words1, const uint32_t *sa0, uint64_t n_sa_words0,
+							const uint32_t *sa1, uint64_t n_sa_words1, nabwa_index_t **out);
+void nabwa_index_destroy(nabwa_index_t *ix);
+uint32_t nabwa_index_seq_len(const nabwa_index_t *ix, int which);
+uint64_t nabwa_index_device_bytes(const nabwa_index_t *ix);
+
+/* Batch form of bwa_cal_sa_reg_gap (bwtaln.c:93-142; callers bam2bam.c:616,676, bwtaln.c:235).
+ *  seq/rseq : concatenated bwa_seq_t.seq / .rseq codes (0-3, 4=N) of n reads; off[i]..off[i+1]
+ *             delimit read i (seq = read reversed, rseq = its reverse complement, bwaseqio.c:294-297).
+ *  per_read : !=0 gives every read the option block the reference derives when called with
+ *             n_seqs==1 (bam2bam); 0 derives it once from the longest read of the batch (bwa aln).
+ *  n_aln[i], max_entries[i] : as bwa_seq_t.n_aln / .max_entries.
+ *  aln_out  : rows of all reads back to back in read order (capacity aln_cap rows);
+ *             *n_rows receives the total.  NABWA_ECAP if aln_cap is too small (n_aln[] is still valid). */
+int nabwa_cal_sa_reg_gap(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off,
+						 const uint8_t *seq, const uint8_t *rseq, int per_read,
+						 int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
+						 int32_t *max_entries);
+
+/* Device-resident variant for pipelines and for bench.py: upload once, run many times.
+ * A batch owns the device copies of the reads, the per-lane search scratch and the outputs. */
+typedef struct nabwa_batch nabwa_batch_t;
+int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off,
+					   const uint8_t *seq, const uint8_t *rseq, int per_read, nabwa_batch_t **out);
+/* enqueue the FM search of the whole batch on the batch's HIP stream (asynchronous) */
+int nabwa_batch_run(nabwa_batch_t *b);
+/* wait for completion; returns the number of reads that needed the large-arena second pass */
+int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass);
+/* HIP-event time of the most recent run of the dominant kernel (fm_search, first pass), ms */
+float nabwa_batch_last_kernel_ms(nabwa_batch_t *b);
+int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
+					  int32_t *max_entries);
+/* order-independent 64-bit checksum of (read id, row index, row) over all hits, computed on the device */
+int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows);
+void nabwa_batch_destroy(nabwa_batch_t *b);
+
+/* Batch form of bwt_sa (bwt.c:72-81; callers bam2bam.c:635-636,752,761,786, bwase.c:146,151):
+ * sa_out[i] = SA value of row k[i] in index `which[i]` (0 forward, 1 reversed text). */
+int nabwa_sa_lookup(nabwa_index_t *ix, int n, const uint8_t *which, const uint32_t *k, uint32_t *sa_out);
+
+/* Rank primitives for tests: Occ of all four bases at rows k[i] (bwt_occ4, bwt.c:159-176). */
+int nabwa_occ4(nabwa_index_t *ix, int which, int n, const uint32_t *k, uint32_t *cnt_out /* n x 4 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

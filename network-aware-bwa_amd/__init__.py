@@ -1,0 +1,227 @@
+"""network-aware-bwa_amd -- MI355X-native per-read alignment hot path of mpieva/network-aware-bwa.
+
+This package is only the thin Python face (ctypes) of ``libnabwa.so`` -- the C-ABI library declared
+in ``include/nabwa.h`` whose HIP kernels do the work.  It mirrors the reference's own operator
+interface for the path (``bwa_cal_sa_reg_gap``, ``bwt_sa``; reference bwtaln.h:187, bwt.h:100) in
+flat-array form.  There is no CPU fallback: if the library or a GPU is missing, calls raise.
+
+The directory name contains a hyphen; import it with
+``importlib.import_module("network-aware-bwa_amd")``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnabwa.so")
+
+OK, ENODEV, EINVAL, EIO, ENOMEM, ECAP = 0, -1, -2, -3, -4, -5
+
+ALN_DT = np.dtype([("info", "<u4"), ("k", "<u4"), ("l", "<u4"), ("score", "<i4")])  # bwt_aln1_t, bwtaln.h:41-45
+
+
+class GapOpt(C.Structure):
+    """gap_opt_t (reference bwtaln.h:143-153), 64 bytes."""
+    _fields_ = [("s_mm", C.c_int), ("s_gapo", C.c_int), ("s_gape", C.c_int), ("mode", C.c_int),
+                ("indel_end_skip", C.c_int), ("max_del_occ", C.c_int), ("max_entries", C.c_int),
+                ("fnr", C.c_float), ("max_diff", C.c_int), ("max_gapo", C.c_int), ("max_gape", C.c_int),
+                ("max_seed_diff", C.c_int), ("seed_len", C.c_int), ("n_threads", C.c_int),
+                ("max_top2", C.c_int), ("trim_qual", C.c_int)]
+
+
+class NabwaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libnabwa error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile libnabwa.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libnabwa.so failed:\n%s\n%s" % (r.stdout, r.stderr))
+
+
+_lib = None
+_P = C.c_void_p
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built -- there is no other implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libnabwa.so is missing (%s): run __graft_entry__.build() / make -C %s"
+                           % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    L = C.CDLL(LIB_PATH)
+    L.nabwa_last_error.restype = C.c_char_p
+    L.nabwa_device_count.restype = C.c_int
+    L.nabwa_gap_init_opt.argtypes = [_P]
+    L.nabwa_cal_maxdiff.restype = C.c_int
+    L.nabwa_cal_maxdiff.argtypes = [C.c_int, C.c_double, C.c_double]
+    L.nabwa_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, _P]
+    L.nabwa_index_from_arrays.argtypes = [C.c_int, C.c_int, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P,
+                                          C.c_uint64, _P]
+    L.nabwa_index_destroy.argtypes = [_P]
+    L.nabwa_index_destroy.restype = None
+    L.nabwa_index_seq_len.restype = C.c_uint32
+    L.nabwa_index_seq_len.argtypes = [_P, C.c_int]
+    L.nabwa_index_device_bytes.restype = C.c_uint64
+    L.nabwa_index_device_bytes.argtypes = [_P]
+    L.nabwa_cal_sa_reg_gap.argtypes = [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int64, _P, _P]
+    L.nabwa_batch_create.argtypes = [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P]
+    L.nabwa_batch_run.argtypes = [_P]
+    L.nabwa_batch_sync.argtypes = [_P, _P]
+    L.nabwa_batch_last_kernel_ms.restype = C.c_float
+    L.nabwa_batch_last_kernel_ms.argtypes = [_P]
+    L.nabwa_batch_fetch.argtypes = [_P, _P, _P, C.c_int64, _P, _P]
+    L.nabwa_batch_checksum.argtypes = [_P, _P, _P]
+    L.nabwa_batch_destroy.argtypes = [_P]
+    L.nabwa_batch_destroy.restype = None
+    L.nabwa_sa_lookup.argtypes = [_P, C.c_int, _P, _P, _P]
+    L.nabwa_occ4.argtypes = [_P, C.c_int, C.c_int, _P, _P]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != OK:
+        raise NabwaError(rc, lib().nabwa_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_P) if a is not None else None
+
+
+def gap_init_opt():
+    """gap_init_opt (reference bwtaln.c:19-35)."""
+    o = GapOpt()
+    lib().nabwa_gap_init_opt(C.byref(o))
+    return o
+
+
+def cal_maxdiff(length, err=0.02, thres=0.04):
+    """bwa_cal_maxdiff (reference bwtaln.c:37-49)."""
+    return lib().nabwa_cal_maxdiff(int(length), float(err), float(thres))
+
+
+class Index:
+    """Both FM-indexes (forward and reversed text) resident in HBM; replaces the globals set up by
+    init_genome_index (reference bam2bam.c:844-858)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, prefix, device=0, with_sa=True):
+        h = _P()
+        _chk(lib().nabwa_index_load(prefix.encode(), device, int(with_sa), 0, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, bwt0, bwt1, sa0=None, sa1=None, device=0, device_ptrs=False):
+        """bwt0/bwt1: .bwt/.rbwt file content as uint32 words (numpy arrays, or (ptr, n_words) tuples of
+        device memory when device_ptrs)."""
+        h = _P()
+
+        def pn(x):
+            if x is None:
+                return None, 0
+            if isinstance(x, tuple):
+                return C.c_void_p(x[0]), int(x[1])
+            return _ptr(x), x.size
+        p0, n0 = pn(bwt0)
+        p1, n1 = pn(bwt1)
+        s0, m0 = pn(sa0)
+        s1, m1 = pn(sa1)
+        _chk(lib().nabwa_index_from_arrays(device, int(device_ptrs), p0, n0, p1, n1, s0, m0, s1, m1, C.byref(h)))
+        return cls(h)
+
+    def seq_len(self, which=0):
+        return lib().nabwa_index_seq_len(self._h, which)
+
+    def device_bytes(self):
+        return lib().nabwa_index_device_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            lib().nabwa_index_destroy(self._h)
+            self._h = None
+
+    def sa_lookup(self, which, k):
+        """bwt_sa (reference bwt.c:72-81) for many rows."""
+        which = np.ascontiguousarray(which, np.uint8)
+        k = np.ascontiguousarray(k, np.uint32)
+        out = np.zeros(len(k), np.uint32)
+        _chk(lib().nabwa_sa_lookup(self._h, len(k), _ptr(which), _ptr(k), _ptr(out)))
+        return out
+
+    def occ4(self, which, k):
+        """bwt_occ4 (reference bwt.c:159-176) for many rows."""
+        k = np.ascontiguousarray(k, np.uint32)
+        out = np.zeros((len(k), 4), np.uint32)
+        _chk(lib().nabwa_occ4(self._h, which, len(k), _ptr(k), _ptr(out)))
+        return out
+
+    def cal_sa_reg_gap(self, opt, seq, rseq, off, per_read=False):
+        """bwa_cal_sa_reg_gap (reference bwtaln.c:93-142) over a flat batch.
+        Returns (list of per-read hit arrays, max_entries)."""
+        b = Batch(self, opt, seq, rseq, off, per_read)
+        try:
+            b.run()
+            b.sync()
+            return b.fetch()
+        finally:
+            b.close()
+
+
+class Batch:
+    """Device-resident batch of reads: upload once, run the FM search many times."""
+
+    def __init__(self, index, opt, seq, rseq, off, per_read=False):
+        self.n = len(off) - 1
+        self._seq = np.ascontiguousarray(seq, np.uint8)
+        self._rseq = np.ascontiguousarray(rseq, np.uint8)
+        self._off = np.ascontiguousarray(off, np.int64)
+        self._h = _P()
+        _chk(lib().nabwa_batch_create(index._h, C.byref(opt), self.n, _ptr(self._off), _ptr(self._seq),
+                                      _ptr(self._rseq), int(per_read), C.byref(self._h)))
+
+    def run(self):
+        _chk(lib().nabwa_batch_run(self._h))
+
+    def sync(self):
+        n2 = C.c_int()
+        _chk(lib().nabwa_batch_sync(self._h, C.byref(n2)))
+        return n2.value
+
+    def last_kernel_ms(self):
+        return float(lib().nabwa_batch_last_kernel_ms(self._h))
+
+    def checksum(self):
+        s = C.c_uint64()
+        r = C.c_int64()
+        _chk(lib().nabwa_batch_checksum(self._h, C.byref(s), C.byref(r)))
+        return s.value, r.value
+
+    def fetch(self):
+        n_aln = np.zeros(max(self.n, 1), np.int32)
+        maxe = np.zeros(max(self.n, 1), np.int32)
+        rows = C.c_int64()
+        rc = lib().nabwa_batch_fetch(self._h, _ptr(n_aln), None, 0, C.byref(rows), _ptr(maxe))
+        if rc not in (OK, ECAP):
+            _chk(rc)
+        buf = np.zeros(max(rows.value, 1), ALN_DT)
+        if rows.value:
+            _chk(lib().nabwa_batch_fetch(self._h, _ptr(n_aln), _ptr(buf), rows.value, C.byref(rows), _ptr(maxe)))
+        n_aln = n_aln[:self.n]
+        bounds = np.concatenate([[0], np.cumsum(n_aln)])
+        return [buf[bounds[i]:bounds[i + 1]] for i in range(self.n)], maxe[:self.n]
+
+    def close(self):
+        if self._h:
+            lib().nabwa_batch_destroy(self._h)
+            self._h = None

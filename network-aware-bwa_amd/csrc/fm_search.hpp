@@ -1,0 +1,31 @@
+// fm_search.hpp -- parameter block shared by the search kernel and the host API.
+#pragma once
+#include <stdint.h>
+#include "nabwa_dev.hpp"
+
+#define NABWA_SEARCH_BLOCK 256
+#define NABWA_ST_OK        0
+#define NABWA_ST_OVERFLOW  1   // arena or hit list outgrown in the first pass: re-run in the wide pass
+
+struct SearchParams {
+	DevBwt bwt[2];
+	// reads (device): codes 0-3, 4 = N; seq = read reversed, rseq = reverse complement
+	const uint8_t *seq, *rseq;
+	const int64_t *off;
+	const uint8_t *rd_maxdiff, *rd_maxgapo;   // per read: max_diff and clamped max_gapo (host-side FP, bwtaln.c:104-105,125)
+	const int32_t *ids;                       // work item -> read id (wide pass), or null
+	int n;
+	// gap_opt_t fields that are uniform over the batch
+	int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries, max_gape, max_seed_diff, seed_len, max_top2;
+	// per-lane scratch
+	uint8_t *scratch;
+	size_t lane_stride;
+	uint32_t off_link, off_free, off_head, off_w, off_sw, off_bid, off_sbid;
+	uint32_t cap, WL, SL, NS;
+	// outputs, indexed by work item
+	int32_t *n_aln, *max_ent;
+	uint8_t *status;
+	uint4 *aln;
+	int aln_cap;
+	unsigned int *work_counter;
+};

@@ -1,0 +1,500 @@
+// nabwa_api.hip -- host side of libnabwa.so: the C ABI declared in include/nabwa.h.
+// Plain HIP runtime calls; no torch, no CPU fallback of the compute path.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include "../../include/nabwa.h"
+#include "fm_search.hpp"
+
+extern "C" {
+void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets, uint4 *out, hipStream_t s);
+void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
+void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uint32_t *out, hipStream_t s);
+void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s);
+void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
+						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
+						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
+void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, hipStream_t s);
+void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
+							   const uint8_t *status2, int32_t *n_aln, int32_t *max_ent, uint8_t *status,
+							   int32_t *wide_idx, hipStream_t s);
+void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, const uint4 *aln, int aln_cap,
+						 const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
+						 uint4 *out, hipStream_t s);
+int nabwa_search_occupancy(int wide);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, const char *a = "")
+{
+	char buf[512]; snprintf(buf, sizeof buf, fmt, a); g_err = buf; return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+	char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+	g_err = b_; return NABWA_ENODEV; } } while (0)
+
+extern "C" const char *nabwa_last_error(void) { return g_err.c_str(); }
+
+extern "C" int nabwa_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" void nabwa_gap_init_opt(nabwa_gap_opt_t *o)   /* gap_init_opt, bwtaln.c:19-35 */
+{
+	memset(o, 0, sizeof(*o));
+	o->s_mm = 3; o->s_gapo = 11; o->s_gape = 4;
+	o->max_diff = -1; o->max_gapo = 1; o->max_gape = 6;
+	o->indel_end_skip = 5; o->max_del_occ = 10; o->max_entries = 2000000;
+	o->mode = NABWA_MODE_GAPE | NABWA_MODE_COMPREAD;
+	o->seed_len = 32; o->max_seed_diff = 2;
+	o->fnr = 0.04f; o->n_threads = 1; o->max_top2 = 30; o->trim_qual = 0;
+}
+
+/* bwa_cal_maxdiff (bwtaln.c:37-49): Poisson tail with the reference's int factorial, which
+ * wraps past 12!; evaluated on the host in double, same expression order. */
+extern "C" int nabwa_cal_maxdiff(int l, double err, double thres)
+{
+	double elambda = exp(-l * err), sum = elambda, y = 1.0;
+	uint32_t x = 1;
+	for (int k = 1; k < 1000; ++k) {
+		y *= l * err;
+		x *= (uint32_t)k;
+		sum += elambda * y / (int32_t)x;
+		if (1.0 - sum < thres) return k;
+	}
+	return 2;
+}
+
+/* ------------------------------------------------------------------ index */
+
+struct nabwa_index {
+	int device;
+	DevBwt bwt[2];
+	uint4 *bk[2];
+	uint32_t *sa[2];
+	uint64_t bytes;
+};
+
+static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_words, bool on_device,
+					 const uint32_t *sa_words, uint64_t n_sa_words)
+{
+	uint32_t hdr[5];
+	if (n_words < 5) return fail(NABWA_EIO, "bwt array too short");
+	if (on_device) HIPCHK(hipMemcpy(hdr, words, 20, hipMemcpyDeviceToHost)); else memcpy(hdr, words, 20);
+	DevBwt &B = ix->bwt[t];
+	memset(&B, 0, sizeof(B));
+	B.primary = hdr[0]; B.L2[0] = 0; B.L2[1] = hdr[1]; B.L2[2] = hdr[2]; B.L2[3] = hdr[3]; B.seq_len = hdr[4];
+	const uint64_t expect = ((uint64_t)B.seq_len + 127) / 128 * 8 + (((uint64_t)B.seq_len + 127) / 128 + 1) * 4;
+	if (n_words - 5 < expect) return fail(NABWA_EIO, "bwt array shorter than its seq_len implies");
+	B.n_buckets = (uint32_t)(((uint64_t)B.seq_len + NABWA_INTV - 1) / NABWA_INTV);
+	uint32_t *raw = 0;
+	const uint32_t *src = words + 5;
+	if (!on_device) {
+		HIPCHK(hipMalloc(&raw, (n_words - 5) * 4));
+		HIPCHK(hipMemcpy(raw, words + 5, (n_words - 5) * 4, hipMemcpyHostToDevice));
+		src = raw;
+	}
+	HIPCHK(hipMalloc(&ix->bk[t], (size_t)B.n_buckets * 64));
+	nabwa_launch_repack(src, B.seq_len, B.n_buckets, ix->bk[t], 0);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipDeviceSynchronize());
+	if (raw) HIPCHK(hipFree(raw));
+	B.bk = ix->bk[t];
+	ix->bytes += (uint64_t)B.n_buckets * 64;
+	if (sa_words) {
+		uint32_t sh[7];
+		if (n_sa_words < 7) return fail(NABWA_EIO, "sa array too short");
+		if (on_device) HIPCHK(hipMemcpy(sh, sa_words, 28, hipMemcpyDeviceToHost)); else memcpy(sh, sa_words, 28);
+		if (sh[0] != B.primary || sh[6] != B.seq_len) return fail(NABWA_EIO, "SA-BWT inconsistency");   /* bwtio.c:169,173 */
+		B.sa_intv = sh[5];
+		B.n_sa = (uint32_t)(((uint64_t)B.seq_len + B.sa_intv) / B.sa_intv);
+		if (n_sa_words - 7 < (uint64_t)B.n_sa - 1) return fail(NABWA_EIO, "sa array shorter than n_sa");
+		HIPCHK(hipMalloc(&ix->sa[t], (size_t)B.n_sa * 4));
+		HIPCHK(hipMemset(ix->sa[t], 0xff, 4));
+		HIPCHK(hipMemcpy(ix->sa[t] + 1, sa_words + 7, (size_t)(B.n_sa - 1) * 4,
+						 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+		B.sa = ix->sa[t];
+		ix->bytes += (uint64_t)B.n_sa * 4;
+	}
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t *bwt0, uint64_t nw0,
+									   const uint32_t *bwt1, uint64_t nw1, const uint32_t *sa0, uint64_t ns0,
+									   const uint32_t *sa1, uint64_t ns1, nabwa_index_t **out)
+{
+	if (!out || !bwt0 || !bwt1) return fail(NABWA_EINVAL, "null argument");
+	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
+	HIPCHK(hipSetDevice(device));
+	nabwa_index *ix = new nabwa_index();
+	memset(ix, 0, sizeof(*ix));
+	ix->device = device;
+	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
+	if (r == NABWA_OK) r = build_one(ix, 1, bwt1, nw1, is_device != 0, sa1, ns1);
+	if (r != NABWA_OK) { nabwa_index_destroy(ix); return r; }
+	*out = ix;
+	return NABWA_OK;
+}
+
+static bool slurp(const std::string &fn, std::vector<uint32_t> &v)
+{
+	FILE *f = fopen(fn.c_str(), "rb");
+	if (!f) return false;
+	fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+	v.resize((n + 3) / 4);
+	bool ok = fread(v.data(), 1, n, f) == (size_t)n;
+	fclose(f);
+	return ok;
+}
+
+extern "C" int nabwa_index_load(const char *prefix, int device, int with_sa, int with_pac, nabwa_index_t **out)
+{
+	(void)with_pac;
+	if (!prefix || !out) return fail(NABWA_EINVAL, "null argument");
+	std::vector<uint32_t> b0, b1, s0, s1;
+	std::string p(prefix);
+	if (!slurp(p + ".bwt", b0)) return fail(NABWA_EIO, "cannot read %s.bwt", prefix);
+	if (!slurp(p + ".rbwt", b1)) return fail(NABWA_EIO, "cannot read %s.rbwt", prefix);
+	if (with_sa) {
+		if (!slurp(p + ".sa", s0)) return fail(NABWA_EIO, "cannot read %s.sa", prefix);
+		if (!slurp(p + ".rsa", s1)) return fail(NABWA_EIO, "cannot read %s.rsa", prefix);
+	}
+	return nabwa_index_from_arrays(device, 0, b0.data(), b0.size(), b1.data(), b1.size(),
+								   with_sa ? s0.data() : 0, s0.size(), with_sa ? s1.data() : 0, s1.size(), out);
+}
+
+extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
+{
+	if (!ix) return;
+	(void)hipSetDevice(ix->device);
+	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); }
+	delete ix;
+}
+
+extern "C" uint32_t nabwa_index_seq_len(const nabwa_index_t *ix, int which) { return ix->bwt[which & 1].seq_len; }
+extern "C" uint64_t nabwa_index_device_bytes(const nabwa_index_t *ix) { return ix->bytes; }
+
+/* ------------------------------------------------------------------ batch */
+
+struct nabwa_batch {
+	nabwa_index *ix;
+	nabwa_gap_opt_t opt;
+	int n;
+	hipStream_t stream;
+	hipEvent_t ev0, ev1;
+	float last_ms;
+	// device inputs
+	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_off;
+	// first pass
+	SearchParams P; int n_blocks; uint8_t *d_scratch;
+	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
+	unsigned int *d_counter, *d_novf; int32_t *d_ovf_ids;
+	// wide pass (allocated on demand)
+	int n2, aln_cap2; uint8_t *d_scratch2; int32_t *d_naln2, *d_maxent2; uint8_t *d_status2; uint4 *d_aln2;
+	int unresolved;
+	unsigned long long *d_sum;
+};
+
+static int env_int(const char *name, int dflt)
+{
+	const char *s = getenv(name);
+	return s && *s ? atoi(s) : dflt;
+}
+
+static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+static void layout(SearchParams &P, uint32_t cap, uint32_t link_bytes, bool reuse, int max_len, int seed_len, uint32_t NS)
+{
+	P.cap = cap;
+	P.WL = align_up((uint32_t)max_len + 1, 4);
+	P.SL = align_up((uint32_t)seed_len + 1, 4);
+	P.NS = NS;
+	uint32_t o = cap * 16;
+	P.off_link = o; o = align_up(o + cap * link_bytes, 16);
+	P.off_free = o; if (reuse) o = align_up(o + cap * link_bytes, 16);
+	P.off_head = o; o = align_up(o + NS * link_bytes, 16);
+	P.off_w = o; o += 2 * P.WL * 4;
+	P.off_sw = o; o += 2 * P.SL * 4;
+	P.off_bid = o; o += 2 * P.WL;
+	P.off_sbid = o; o += 2 * P.SL;
+	P.lane_stride = align_up(o, 64);
+}
+
+extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
+{
+	if (!b) return;
+	(void)hipSetDevice(b->ix->device);
+	void *ptrs[] = { b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_off, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
+					 b->d_status2, b->d_aln2, b->d_sum };
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	if (b->ev0) (void)hipEventDestroy(b->ev0);
+	if (b->ev1) (void)hipEventDestroy(b->ev1);
+	if (b->stream) (void)hipStreamDestroy(b->stream);
+	delete b;
+}
+
+#define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+	char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+	g_err = b_; nabwa_batch_destroy(b); return NABWA_ENODEV; } } while (0)
+
+extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off,
+								  const uint8_t *seq, const uint8_t *rseq, int per_read, nabwa_batch_t **out)
+{
+	if (!ix || !opt || !off || !out || n < 0 || (n && (!seq || !rseq))) return fail(NABWA_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(ix->device));
+	// ---- per-read option derivation, on the host in double (bwtaln.c:102-106,125)
+	int max_len = 0;
+	for (int i = 0; i < n; ++i) {
+		const int64_t L = off[i + 1] - off[i];
+		if (L < 0 || L > 65535) return fail(NABWA_EINVAL, "read length outside 0..65535");
+		if (L > max_len) max_len = (int)L;
+	}
+	std::vector<int> md_of(max_len + 1, opt->max_diff);
+	if (opt->fnr > 0.0f) for (int L = 0; L <= max_len; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
+	std::vector<uint8_t> md(n ? n : 1), mg(n ? n : 1);
+	uint32_t NS = 1;
+	for (int i = 0; i < n; ++i) {
+		const int L = (int)(off[i + 1] - off[i]);
+		const int md_sizing = md_of[per_read ? L : max_len];
+		int g = opt->max_gapo; if (md_sizing < g) g = md_sizing;
+		const int d = md_of[L];
+		if (d < 0 || d > 254 || g < 0 || g > 254) return fail(NABWA_EINVAL, "max_diff / max_gapo outside 0..254");
+		md[i] = (uint8_t)d; mg[i] = (uint8_t)g;
+		const long ns = (long)(md_sizing + 1) * opt->s_mm + (long)(g + 1) * opt->s_gapo + (long)(opt->max_gape + 1) * opt->s_gape;
+		if (ns > (long)NS) NS = (uint32_t)ns;
+	}
+	if (NS > 128 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 254)
+		return fail(NABWA_EINVAL, "option block needs more than 128 score levels (unsupported)");
+	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
+
+	nabwa_batch *b = new nabwa_batch();
+	memset(b, 0, sizeof(*b));
+	b->ix = ix; b->opt = *opt; b->n = n;
+	BCHK(hipStreamCreate(&b->stream));
+	BCHK(hipEventCreate(&b->ev0));
+	BCHK(hipEventCreate(&b->ev1));
+	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1;
+	BCHK(hipMalloc(&b->d_seq, nb)); BCHK(hipMalloc(&b->d_rseq, nb));
+	BCHK(hipMalloc(&b->d_off, (size_t)(n + 1) * 8));
+	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1));
+	if (n) {
+		BCHK(hipMemcpy(b->d_seq, seq, (size_t)off[n], hipMemcpyHostToDevice));
+		BCHK(hipMemcpy(b->d_rseq, rseq, (size_t)off[n], hipMemcpyHostToDevice));
+		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));
+		BCHK(hipMemcpy(b->d_mg, mg.data(), n, hipMemcpyHostToDevice));
+	}
+	BCHK(hipMemcpy(b->d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+
+	SearchParams &P = b->P;
+	memset(&P, 0, sizeof(P));
+	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
+	P.seq = b->d_seq; P.rseq = b->d_rseq; P.off = b->d_off; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg;
+	P.ids = 0; P.n = n;
+	P.s_mm = opt->s_mm; P.s_gapo = opt->s_gapo; P.s_gape = opt->s_gape; P.mode = opt->mode;
+	P.indel_end_skip = opt->indel_end_skip; P.max_del_occ = opt->max_del_occ; P.max_entries = opt->max_entries;
+	P.max_gape = opt->max_gape; P.max_seed_diff = opt->max_seed_diff; P.seed_len = opt->seed_len; P.max_top2 = opt->max_top2;
+	int cap1 = env_int("NABWA_CAP1", 4096);
+	if (cap1 < 16) cap1 = 16;
+	if (cap1 > 65534) cap1 = 65534;
+	layout(P, (uint32_t)cap1, 2, false, max_len, opt->seed_len, NS);
+	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
+	if (P.aln_cap < 1) P.aln_cap = 1;
+
+	hipDeviceProp_t prop;
+	BCHK(hipGetDeviceProperties(&prop, ix->device));
+	int occ = nabwa_search_occupancy(0);
+	if (occ < 1) occ = 1;
+	const int occ_env = env_int("NABWA_BLOCKS_PER_CU", 0);
+	if (occ_env > 0) occ = occ_env;
+	long blocks = (long)prop.multiProcessorCount * occ;
+	const long need = ((long)n + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
+	if (blocks > need) blocks = need;
+	if (blocks < 1) blocks = 1;
+	b->n_blocks = (int)blocks;
+	BCHK(hipMalloc(&b->d_scratch, (size_t)blocks * NABWA_SEARCH_BLOCK * P.lane_stride));
+	const size_t n1 = n ? n : 1;
+	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
+	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
+	BCHK(hipMalloc(&b->d_counter, 4)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
+	BCHK(hipMalloc(&b->d_sum, 16));
+	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
+	P.work_counter = b->d_counter;
+	*out = b;
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_batch_run(nabwa_batch_t *b)
+{
+	if (!b) return fail(NABWA_EINVAL, "null batch");
+	HIPCHK(hipSetDevice(b->ix->device));
+	b->unresolved = 0;
+	if (b->n == 0) return NABWA_OK;
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 4, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
+	HIPCHK(hipEventRecord(b->ev0, b->stream));
+	nabwa_launch_fm_search(&b->P, b->n_blocks, 0, b->stream);
+	HIPCHK(hipEventRecord(b->ev1, b->stream));
+	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
+	HIPCHK(hipGetLastError());
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
+{
+	if (!b) return fail(NABWA_EINVAL, "null batch");
+	HIPCHK(hipSetDevice(b->ix->device));
+	if (n_second_pass) *n_second_pass = 0;
+	if (b->n == 0) return NABWA_OK;
+	unsigned int novf = 0;
+	HIPCHK(hipMemcpyAsync(&novf, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	HIPCHK(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+	if (n_second_pass) *n_second_pass = (int)novf;
+	if (novf == 0) return NABWA_OK;
+	// ---- wide pass: the flagged reads again, from scratch, with slot reuse and an arena that holds
+	// max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140)
+	if (b->n2 < (int)novf) {
+		void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
+		for (void *p : old) if (p) (void)hipFree(p);
+		b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
+		b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
+		HIPCHK(hipMalloc(&b->d_naln2, (size_t)novf * 4)); HIPCHK(hipMalloc(&b->d_maxent2, (size_t)novf * 4));
+		HIPCHK(hipMalloc(&b->d_status2, novf)); HIPCHK(hipMalloc(&b->d_aln2, (size_t)novf * b->aln_cap2 * 16));
+		b->n2 = (int)novf;
+	}
+	SearchParams Q = b->P;
+	uint64_t cap2 = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
+	const int max_len = (int)Q.WL - 1;
+	layout(Q, (uint32_t)cap2, 4, true, max_len, b->opt.seed_len, Q.NS);
+	long blocks2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
+	const long max_blocks2 = env_int("NABWA_WIDE_BLOCKS", 2);
+	if (blocks2 > max_blocks2) blocks2 = max_blocks2;
+	const size_t need = (size_t)blocks2 * NABWA_SEARCH_BLOCK * Q.lane_stride;
+	if (!b->d_scratch2) HIPCHK(hipMalloc(&b->d_scratch2, need));   // size only depends on the option block
+	Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)novf;
+	Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2;
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 4, b->stream));
+	nabwa_launch_fm_search(&Q, (int)blocks2, 1, b->stream);
+	nabwa_launch_scatter_wide((int)novf, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
+							  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
+	HIPCHK(hipGetLastError());
+	// any read that outgrew even the wide pass (hit list > NABWA_ALNCAP2) is reported, never dropped
+	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
+	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
+	unsigned int left = 0;
+	HIPCHK(hipMemcpyAsync(&left, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	b->unresolved = (int)left;
+	if (left) return fail(NABWA_ECAP, "reads with more hits than NABWA_ALNCAP2 rows");
+	return NABWA_OK;
+}
+
+extern "C" float nabwa_batch_last_kernel_ms(nabwa_batch_t *b) { return b ? b->last_ms : 0.f; }
+
+extern "C" int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows)
+{
+	if (!b) return fail(NABWA_EINVAL, "null batch");
+	HIPCHK(hipSetDevice(b->ix->device));
+	unsigned long long h[2] = { 0, 0 };
+	HIPCHK(hipMemsetAsync(b->d_sum, 0, 16, b->stream));
+	nabwa_launch_checksum(b->n, b->d_naln, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2,
+						  b->d_sum, b->d_sum + 1, b->stream);
+	HIPCHK(hipMemcpyAsync(h, b->d_sum, 16, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	if (sum) *sum = h[0];
+	if (n_rows) *n_rows = (int64_t)h[1];
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
+								 int32_t *max_entries)
+{
+	if (!b || !n_aln) return fail(NABWA_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(b->ix->device));
+	if (n_rows) *n_rows = 0;
+	if (b->n == 0) return NABWA_OK;
+	// device-side compaction: exclusive scan of n_aln, then gather rows
+	uint32_t *d_off = 0; void *d_tmp = 0; size_t tmp_bytes = 0; uint4 *d_rows = 0;
+	HIPCHK(hipMalloc(&d_off, (size_t)(b->n + 1) * 4));
+	HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const uint32_t*)b->d_naln, d_off, b->n, b->stream));
+	HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+	HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (const uint32_t*)b->d_naln, d_off, b->n, b->stream));
+	uint32_t last_off = 0; int32_t last_n = 0;
+	HIPCHK(hipMemcpyAsync(&last_off, d_off + (b->n - 1), 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipMemcpyAsync(&last_n, b->d_naln + (b->n - 1), 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipMemcpyAsync(n_aln, b->d_naln, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->stream));
+	if (max_entries) HIPCHK(hipMemcpyAsync(max_entries, b->d_maxent, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	const int64_t total = (int64_t)last_off + last_n;
+	if (n_rows) *n_rows = total;
+	int rc = NABWA_OK;
+	if (total > aln_cap || (total && !aln_out)) rc = fail(NABWA_ECAP, "aln_cap too small");
+	else if (total) {
+		HIPCHK(hipMalloc(&d_rows, (size_t)total * 16));
+		nabwa_launch_gather(b->n, b->d_naln, d_off, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2,
+							d_rows, b->stream);
+		HIPCHK(hipMemcpyAsync(aln_out, d_rows, (size_t)total * 16, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		HIPCHK(hipFree(d_rows));
+	}
+	HIPCHK(hipFree(d_off)); HIPCHK(hipFree(d_tmp));
+	return rc;
+}
+
+extern "C" int nabwa_cal_sa_reg_gap(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off,
+									const uint8_t *seq, const uint8_t *rseq, int per_read,
+									int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
+									int32_t *max_entries)
+{
+	nabwa_batch_t *b = 0;
+	int r = nabwa_batch_create(ix, opt, n, off, seq, rseq, per_read, &b);
+	if (r != NABWA_OK) return r;
+	r = nabwa_batch_run(b);
+	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
+	if (r == NABWA_OK) r = nabwa_batch_fetch(b, n_aln, aln_out, aln_cap, n_rows, max_entries);
+	nabwa_batch_destroy(b);
+	return r;
+}
+
+/* ------------------------------------------------------------------ bwt_sa / occ batches */
+
+extern "C" int nabwa_sa_lookup(nabwa_index_t *ix, int n, const uint8_t *which, const uint32_t *k, uint32_t *sa_out)
+{
+	if (!ix || n < 0 || (n && (!which || !k || !sa_out))) return fail(NABWA_EINVAL, "null argument");
+	if (!ix->bwt[0].sa || !ix->bwt[1].sa) return fail(NABWA_EINVAL, "index was loaded without suffix arrays");
+	if (n == 0) return NABWA_OK;
+	HIPCHK(hipSetDevice(ix->device));
+	uint8_t *dw = 0; uint32_t *dk = 0, *dout = 0;
+	HIPCHK(hipMalloc(&dw, n)); HIPCHK(hipMalloc(&dk, (size_t)n * 4)); HIPCHK(hipMalloc(&dout, (size_t)n * 4));
+	HIPCHK(hipMemcpy(dw, which, n, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dk, k, (size_t)n * 4, hipMemcpyHostToDevice));
+	nabwa_launch_sa_lookup(ix->bwt, n, dw, dk, dout, 0);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(sa_out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipFree(dw)); HIPCHK(hipFree(dk)); HIPCHK(hipFree(dout));
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_occ4(nabwa_index_t *ix, int which, int n, const uint32_t *k, uint32_t *cnt_out)
+{
+	if (!ix || n < 0 || (n && (!k || !cnt_out))) return fail(NABWA_EINVAL, "null argument");
+	if (n == 0) return NABWA_OK;
+	HIPCHK(hipSetDevice(ix->device));
+	uint32_t *dk = 0, *dout = 0;
+	HIPCHK(hipMalloc(&dk, (size_t)n * 4)); HIPCHK(hipMalloc(&dout, (size_t)n * 16));
+	HIPCHK(hipMemcpy(dk, k, (size_t)n * 4, hipMemcpyHostToDevice));
+	nabwa_launch_occ4(&ix->bwt[which & 1], n, dk, dout, 0);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(cnt_out, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+	HIPCHK(hipFree(dk)); HIPCHK(hipFree(dout));
+	return NABWA_OK;
+}

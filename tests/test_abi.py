@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: libnabwa.so loads and exports every symbol that
+include/nabwa.h declares; struct layouts match the reference's; host-only entry points work.
+No compute call is made here (no GPU in this container)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+
+nabwa = importlib.import_module("network-aware-bwa_amd")
+
+
+def declared_symbols():
+    txt = open(os.path.join(T.ROOT, "include", "nabwa.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nabwa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(nabwa.LIB_PATH):
+        nabwa.build()
+    L = C.CDLL(nabwa.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), "libnabwa.so does not export %s" % s
+
+
+def test_struct_layouts_match_reference():
+    assert C.sizeof(nabwa.GapOpt) == 64            # gap_opt_t, bwtaln.h:143-153
+    assert nabwa.ALN_DT.itemsize == 16             # bwt_aln1_t, bwtaln.h:41-45
+    o = nabwa.gap_init_opt()                       # defaults, bwtaln.c:19-35
+    assert (o.s_mm, o.s_gapo, o.s_gape) == (3, 11, 4)
+    assert (o.max_diff, o.max_gapo, o.max_gape) == (-1, 1, 6)
+    assert (o.indel_end_skip, o.max_del_occ, o.max_entries) == (5, 10, 2000000)
+    assert o.mode == 3 and o.seed_len == 32 and o.max_seed_diff == 2 and o.max_top2 == 30
+    assert abs(o.fnr - 0.04) < 1e-7
+    # the header of a reference-written .sai is exactly this block
+    raw = open(os.path.join(T.GOLDEN, "se_default.sai"), "rb").read(64)
+    assert bytes(o) == raw
+
+
+def test_maxdiff_matches_reference_table():
+    vec = np.load(os.path.join(T.GOLDEN, "vectors.npz"))
+    for l in range(1, 400):
+        assert nabwa.cal_maxdiff(l, 0.02, 0.04) == vec["maxdiff_004"][l - 1]
+        assert nabwa.cal_maxdiff(l, 0.02, 0.01) == vec["maxdiff_001"][l - 1]
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a device the product path must fail loudly, not compute on the CPU."""
+    if nabwa.lib().nabwa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(nabwa.NabwaError) as e:
+        nabwa.Index.load(T.TOY)
+    assert e.value.code == nabwa.ENODEV

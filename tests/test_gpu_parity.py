@@ -1,0 +1,211 @@
+"""GPU parity (run with -m gpu on an MI355X): the HIP path through the C ABI against
+ (a) the golden vectors the reference itself produced and (b) the CPU oracle on fresh seeded inputs.
+Integer work: everything is compared bit-exact."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+
+pytestmark = pytest.mark.gpu
+nabwa = importlib.import_module("network-aware-bwa_amd")
+
+SAI_SETS = ["default", "adna", "n3", "e3", "loggap", "k1R5", "i2", "q20", "m64", "nonstop"]
+
+
+@pytest.fixture(scope="module")
+def gix():
+    ix = nabwa.Index.load(T.TOY, 0, True)
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="module")
+def olib():
+    return T.load_oracle()
+
+
+@pytest.fixture(scope="module")
+def oix(olib):
+    return T.OracleIndex(olib)
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(T.GOLDEN, "vectors.npz"))
+
+
+def to_gap_opt(o):
+    g = nabwa.GapOpt()
+    C.memmove(C.byref(g), C.byref(o), 64)
+    return g
+
+
+def test_occ4_golden(gix, vec):
+    for which in (0, 1):
+        got = gix.occ4(which, vec["occ_k%d" % which])
+        assert np.array_equal(got, vec["occ4_v%d" % which])
+        assert np.array_equal(gix.occ4(which, vec["p_k%d" % which]), vec["p_ck%d" % which])
+        assert np.array_equal(gix.occ4(which, vec["p_l%d" % which]), vec["p_cl%d" % which])
+
+
+def test_occ4_every_row(gix, olib, oix):
+    """all rows of both toy indexes, incl. -1, primary and seq_len"""
+    buf = (C.c_uint32 * 4)()
+    for which in (0, 1):
+        n = gix.seq_len(which)
+        ks = np.concatenate([np.arange(0, n + 1, dtype=np.uint32), np.array([0xFFFFFFFF], np.uint32)])
+        got = gix.occ4(which, ks)
+        step = 97
+        for i in list(range(0, len(ks), step)) + [len(ks) - 2, len(ks) - 1]:
+            olib.orc_occ4(oix.bwt(which), int(ks[i]), buf)
+            assert list(got[i]) == list(buf), (which, int(ks[i]))
+        # differences between consecutive rows are 0/1 and sum to one base per row (except '$')
+        d = np.diff(got[:-1].astype(np.int64), axis=0)
+        assert d.min() >= 0 and d.sum(axis=1).max() <= 1
+
+
+def test_sa_lookup_golden(gix, vec):
+    for which in (0, 1):
+        k = vec["sa_k%d" % which]
+        got = gix.sa_lookup(np.full(len(k), which, np.uint8), k)
+        assert np.array_equal(got, vec["sa_v%d" % which])
+
+
+def test_sa_is_a_permutation(gix):
+    """size-independent property: SA over all rows 1..n is a permutation of 0..n-1"""
+    for which in (0, 1):
+        n = gix.seq_len(which)
+        k = np.arange(1, n + 1, dtype=np.uint32)
+        got = gix.sa_lookup(np.full(n, which, np.uint8), k)
+        assert np.array_equal(np.sort(got), np.arange(n, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("name", SAI_SETS)
+def test_sai_parity(gix, name):
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "nonstop" else "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
+    got, _ = gix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off, per_read=False)
+    bad = [reads[i][0] for i in range(len(reads)) if got[i].tobytes() != gold[i].tobytes()]
+    assert not bad, "GPU differs from the reference .sai for %d reads, e.g. %s" % (len(bad), bad[:5])
+
+
+def random_reads(rng, n, genome, lens=(100,), err=0.01, indel=0.05):
+    reads = []
+    G = len(genome)
+    for i in range(n):
+        L = int(rng.choice(lens))
+        if rng.random() < 0.05:
+            s = "".join("ACGT"[x] for x in rng.integers(0, 4, L))
+        else:
+            p = int(rng.integers(0, G - L - 8))
+            s = list(genome[p:p + L + 8])
+            for j in range(L):
+                if rng.random() < err:
+                    s[j] = "ACGTN"[int(rng.integers(0, 5))]
+            if rng.random() < indel:
+                q = int(rng.integers(8, L - 8))
+                if rng.random() < 0.5:
+                    del s[q]
+                else:
+                    s.insert(q, "ACGT"[int(rng.integers(0, 4))])
+            s = "".join(s[:L])
+        if rng.random() < 0.5:
+            s = s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+        reads.append(("q%d" % i, s, "I" * len(s)))
+    return reads
+
+
+def toy_genome():
+    seqs = []
+    cur = []
+    for line in open(T.TOY + ".fa"):
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+            cur = []
+        else:
+            cur.append(line.strip())
+    seqs.append("".join(cur))
+    return "".join(seqs)
+
+
+@pytest.mark.parametrize("per_read", [False, True])
+def test_random_reads_vs_oracle(gix, olib, oix, per_read):
+    """fresh seeded reads of mixed length (ragged batch), both option-derivation modes, max_entries too"""
+    rng = np.random.default_rng(7 + per_read)
+    reads = random_reads(rng, 3000, toy_genome(), lens=(36, 50, 76, 100, 100, 100, 150), err=0.02)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = T.default_opt()
+    want, wmax = T.oracle_cal_sa_reg_gap(olib, oix.h, opt, seq, rseq, off, per_read=int(per_read), n_threads=8)
+    got, gmax = gix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off, per_read=per_read)
+    bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
+    assert not bad, "GPU differs from the oracle for %d reads, first %s" % (len(bad), reads[bad[0]])
+    assert np.array_equal(gmax, wmax)
+
+
+def test_edge_batches(gix):
+    opt = nabwa.gap_init_opt()
+    # empty batch
+    got, _ = gix.cal_sa_reg_gap(opt, np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert got == []
+    # zero-length read between two normal ones; single read
+    reads = [("a", "ACGTACGTACGTAGCTAGCTAGCATCGATCGATCGACTAGCTAGC", "I" * 45), ("e", "", ""),
+             ("n", "N" * 50, "I" * 50)]
+    seq, rseq, off, _ = T.encode_reads(reads)
+    got, maxe = gix.cal_sa_reg_gap(opt, seq, rseq, off)
+    assert len(got) == 3 and len(got[1]) == 0 and len(got[2]) == 0 and maxe[1] == 0 and maxe[2] == 0
+
+
+def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
+    """force the first pass to overflow (tiny arena / hit list): the slot-reusing second pass must
+    give the same answers"""
+    monkeypatch.setenv("NABWA_CAP1", "48")
+    monkeypatch.setenv("NABWA_ALNCAP1", "1")
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    n2 = b.sync()
+    got, _ = b.fetch()
+    cs = b.checksum()
+    b.close()
+    assert n2 > 100
+    assert all(got[i].tobytes() == gold[i].tobytes() for i in range(len(reads)))
+    monkeypatch.delenv("NABWA_CAP1")
+    monkeypatch.delenv("NABWA_ALNCAP1")
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    assert b.sync() == 0
+    assert b.checksum() == cs          # device checksum is independent of which pass produced a row
+    assert b.checksum()[1] == sum(len(g) for g in gold)
+    b.close()
+
+
+def test_rerun_is_idempotent(gix):
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    sums = []
+    for _ in range(3):
+        b.run()
+        b.sync()
+        sums.append(b.checksum())
+    b.close()
+    assert sums[0] == sums[1] == sums[2]
+
+
+def test_unsupported_options_fail_loudly(gix):
+    opt = nabwa.gap_init_opt()
+    opt.max_gape = 40           # > 128 score levels
+    reads = [("a", "ACGT" * 20, "I" * 80)]
+    seq, rseq, off, _ = T.encode_reads(reads)
+    with pytest.raises(nabwa.NabwaError) as e:
+        gix.cal_sa_reg_gap(opt, seq, rseq, off)
+    assert e.value.code == nabwa.EINVAL
