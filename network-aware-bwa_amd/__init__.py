@@ -39,7 +39,7 @@ class NabwaError(RuntimeError):
 
 def build(verbose=False):
     """Compile libnabwa.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=not verbose, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "all"], capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libnabwa.so failed:\n%s\n%s" % (r.stdout, r.stderr))
 

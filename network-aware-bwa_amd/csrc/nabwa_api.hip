@@ -92,7 +92,8 @@ static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_w
 	DevBwt &B = ix->bwt[t];
 	memset(&B, 0, sizeof(B));
 	B.primary = hdr[0]; B.L2[0] = 0; B.L2[1] = hdr[1]; B.L2[2] = hdr[2]; B.L2[3] = hdr[3]; B.seq_len = hdr[4];
-	const uint64_t expect = ((uint64_t)B.seq_len + 127) / 128 * 8 + (((uint64_t)B.seq_len + 127) / 128 + 1) * 4;
+	/* (seq_len+15)/16 BWT words plus (seq_len+127)/128+1 checkpoints of 4 words (bwtmisc.c:130-131) */
+	const uint64_t expect = ((uint64_t)B.seq_len + 15) / 16 + (((uint64_t)B.seq_len + 127) / 128 + 1) * 4;
 	if (n_words - 5 < expect) return fail(NABWA_EIO, "bwt array shorter than its seq_len implies");
 	B.n_buckets = (uint32_t)(((uint64_t)B.seq_len + NABWA_INTV - 1) / NABWA_INTV);
 	uint32_t *raw = 0;

