@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned reads/s of the FM-index search hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): a GRCh38-sized index (3.1 Gbp; synthetic genome, because there is
+no network for the real one -- see DESIGN.md) and 10 M synthetic 100 bp single-end reads per GPU at
+0.2 % substitutions.  One "step" = one pass of bwa_cal_sa_reg_gap over the whole batch, inputs and the
+index resident in HBM.  With --gpus N every rank holds a replica of the index and its own shard of reads
+(no collective on the data path; weak scaling).
+
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic Occ-bucket bytes / HIP-event kernel time
+vs. the 8 TB/s HBM peak) and `cpu_baseline` (the reference's own compiled code, oracle/_ref, on the
+host cores of this box, on a bounded sample of the same reads).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GRCH38_LEN = 3_099_734_149   # GRCh38 primary assembly, total bases
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-len", type=int, default=int(os.environ.get("NABWA_BENCH_GENOME", GRCH38_LEN)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("NABWA_BENCH_READS", 10_000_000)))
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--sub-ppm", type=int, default=2000)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    nabwa = importlib.import_module("network-aware-bwa_amd")
+    synth = importlib.import_module("network-aware-bwa_amd.synth")
+    if not os.path.exists(nabwa.LIB_PATH) or not os.path.exists(synth.LIB_PATH):
+        nabwa.build()
+    import nabwa_testlib as T
+
+    t0 = time.time()
+    n = args.genome_len
+    d_text = synth.synth_text(n, 20261004, n_dup=2000, dup_len=5000, device=dev)
+    parts = [synth.build_index(d_text, n, rev, 32, False, device=dev, verbose=(rank == 0)) for rev in (0, 1)]
+    ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]), device=dev,
+                                 device_ptrs=True)
+    if rank == 0:
+        log("index: %d bp x2 FM-indexes built on GPU + re-packed in %.1f s (%.2f GB in HBM)"
+            % (n, time.time() - t0, ix.device_bytes() / 1e9))
+    host_bwt = None
+    want_cpu = rank == 0 and not args.no_cpu
+    if want_cpu:
+        host_bwt = [p[0].to_host(np.uint32, p[1]) for p in parts]
+    for p in parts:
+        p[0].free()
+
+    # reads: this rank's shard (seeded by rank)
+    seq, rseq, off = synth.synth_reads(d_text, n, args.reads, args.read_len, args.sub_ppm, 0, 2 + 1000 * rank, device=dev)
+    d_text.free()
+    opt = nabwa.gap_init_opt()
+    batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n2 = 0
+    for _ in range(args.warmup):
+        batch.run()
+        n2 = batch.sync()
+    barrier()
+    t1 = time.time()
+    kms = []
+    for _ in range(args.steps):
+        batch.run()
+        n2 = batch.sync()
+        kms.append(batch.last_kernel_ms())
+    barrier()
+    elapsed = time.time() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    checksum, n_rows = batch.checksum()
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (fm_search, first pass): algorithmic bytes / event time
+        touches = batch.count_touches()
+        assert batch.checksum() == (checksum, n_rows), "instrumented run changed the results"
+        bytes_alg = 48 * touches + args.reads * ((args.read_len + 1) // 2) + 16 * n_rows
+        k_ms = float(np.mean(kms))
+        achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "fm_search_kernel<uint16_t,false,false>", "kernel_ms": round(k_ms, 3),
+                    "bytes_per_read": round(bytes_alg / args.reads, 1), "bucket_touches_per_read": round(touches / args.reads, 1)}
+        cpu = None
+        bit_exact = None
+        if want_cpu:
+            cpu, bit_exact = cpu_baseline(T, host_bwt, opt, seq, rseq, off, batch, args)
+        reads_per_s = args.reads * world * args.steps / elapsed
+        out = {"metric": "aligned reads/s to GRCh38 (100 bp SE), FM-index search (bwa_cal_sa_reg_gap), bit-exact vs CPU",
+               "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "GRCh38-sized synthetic genome (%d bp, uniform ACGT + 2000 planted 5 kb repeats), "
+                                      "%d x %d bp SE reads/GPU at %.1f%% subs, default gap_opt_t, index replicated per GPU"
+                                      % (n, args.reads, args.read_len, args.sub_ppm / 1e4),
+                          "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_len": n,
+                          "parallelism": "reads sharded x%d, index replicated" % world,
+                          "second_pass_reads": n2, "hits": n_rows, "checksum": "%016x" % checksum,
+                          "bit_exact_vs_cpu_sample": bit_exact},
+               "roofline": roofline, "cpu_baseline": cpu}
+    batch.close()
+    ix.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(T, host_bwt, opt, seq, rseq, off, batch, args):
+    """The reference's own bwa_cal_sa_reg_gap (oracle/_ref, compiled from /root/reference) on all host
+    cores over a bounded sample of the same reads; falls back to the CPU restatement ("port") when the
+    compiled reference did not travel.  Also checks the GPU rows of the sample bit-for-bit."""
+    # the GPU box gives one GPU's job a share of 16 host threads (pool-sizing rule of the box); NABWA_BENCH_CPU_THREADS overrides
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("NABWA_BENCH_CPU_THREADS", "16")))
+    ref = T.load_ref()
+    n_all = len(off) - 1
+    got, _ = None, None
+
+    def run(n_s, threads):
+        o = np.ascontiguousarray(off[:n_s + 1])
+        n_aln = np.zeros(n_s, np.int32)
+        cap = 64 * n_s + 4096
+        rows = np.zeros(cap, T.ALN_DT)
+        t = time.time()
+        if ref is not None:
+            tot = ref.ref_cal_sa_reg_gap_mt(rix, C.byref(copt), n_s, T.ptr(o), T.ptr(seq), T.ptr(rseq), threads,
+                                            T.ptr(n_aln), T.ptr(rows), cap)
+        else:
+            maxe = np.zeros(n_s, np.int32)
+            tot = olib.orc_cal_sa_reg_gap(oix, C.byref(copt), n_s, T.ptr(o), T.ptr(seq), T.ptr(rseq), 1, T.ptr(n_aln),
+                                          T.ptr(rows), cap, T.ptr(maxe), threads, None)
+        dt = time.time() - t
+        assert tot >= 0
+        return dt, n_aln, rows[:tot]
+
+    copt = T.GapOpt()
+    C.memmove(C.byref(copt), C.byref(opt), 64)
+    if ref is not None:
+        ref.ref_index_wrap.restype = C.c_void_p
+        ref.ref_index_wrap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        ref.ref_cal_sa_reg_gap_mt.restype = C.c_long
+        ref.ref_cal_sa_reg_gap_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_long]
+        rix = C.c_void_p(ref.ref_index_wrap(T.ptr(host_bwt[0]), len(host_bwt[0]), T.ptr(host_bwt[1]), len(host_bwt[1])))
+        kind = "reference"
+    else:
+        olib = T.load_oracle()
+        oix = C.c_void_p(olib.orc_index_wrap(T.ptr(host_bwt[0]), len(host_bwt[0]), T.ptr(host_bwt[1]), len(host_bwt[1])))
+        kind = "port"
+    pilot = min(n_all, 256 * cores)
+    dt, _, _ = run(pilot, cores)
+    n_s = int(min(n_all, max(pilot, pilot / max(dt, 1e-3) * args.cpu_seconds)))
+    dt, n_aln, rows = run(n_s, cores)
+    log("cpu baseline (%s): %d reads on %d threads in %.2f s" % (kind, n_s, cores, dt))
+    # parity of the GPU rows for the sample
+    g_rows, _ = batch.fetch()
+    bounds = np.concatenate([[0], np.cumsum(n_aln)])
+    exact = all(g_rows[i].tobytes() == rows[bounds[i]:bounds[i + 1]].tobytes() for i in range(n_s))
+    cpu = {"value": round(n_s / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
+           "sample": "first %d reads of the same batch, bwa_cal_sa_reg_gap once per read on %d host threads, %.1f s"
+                     % (n_s, cores, dt)}
+    return cpu, bool(exact)
+
+
+if __name__ == "__main__":
+    main()

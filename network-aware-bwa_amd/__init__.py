@@ -79,6 +79,7 @@ def lib():
     L.nabwa_batch_last_kernel_ms.argtypes = [_P]
     L.nabwa_batch_fetch.argtypes = [_P, _P, _P, C.c_int64, _P, _P]
     L.nabwa_batch_checksum.argtypes = [_P, _P, _P]
+    L.nabwa_batch_count_touches.argtypes = [_P, _P]
     L.nabwa_batch_destroy.argtypes = [_P]
     L.nabwa_batch_destroy.restype = None
     L.nabwa_sa_lookup.argtypes = [_P, C.c_int, _P, _P, _P]
@@ -206,6 +207,12 @@ class Batch:
         r = C.c_int64()
         _chk(lib().nabwa_batch_checksum(self._h, C.byref(s), C.byref(r)))
         return s.value, r.value
+
+    def count_touches(self):
+        """Occ-bucket touches of the reference algorithm on this batch (untimed instrumented run)."""
+        v = C.c_uint64()
+        _chk(lib().nabwa_batch_count_touches(self._h, C.byref(v)))
+        return v.value
 
     def fetch(self):
         n_aln = np.zeros(max(self.n, 1), np.int32)

@@ -32,7 +32,20 @@
 #define STATE_I 1
 #define STATE_D 2
 
-template <typename LinkT, bool REUSE>
+// bucket touches the REFERENCE algorithm performs for one (k-1, l) query: one per
+// bwt_occ / bwt_occ4 body execution, one for a same-128-row-block pair (bwt.c:92-216)
+__device__ __forceinline__ uint32_t ref_touches(const DevBwt &B, uint32_t kq, uint32_t lq, bool four)
+{
+	const uint32_t NEG = 0xffffffffu;
+	const uint32_t bk = (kq == NEG || (!four && kq == B.seq_len)) ? 0u : 1u;
+	const uint32_t bl = (lq == NEG || (!four && lq == B.seq_len)) ? 0u : 1u;
+	if (kq == lq) return bk;
+	const uint32_t _k = kq - (kq >= B.primary ? 1u : 0u), _l = lq - (lq >= B.primary ? 1u : 0u);
+	if (!(_l >> 7 != _k >> 7 || kq == NEG || lq == NEG)) return 1u;
+	return bk + bl;
+}
+
+template <typename LinkT, bool REUSE, bool COUNT>
 __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const SearchParams P)
 {
 	const LinkT NIL = (LinkT)~(LinkT)0;
@@ -61,6 +74,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;
 	// current entry
 	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, m = 0, m_seed = 0, xt = 0;
+	unsigned long long touches = 0; uint32_t rd_touch = 0;   // COUNT only
 
 	for (;;) {
 		// ---------------------------------------------------------------- refill
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 					len = (int)(P.off[rid + 1] - o);
 					sq0 = P.seq + o; sq1 = P.rseq + o;
 					md_read = P.rd_maxdiff[rid]; mg_read = P.rd_maxgapo[rid];
-					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; nN = 0;
+					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; nN = 0; rd_touch = 0;
 					if (len > 0) { pass = 0; wi = 0; wbid = 0; k = 0; l = P.bwt[0].seq_len; st = ST_WIDTH; }
 					else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
 				} else st = ST_EXIT;
@@ -141,6 +155,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 		}
 		Occ4 ck, cl;
 		if (query) nabwa_occ4_pair(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, ck, cl);
+		if (COUNT && query) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, st == ST_EXPAND);
 		const uint32_t L2q0 = qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0], L2q1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1];
 		const uint32_t L2q2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], L2q3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
 		const uint32_t seqlen_q = qb ? P.bwt[1].seq_len : P.bwt[0].seq_len;
@@ -312,22 +327,30 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 
 		if (finish) {
 			P.n_aln[item] = n_aln; P.max_ent[item] = max_ent; P.status[item] = (uint8_t)status;
+			if (COUNT && status == NABWA_ST_OK) touches += rd_touch;   // abandoned reads are counted by the wide pass
 			st = ST_IDLE;
 		}
+	}
+	if (COUNT) {
+		for (int o = 32; o > 0; o >>= 1) touches += __shfl_down(touches, o);
+		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter, touches);
 	}
 }
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
 {
-	if (wide) hipLaunchKernelGGL((fm_search_kernel<uint32_t, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
-	else hipLaunchKernelGGL((fm_search_kernel<uint16_t, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+	if (P->touch_counter) {
+		if (wide) hipLaunchKernelGGL((fm_search_kernel<uint32_t, true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+		else hipLaunchKernelGGL((fm_search_kernel<uint16_t, false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+	} else if (wide) hipLaunchKernelGGL((fm_search_kernel<uint32_t, true, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+	else hipLaunchKernelGGL((fm_search_kernel<uint16_t, false, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
 }
 
 extern "C" int nabwa_search_occupancy(int wide)
 {
 	int nb = 0;
-	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint32_t, true>, NABWA_SEARCH_BLOCK, 0)
-						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint16_t, false>, NABWA_SEARCH_BLOCK, 0);
+	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint32_t, true, false>, NABWA_SEARCH_BLOCK, 0)
+						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint16_t, false, false>, NABWA_SEARCH_BLOCK, 0);
 	return e == hipSuccess ? nb : 0;
 }
 

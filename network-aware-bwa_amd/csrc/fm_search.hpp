@@ -28,4 +28,5 @@ struct SearchParams {
 	uint4 *aln;
 	int aln_cap;
 	unsigned int *work_counter;
+	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
 };

@@ -401,6 +401,24 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 
 extern "C" float nabwa_batch_last_kernel_ms(nabwa_batch_t *b) { return b ? b->last_ms : 0.f; }
 
+/* One extra, untimed run of both passes with the instrumented kernel: total Occ-bucket touches the
+ * REFERENCE algorithm performs on this batch (the "algorithmic bytes" of the roofline are 48 B each). */
+extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket)
+{
+	if (!b || !n_bucket) return fail(NABWA_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(b->ix->device));
+	HIPCHK(hipMemsetAsync(b->d_sum, 0, 16, b->stream));
+	b->P.touch_counter = b->d_sum;
+	int r = nabwa_batch_run(b);
+	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
+	b->P.touch_counter = 0;
+	if (r != NABWA_OK) return r;
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpy(&v, b->d_sum, 8, hipMemcpyDeviceToHost));
+	*n_bucket = v;
+	return NABWA_OK;
+}
+
 extern "C" int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows)
 {
 	if (!b) return fail(NABWA_EINVAL, "null batch");

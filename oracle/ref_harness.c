@@ -16,6 +16,7 @@
 #include "bwase.h"
 #include "bntseq.h"
 #include "stdaln.h"
+#include <pthread.h>
 
 typedef struct {
 	bwt_t *bwt[2];
@@ -208,4 +209,64 @@ int ref_pac2real(ref_index_t *ix, int64_t pac_coor, int len, int32_t *seqid, int
 	int nn = bns_coor_pac2real(ix->bns, pac_coor, len, seqid);
 	*offset = ix->bns->anns[*seqid].offset;
 	return nn;
+}
+
+/* Wrap in-memory arrays holding the content of .bwt / .rbwt files (bench.py builds them on the GPU):
+ * the same fields bwt_restore_bwt fills (bwtio.c:184-204). */
+ref_index_t *ref_index_wrap(const uint32_t *bwt0, uint64_t nw0, const uint32_t *bwt1, uint64_t nw1)
+{
+	ref_index_t *ix = (ref_index_t*)calloc(1, sizeof(ref_index_t));
+	const uint32_t *raw[2] = { bwt0, bwt1 }; uint64_t nw[2] = { nw0, nw1 }; int t;
+	for (t = 0; t < 2; ++t) {
+		bwt_t *b = (bwt_t*)calloc(1, sizeof(bwt_t));
+		b->primary = raw[t][0];
+		memcpy(b->L2 + 1, raw[t] + 1, 16);
+		b->seq_len = b->L2[4];
+		b->bwt_size = nw[t] - 5;
+		b->bwt = (uint32_t*)(raw[t] + 5);
+		bwt_gen_cnt_table(b);
+		ix->bwt[t] = b;
+	}
+	return ix;
+}
+void ref_index_unwrap(ref_index_t *ix) { free(ix->bwt[0]); free(ix->bwt[1]); free(ix); }
+
+/* bwa_cal_sa_reg_gap from n_threads host threads, each on a contiguous share of the reads, one call per
+ * read as bam2bam's workers do (bam2bam.c:616; the function is re-entrant, SURVEY 8b "Threading").
+ * Only n_aln[] and the hit count are kept; used as the CPU baseline of bench.py. */
+typedef struct { ref_index_t *ix; const gap_opt_t *opt; int lo, hi; const int64_t *off; const uint8_t *seq, *rseq;
+				 int32_t *n_aln; bwt_aln1_t **rows; } ref_job_t;
+static void *ref_job(void *a)
+{
+	ref_job_t *J = (ref_job_t*)a; int i;
+	for (i = J->lo; i < J->hi; ++i) {
+		bwa_seq_t s; memset(&s, 0, sizeof(s));
+		s.len = s.full_len = s.clip_len = (int)(J->off[i+1] - J->off[i]);
+		s.seq = (ubyte_t*)(J->seq + J->off[i]); s.rseq = (ubyte_t*)(J->rseq + J->off[i]);
+		bwa_cal_sa_reg_gap(J->ix->bwt, 1, &s, J->opt);
+		J->n_aln[i] = s.n_aln; J->rows[i] = s.aln;
+	}
+	return 0;
+}
+long ref_cal_sa_reg_gap_mt(ref_index_t *ix, const gap_opt_t *opt, int n, const int64_t *off, const uint8_t *seq,
+						   const uint8_t *rseq, int n_threads, int32_t *n_aln, uint32_t *aln_out, long aln_cap)
+{
+	ref_job_t *jobs = (ref_job_t*)calloc(n_threads, sizeof(ref_job_t));
+	pthread_t *tid = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+	bwt_aln1_t **rows = (bwt_aln1_t**)calloc(n ? n : 1, sizeof(*rows));
+	long tot = 0; int t, i;
+	for (t = 0; t < n_threads; ++t) {
+		ref_job_t *J = jobs + t;
+		J->ix = ix; J->opt = opt; J->off = off; J->seq = seq; J->rseq = rseq; J->n_aln = n_aln; J->rows = rows;
+		J->lo = (int)((long)n * t / n_threads); J->hi = (int)((long)n * (t + 1) / n_threads);
+		pthread_create(&tid[t], 0, ref_job, J);
+	}
+	for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+	for (i = 0; i < n; ++i) {
+		if (tot >= 0 && tot + n_aln[i] <= aln_cap) { if (n_aln[i]) memcpy(aln_out + 4 * tot, rows[i], 16 * (size_t)n_aln[i]); tot += n_aln[i]; }
+		else tot = -1;
+		free(rows[i]);
+	}
+	free(rows); free(jobs); free(tid);
+	return tot;
 }

@@ -209,3 +209,16 @@ def test_unsupported_options_fail_loudly(gix):
     with pytest.raises(nabwa.NabwaError) as e:
         gix.cal_sa_reg_gap(opt, seq, rseq, off)
     assert e.value.code == nabwa.EINVAL
+
+
+def test_touch_counter_matches_oracle(gix, olib, oix):
+    """the instrumented kernel counts the reference algorithm's Occ-bucket touches (roofline bytes)
+    exactly as the CPU restatement's counters do"""
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    ctr = T.Counters()
+    T.oracle_cal_sa_reg_gap(olib, oix.h, opt, seq, rseq, off, per_read=0, counters=ctr)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    assert b.count_touches() == ctr.n_bucket
+    b.close()
