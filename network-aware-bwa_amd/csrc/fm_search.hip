@@ -12,12 +12,24 @@
 // lane is doing (width pass, exact tail match, node expansion), so lanes in different phases
 // stay converged on the expensive part: the bucket gathers.
 //
-// Priority stack: entries live in a per-lane arena in HBM (16 B each); entries of one score
-// form a linked list through link[]; head[score] is the newest entry, a 128-bit mask in
-// registers tracks the non-empty scores, so "pop the newest entry of the lowest score"
-// is one ctz + two dependent loads.  First pass: bump allocation (arena = total pushes);
-// reads that outgrow it are flagged and re-run from scratch by the same kernel instantiated
-// with slot reuse and an arena of max_entries+16 live entries (never on the CPU).
+// Memory discipline (v2).  With ~260 k reads in flight the caches hold ~128 B of L2 and ~1 KB of
+// Infinity Cache per lane, so every touch of lane-private state in HBM costs a 64-byte
+// transaction -- as much as the rank query it accompanies (v1 moved 4.5x the algorithmic bytes,
+// profiles/r01_v1_pmc.json).  Therefore:
+//   * the child that continues the current path (always the LAST push of an expansion) is kept
+//     in registers as the "pending" entry; it is the next pop whenever its score is not above the
+//     lowest score in memory (for the match child: always) and is spilled otherwise, so the
+//     observable pop order is unchanged;
+//   * an arena entry is one 16-byte word with its list link embedded; head[score] lives in LDS
+//     ([score][lane], 2 bytes each); a 128-bit register mask tracks the non-empty scores;
+//   * read bases and the per-position bound bytes are read through 16-byte register windows
+//     that stay valid for 8-16 steps of a descent;
+//   * the test "w[i-1] == w[i]" (bwtgap.c:208,212) is precomputed into bit 7 of the bound byte,
+//     so the 32-bit interval widths are only touched by gap_shadow (bwtgap.c:81-91);
+//   * the width passes write their results in 16-byte chunks (4 widths / 16 bound bytes).
+// First pass: bump allocation (arena = pushes that reach memory).  Reads that outgrow the arena
+// or the per-read hit list are flagged and re-run from scratch by the WIDE instantiation
+// (32-bit links, slot reuse, arena of max_entries+16 live entries) -- never on the CPU.
 #include "nabwa_dev.hpp"
 #include "fm_search.hpp"
 
@@ -45,36 +57,110 @@ __device__ __forceinline__ uint32_t ref_touches(const DevBwt &B, uint32_t kq, ui
 	return bk + bl;
 }
 
-template <typename LinkT, bool REUSE, bool COUNT>
+// 16-byte register windows are kept as two separate 64-bit scalars and indexed with a select and a
+// shift: a dynamically indexed uint4 (or a struct of two halves) makes hipcc keep the value in
+// scratch and load one piece back.
+__device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, uint32_t idx)
+{
+	const uint64_t h = (idx & 8u) ? hi : lo;
+	return (uint32_t)(h >> ((idx & 7u) << 3)) & 0xffu;
+}
+#define WIN_SET(lo_, hi_, a_, b_, c_, d_) do { lo_ = (uint64_t)(b_) << 32 | (a_); hi_ = (uint64_t)(d_) << 32 | (c_); \
+	asm volatile("" : "+v"(lo_), "+v"(hi_)); } while (0)
+
+__device__ __forceinline__ void set_word(uint4 &q, uint32_t c, uint32_t v)
+{
+	q.x = c == 0 ? v : q.x; q.y = c == 1 ? v : q.y; q.z = c == 2 ? v : q.z; q.w = c == 3 ? v : q.w;
+}
+
+extern __shared__ uint16_t s_head[];   // first pass only: [score][lane of the block]
+
+template <bool WIDE, bool COUNT>
 __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const SearchParams P)
 {
-	const LinkT NIL = (LinkT)~(LinkT)0;
+	const uint32_t NIL = WIDE ? 0xffffffffu : 0xffffu;
 	const uint32_t lane = threadIdx.x & 63u;
 	const size_t slot = (size_t)blockIdx.x * NABWA_SEARCH_BLOCK + threadIdx.x;
 	uint8_t *const sc = P.scratch + slot * P.lane_stride;
 	uint4 *const ent = (uint4*)sc;
-	LinkT *const lnk = (LinkT*)(sc + P.off_link);
-	LinkT *const freel = (LinkT*)(sc + P.off_free);
-	LinkT *const head = (LinkT*)(sc + P.off_head);
-	uint32_t *const Wd = (uint32_t*)(sc + P.off_w);      // [2][WL] interval widths
-	uint32_t *const SWd = (uint32_t*)(sc + P.off_sw);    // [2][SL] seed widths
-	uint8_t *const Bd = sc + P.off_bid;                  // [2][WL] lower bounds
-	uint8_t *const SBd = sc + P.off_sbid;                // [2][SL]
+	uint32_t *const lnk = (uint32_t*)(sc + P.off_link);     // WIDE only
+	uint32_t *const freel = (uint32_t*)(sc + P.off_free);   // WIDE only
+	uint32_t *const ghead = (uint32_t*)(sc + P.off_head);   // WIDE only
+	uint32_t *const Wd = (uint32_t*)(sc + P.off_w);         // [2][WL] interval widths (gap_shadow only)
+	uint8_t *const Bd = sc + P.off_bid;                     // [2][WLB] bound | weq<<7
+	uint8_t *const SBd = sc + P.off_sbid;                   // [2][SLB] seed bound | weq<<7
 	const bool gape_mode = P.mode & 0x01, nonstop = P.mode & 0x10, loggap = P.mode & 0x04;
 
 	int st = ST_IDLE;
 	// per-read
 	uint32_t item = 0; int len = 0, md_read = 0, mg_read = 0; const uint8_t *sq0 = 0, *sq1 = 0;
 	// width passes
-	int pass = 0, wi = 0, wbid = 0, nN = 0;
-	// current interval / query
+	int pass = 0, wi = 0, wbid = 0, nN = 0; uint32_t prev_w = 0;
+	uint4 wacc = make_uint4(0, 0, 0, 0); uint64_t bacc_lo = 0, bacc_hi = 0;
+	// current interval
 	uint32_t k = 0, l = 0;
 	// search globals
 	int max_diff = 0, best_score = 0, best_cnt = 0, n_aln = 0, max_ent = 0, n_entries = 0;
 	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;
 	// current entry
 	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, m = 0, m_seed = 0, xt = 0;
-	unsigned long long touches = 0; uint32_t rd_touch = 0;   // COUNT only
+	// pending entry: the last child pushed by the previous expansion, still in registers
+	bool p_valid = false; uint32_t p_k = 0, p_l = 0;
+	int p_i = 0, p_ldp = 0, p_mm = 0, p_go = 0, p_ge = 0, p_state = 0, p_a = 0, p_score = 0;
+	// register windows over lane-private / read data
+	uint64_t sqw_lo = 0, sqw_hi = 0; int sq_tag = -1;                 // 16 read bases
+	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;      // 16 bound bytes of strand bw_a from bw_base
+	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;      // same for the seed bounds
+	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
+	bool ovf = false;
+
+	auto seq_at = [&](int a, int pos) -> int {
+		const int tag = (a << 20) | (pos >> 4);
+		if (tag != sq_tag) { const uint4 q = *(const uint4*)((a ? sq1 : sq0) + (pos & ~15)); WIN_SET(sqw_lo, sqw_hi, q.x, q.y, q.z, q.w); sq_tag = tag; }
+		return (int)byte_of(sqw_lo, sqw_hi, (uint32_t)pos & 15u);
+	};
+	auto bid_at = [&](int a, int pos) -> uint32_t {
+		if (a != bw_a || pos < bw_base || pos >= bw_base + 16) {
+			int base = (pos | 7) - 15; if (base < 0) base = 0;
+			const uint2 *p = (const uint2*)(Bd + a * P.WLB + base);
+			const uint2 u = p[0], v = p[1];
+			WIN_SET(bw_lo, bw_hi, u.x, u.y, v.x, v.y); bw_base = base; bw_a = a;
+		}
+		return byte_of(bw_lo, bw_hi, (uint32_t)(pos - bw_base));
+	};
+	auto sbid_at = [&](int a, int pos) -> uint32_t {
+		if (a != sw_a || pos < sw_base || pos >= sw_base + 16) {
+			int base = (pos | 7) - 15; if (base < 0) base = 0;
+			const uint2 *p = (const uint2*)(SBd + a * P.SLB + base);
+			const uint2 u = p[0], v = p[1];
+			WIN_SET(sw_lo, sw_hi, u.x, u.y, v.x, v.y); sw_base = base; sw_a = a;
+		}
+		return byte_of(sw_lo, sw_hi, (uint32_t)(pos - sw_base));
+	};
+	auto head_get = [&](int score) -> uint32_t {
+		return WIDE ? ghead[score] : (uint32_t)s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x];
+	};
+	auto head_set = [&](int score, uint32_t v) {
+		if (WIDE) ghead[score] = v; else s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x] = (uint16_t)v;
+	};
+	auto mask_has = [&](int score) -> bool { return score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull); };
+	// append an entry to the in-memory list of its score (n_entries is maintained by the callers)
+	auto push_mem = [&](int score, uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int na) {
+		if (ovf) return;
+		uint32_t s;
+		if (WIDE && nfree) s = freel[--nfree];
+		else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
+		const uint32_t prev = mask_has(score) ? head_get(score) : NIL;
+		const uint32_t z = (uint32_t)ni | (uint32_t)nldp << 16;
+		if (WIDE) {
+			ent[s] = make_uint4(nk, nl, z, (uint32_t)nmm | (uint32_t)ngo << 8 | (uint32_t)nge << 16 | (uint32_t)nstate << 24 | (uint32_t)na << 26);
+			lnk[s] = prev;
+		} else {
+			ent[s] = make_uint4(nk, nl, z, prev | (uint32_t)nmm << 16 | (uint32_t)ngo << 20 | (uint32_t)nge << 24 | (uint32_t)nstate << 29 | (uint32_t)na << 31);
+		}
+		head_set(score, s);
+		if (score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64);
+	};
 
 	for (;;) {
 		// ---------------------------------------------------------------- refill
@@ -88,13 +174,16 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 				if (idx < (unsigned int)P.n) {
 					item = idx;
 					const uint32_t rid = P.ids ? (uint32_t)P.ids[idx] : idx;
-					const int64_t o = P.off[rid];
-					len = (int)(P.off[rid + 1] - o);
+					const int64_t o = P.poff[rid];
+					len = P.rd_len[rid];
 					sq0 = P.seq + o; sq1 = P.rseq + o;
 					md_read = P.rd_maxdiff[rid]; mg_read = P.rd_maxgapo[rid];
-					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; nN = 0; rd_touch = 0;
-					if (len > 0) { pass = 0; wi = 0; wbid = 0; k = 0; l = P.bwt[0].seq_len; st = ST_WIDTH; }
-					else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
+					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; nN = 0; rd_touch = 0; ovf = false;
+					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false;
+					if (len > 0) {
+						pass = 0; wi = 0; wbid = 0; k = 0; l = P.bwt[0].seq_len; prev_w = 0;
+						bacc_lo = bacc_hi = 0; st = ST_WIDTH;
+					} else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
 				} else st = ST_EXIT;
 			}
 		}
@@ -107,32 +196,48 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 			if (n_entries == 0) finish = true;
 			else {
 				if (max_ent < n_entries) max_ent = n_entries;
-				if (n_entries > P.max_entries) finish = true;
+				if (n_entries > P.max_entries) finish = true;                 // bwtgap.c:140
 			}
 			if (!finish) {
-				const int best = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1 : 64 + __ffsll((unsigned long long)mask_hi) - 1;
-				const LinkT s = head[best];
-				const uint4 e = ent[s];
-				const LinkT nx = lnk[s];
-				head[best] = nx;
-				if (nx == NIL) { if (best < 64) mask_lo &= ~(1ull << best); else mask_hi &= ~(1ull << (best - 64)); }
-				if (REUSE) freel[nfree++] = s;
+				const int best_mem = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1
+											 : (mask_hi ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff);
+				int pscore;
+				if (p_valid && p_score <= best_mem) {
+					// the pending child is the newest entry of the lowest score: it is the pop
+					k = p_k; l = p_l; e_i = p_i; e_ldp = p_ldp; e_mm = p_mm; e_go = p_go; e_ge = p_ge; e_state = p_state; e_a = p_a;
+					pscore = p_score; p_valid = false;
+				} else {
+					if (p_valid) { push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a); p_valid = false; }
+					const uint32_t s = head_get(best_mem);
+					const uint4 e = ent[s];
+					uint32_t nx;
+					k = e.x; l = e.y; e_i = (int)(e.z & 0xffffu); e_ldp = (int)(e.z >> 16);
+					if (WIDE) {
+						nx = lnk[s];
+						e_mm = (int)(e.w & 0xffu); e_go = (int)(e.w >> 8 & 0xffu); e_ge = (int)(e.w >> 16 & 0xffu);
+						e_state = (int)(e.w >> 24 & 3u); e_a = (int)(e.w >> 26 & 1u);
+						freel[nfree++] = s;
+					} else {
+						nx = e.w & 0xffffu;
+						e_mm = (int)(e.w >> 16 & 15u); e_go = (int)(e.w >> 20 & 15u); e_ge = (int)(e.w >> 24 & 31u);
+						e_state = (int)(e.w >> 29 & 3u); e_a = (int)(e.w >> 31);
+					}
+					head_set(best_mem, nx);
+					if (nx == NIL) { if (best_mem < 64) mask_lo &= ~(1ull << best_mem); else mask_hi &= ~(1ull << (best_mem - 64)); }
+					pscore = best_mem;
+				}
 				--n_entries;
-				k = e.x; l = e.y;
-				e_i = (int)(e.z & 0xffffu); e_ldp = (int)(e.z >> 16);
-				e_mm = (int)(e.w & 0xffu); e_go = (int)(e.w >> 8 & 0xffu); e_ge = (int)(e.w >> 16 & 0xffu);
-				e_state = (int)(e.w >> 24 & 3u); e_a = (int)(e.w >> 26 & 1u);
-				if (!nonstop && best > best_score + P.s_mm) finish = true;      // bwtgap.c:144
+				if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
+				else if (!nonstop && pscore > best_score + P.s_mm) finish = true;   // bwtgap.c:144
 				else {
 					m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
 					m_seed = P.max_seed_diff - (e_mm + e_go); if (gape_mode) m_seed -= e_ge;
 					bool skip = m < 0;
-					if (!skip && e_i > 0 && m < (int)Bd[e_a * P.WL + e_i - 1]) skip = true;   // bwtgap.c:156
+					if (!skip && e_i > 0 && m < (int)(bid_at(e_a, e_i - 1) & 127u)) skip = true;   // bwtgap.c:156
 					if (!skip) {
-						if (e_i == 0) {
-							st = ST_EXACT; xt = -1;       // a hit as it stands; handled in stage C without a query
-						} else if (m == 0 && (e_state == STATE_M || gape_mode || e_ge == P.max_gape)) {
-							st = ST_EXACT; xt = e_i - 1;  // nothing may differ any more: exact tail (bwt.c:237-252)
+						if (e_i == 0) { st = ST_EXACT; xt = -1; }       // a hit as it stands; stage C, no query
+						else if (m == 0 && (e_state == STATE_M || gape_mode || e_ge == P.max_gape)) {
+							st = ST_EXACT; xt = e_i - 1;                 // nothing may differ any more: exact tail (bwt.c:237-252)
 						} else { st = ST_EXPAND; --e_i; }
 					}
 				}
@@ -144,14 +249,14 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 		if (st == ST_WIDTH) {
 			const int sbase = pass < 2 ? 0 : len - P.seed_len;
 			qb = pass & 1;
-			c = (qb ? sq1 : sq0)[sbase + wi];
+			c = seq_at(qb, sbase + wi);
 			query = c < 4;
 		} else if (st == ST_EXACT) {
 			qb = 1 - e_a;
-			if (xt >= 0) { c = (e_a ? sq1 : sq0)[xt]; query = c < 4; }
+			if (xt >= 0) { c = seq_at(e_a, xt); query = c < 4; }
 		} else if (st == ST_EXPAND) {
 			qb = 1 - e_a; query = true;
-			c = (e_a ? sq1 : sq0)[e_i];
+			c = seq_at(e_a, e_i);
 		}
 		Occ4 ck, cl;
 		if (query) nabwa_occ4_pair(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, ck, cl);
@@ -170,14 +275,27 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 			if (c < 4) { k = L2Q(c) + CK(c) + 1u; l = L2Q(c) + CL(c); }
 			else if (pass == 0) ++nN;
 			if (k > l || c > 3) { k = 0; l = seqlen_q; ++wbid; }
-			uint32_t *wp = pass < 2 ? Wd + qb * P.WL : SWd + qb * P.SL;
-			uint8_t *bp = pass < 2 ? Bd + qb * P.WL : SBd + qb * P.SL;
-			wp[wi] = l - k + 1u; bp[wi] = (uint8_t)(wbid > 255 ? 255 : wbid);
-			if (++wi == n) {
-				++wbid; wp[n] = 0; bp[n] = (uint8_t)(wbid > 255 ? 255 : wbid);
+			uint32_t *const wp = Wd + qb * P.WL;
+			uint8_t *const bp = pass < 2 ? Bd + qb * P.WLB : SBd + qb * P.SLB;
+			// results are gathered in registers and stored 16 bytes at a time
+			auto record = [&](uint32_t wv, bool last) {
+				const uint32_t bv = (uint32_t)(wbid > 127 ? 127 : wbid) | ((wi > 0 && wv == prev_w) ? 128u : 0u);
+				set_word(wacc, (uint32_t)wi & 3u, wv);
+				{ const uint64_t sh = (uint64_t)bv << (((uint32_t)wi & 7u) << 3); if (wi & 8) bacc_hi |= sh; else bacc_lo |= sh; }
+				prev_w = wv;
+				if (pass < 2 && ((wi & 3) == 3 || last)) *(uint4*)(wp + (wi & ~3)) = wacc;
+				if ((wi & 15) == 15 || last) {
+					*(uint4*)(bp + (wi & ~15)) = make_uint4((uint32_t)bacc_lo, (uint32_t)(bacc_lo >> 32), (uint32_t)bacc_hi, (uint32_t)(bacc_hi >> 32));
+					bacc_lo = bacc_hi = 0;
+				}
+				++wi;
+			};
+			record(l - k + 1u, false);
+			if (wi == n) {
+				++wbid; record(0u, true);      // terminator: width[len] = {0, ++bid} (bwtaln.c:73-74)
 				++pass;
 				if (pass == 2 && len <= P.seed_len) pass = 4;
-				if (pass < 4) { wi = 0; wbid = 0; k = 0; l = (pass & 1) ? P.bwt[1].seq_len : P.bwt[0].seq_len; }
+				if (pass < 4) { wi = 0; wbid = 0; k = 0; l = (pass & 1) ? P.bwt[1].seq_len : P.bwt[0].seq_len; prev_w = 0; }
 				else {
 					// ---- start of bwt_match_gap (bwtgap.c:104-128)
 					seeded = len > P.seed_len;
@@ -186,11 +304,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 						max_diff = md_read;
 						best_score = (md_read + 1) * P.s_mm + (mg_read + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
 						best_cnt = 0;
-						// roots: strand 0 pushed first, strand 1 second -> strand 1 is expanded first
-						ent[0] = make_uint4(0u, P.bwt[0].seq_len, (uint32_t)len, 0u);
-						ent[1] = make_uint4(0u, P.bwt[0].seq_len, (uint32_t)len, 1u << 26);
-						lnk[0] = NIL; lnk[1] = (LinkT)0; head[0] = (LinkT)1;
-						bump = 2; nfree = 0; n_entries = 2; mask_lo = 1ull; mask_hi = 0ull;
+						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
+						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
+						push_mem(0, 0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0);
+						p_valid = true; p_k = 0u; p_l = P.bwt[0].seq_len; p_i = len; p_ldp = 0; p_mm = p_go = p_ge = 0;
+						p_state = STATE_M; p_a = 1; p_score = 0;
+						n_entries = 2;
 						st = ST_POP;
 					}
 				}
@@ -223,21 +342,34 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 				if (do_add) {
 					if (n_aln == P.aln_cap) { status = NABWA_ST_OVERFLOW; finish = true; }
 					else {
-						// gap_shadow (bwtgap.c:81-91) on this strand's bounds, positions < last_diff_pos
-						const uint32_t x = l - k + 1u, mx = seqlen_q; uint32_t jj = 0;
-						uint32_t *wp = Wd + e_a * P.WL; uint8_t *bp = Bd + e_a * P.WL;
-						for (int t0 = 0; t0 < e_ldp; t0 += 4) {
-							uint4 w4 = *(const uint4*)(wp + t0);
-							uint32_t wv[4] = { w4.x, w4.y, w4.z, w4.w };
+						// gap_shadow (bwtgap.c:81-91) on this strand's bounds, positions < last_diff_pos;
+						// 8 positions per trip; the weq flags of positions 1..last_diff_pos are refreshed
+						const uint32_t x = l - k + 1u, mx = seqlen_q; uint32_t jj = 0, pw = 0;
+						uint32_t *const wp = Wd + e_a * P.WL; uint8_t *const bp = Bd + e_a * P.WLB;
+						for (int t0 = 0; t0 <= e_ldp && e_ldp > 0; t0 += 8) {
+							const uint4 w0 = *(const uint4*)(wp + t0), w1 = *(const uint4*)(wp + t0 + 4);
+							const uint2 bq = *(const uint2*)(bp + t0);
+							uint32_t wv[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
+							uint32_t bb[2] = { bq.x, bq.y };
 #pragma unroll
-							for (int u = 0; u < 4; ++u) {
-								if (t0 + u < e_ldp) {
+							for (int u = 0; u < 8; ++u) {
+								const int t = t0 + u;
+								uint32_t bv = bb[u >> 2] >> ((u & 3) * 8) & 0xffu;
+								if (t < e_ldp) {
 									if (wv[u] > x) wv[u] -= x;
-									else if (wv[u] == x) { bp[t0 + u] = 1; wv[u] = mx - (++jj); }
+									else if (wv[u] == x) { bv = (bv & 128u) | 1u; wv[u] = mx - (++jj); }
 								}
+								if (t <= e_ldp) {
+									bv = (bv & 127u) | ((t > 0 && wv[u] == pw) ? 128u : 0u);
+									bb[u >> 2] = (bb[u >> 2] & ~(0xffu << ((u & 3) * 8))) | bv << ((u & 3) * 8);
+								}
+								pw = wv[u];
 							}
 							*(uint4*)(wp + t0) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+							*(uint4*)(wp + t0 + 4) = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+							*(uint2*)(bp + t0) = make_uint2(bb[0], bb[1]);
 						}
+						bw_a = -1;   // the bound window may be stale now
 						out[n_aln] = make_uint4((uint32_t)e_mm | (uint32_t)e_go << 8 | (uint32_t)e_ge << 16 | (uint32_t)e_a << 24,
 												k, l, (uint32_t)score);
 						++n_aln;
@@ -248,38 +380,25 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 			// ---- node expansion (bwtgap.c:201-260); e_i is already decremented
 			st = ST_POP;
 			const uint32_t occ = l - k + 1u;
-			const uint32_t *wp = Wd + e_a * P.WL; const uint8_t *bp = Bd + e_a * P.WL;
 			bool allow_diff = true, allow_M = true;
 			if (e_i > 0) {
-				const int b1 = bp[e_i - 1], b0 = bp[e_i];
+				const uint32_t B1 = bid_at(e_a, e_i - 1), B0 = bid_at(e_a, e_i);
+				const int b1 = (int)(B1 & 127u), b0 = (int)(B0 & 127u);
 				if (b1 > m - 1) allow_diff = false;
-				else if (b1 == m - 1 && b0 == m - 1 && wp[e_i - 1] == wp[e_i]) allow_M = false;
+				else if (b1 == m - 1 && b0 == m - 1 && (B0 & 128u)) allow_M = false;
 				const int ii = e_i - (len - P.seed_len);
 				if (seeded && ii > 0) {
-					const uint32_t *swp = SWd + e_a * P.SL; const uint8_t *sbp = SBd + e_a * P.SL;
-					const int s1 = sbp[ii - 1], s0 = sbp[ii];
+					const uint32_t S1 = sbid_at(e_a, ii - 1), S0 = sbid_at(e_a, ii);
+					const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
 					if (s1 > m_seed - 1) allow_diff = false;
-					else if (s1 == m_seed - 1 && s0 == m_seed - 1 && swp[ii - 1] == swp[ii]) allow_M = false;
+					else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
 				}
 			}
-			// children are appended to per-score lists; consecutive pushes of one score chain locally
-			int cs = -1; LinkT ch = NIL; bool ovf = false;
-			auto push = [&](int score, uint32_t nk, uint32_t nl, int ni, int nmm, int ngo, int nge, int nstate, bool is_diff) {
-				if (ovf) return;
-				if (score != cs) {
-					if (cs >= 0) head[cs] = ch;
-					cs = score;
-					const bool has = score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull);
-					ch = has ? head[score] : NIL;
-				}
-				uint32_t s;
-				if (REUSE && nfree) s = freel[--nfree];
-				else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
-				ent[s] = make_uint4(nk, nl, (uint32_t)ni | (uint32_t)(is_diff ? ni : 0) << 16,
-									(uint32_t)(nmm & 0xff) | (uint32_t)(ngo & 0xff) << 8 | (uint32_t)(nge & 0xff) << 16 |
-									(uint32_t)nstate << 24 | (uint32_t)e_a << 26);
-				lnk[s] = ch; ch = (LinkT)s;
-				if (score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64);
+			// children go through a one-entry delay: the last one stays in registers as `pending`
+			auto emit = [&](int score, uint32_t nk, uint32_t nl, int ni, int nmm, int ngo, int nge, int nstate, bool is_diff) {
+				if (p_valid) push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a);
+				p_valid = true; p_k = nk; p_l = nl; p_i = ni; p_ldp = is_diff ? ni : 0;
+				p_mm = nmm & 0xff; p_go = ngo & 0xff; p_ge = nge & 0xff; p_state = nstate; p_a = e_a; p_score = score;
 				++n_entries;
 			};
 			const int sc0 = e_mm * P.s_mm + e_go * P.s_gapo + e_ge * P.s_gape;
@@ -288,21 +407,21 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 			if (allow_diff && e_i >= P.indel_end_skip + tmp && len - e_i >= P.indel_end_skip + tmp) {
 				if (e_state == STATE_M) {
 					if (e_go < mg_read) {
-						push(sc0 + P.s_gapo, k, l, e_i, e_mm, e_go + 1, e_ge, STATE_I, true);
+						emit(sc0 + P.s_gapo, k, l, e_i, e_mm, e_go + 1, e_ge, STATE_I, true);
 #pragma unroll
 						for (int j = 0; j < 4; ++j) {
 							const uint32_t nk = L2Q(j) + CK(j) + 1u, nl = L2Q(j) + CL(j);
-							if (nk <= nl) push(sc0 + P.s_gapo, nk, nl, e_i + 1, e_mm, e_go + 1, e_ge, STATE_D, true);
+							if (nk <= nl) emit(sc0 + P.s_gapo, nk, nl, e_i + 1, e_mm, e_go + 1, e_ge, STATE_D, true);
 						}
 					}
 				} else if (e_state == STATE_I) {
-					if (e_ge < P.max_gape) push(sc0 + P.s_gape, k, l, e_i, e_mm, e_go, e_ge + 1, STATE_I, true);
+					if (e_ge < P.max_gape) emit(sc0 + P.s_gape, k, l, e_i, e_mm, e_go, e_ge + 1, STATE_I, true);
 				} else if (e_ge < P.max_gape) {
 					if (e_ge + e_go < max_diff || occ < (uint32_t)P.max_del_occ) {
 #pragma unroll
 						for (int j = 0; j < 4; ++j) {
 							const uint32_t nk = L2Q(j) + CK(j) + 1u, nl = L2Q(j) + CL(j);
-							if (nk <= nl) push(sc0 + P.s_gape, nk, nl, e_i + 1, e_mm, e_go, e_ge + 1, STATE_D, true);
+							if (nk <= nl) emit(sc0 + P.s_gape, nk, nl, e_i + 1, e_mm, e_go, e_ge + 1, STATE_D, true);
 						}
 					}
 				}
@@ -312,13 +431,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 				for (int j = 1; j <= 4; ++j) {
 					const int cc = (c + j) & 3; const bool is_mm = (j != 4 || c > 3);
 					const uint32_t nk = L2Q(cc) + CK(cc) + 1u, nl = L2Q(cc) + CL(cc);
-					if (nk <= nl) push(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, is_mm);
+					if (nk <= nl) emit(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, is_mm);
 				}
 			} else if (c < 4) {
 				const uint32_t nk = L2Q(c) + CK(c) + 1u, nl = L2Q(c) + CL(c);
-				if (nk <= nl) push(sc0, nk, nl, e_i, e_mm, e_go, e_ge, STATE_M, false);
+				if (nk <= nl) emit(sc0, nk, nl, e_i, e_mm, e_go, e_ge, STATE_M, false);
 			}
-			if (cs >= 0) head[cs] = ch;
 			if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 		}
 #undef L2Q
@@ -339,19 +457,41 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const Sea
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
 {
+	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2;
 	if (P->touch_counter) {
-		if (wide) hipLaunchKernelGGL((fm_search_kernel<uint32_t, true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
-		else hipLaunchKernelGGL((fm_search_kernel<uint16_t, false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
-	} else if (wide) hipLaunchKernelGGL((fm_search_kernel<uint32_t, true, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
-	else hipLaunchKernelGGL((fm_search_kernel<uint16_t, false, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+		if (wide) hipLaunchKernelGGL((fm_search_kernel<true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
+		else hipLaunchKernelGGL((fm_search_kernel<false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
+	} else if (wide) hipLaunchKernelGGL((fm_search_kernel<true, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
+	else hipLaunchKernelGGL((fm_search_kernel<false, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
 }
 
-extern "C" int nabwa_search_occupancy(int wide)
+extern "C" int nabwa_search_occupancy(int wide, int ns)
 {
 	int nb = 0;
-	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint32_t, true, false>, NABWA_SEARCH_BLOCK, 0)
-						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<uint16_t, false, false>, NABWA_SEARCH_BLOCK, 0);
+	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<true, false>, NABWA_SEARCH_BLOCK, 0)
+						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false, false>, NABWA_SEARCH_BLOCK,
+																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2);
 	return e == hipSuccess ? nb : 0;
+}
+
+// re-lay the reads out with every read starting on a 16-byte boundary (register windows load 16 bases)
+__global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ rseq,
+													const int64_t *__restrict__ off, const int64_t *__restrict__ poff,
+													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const int64_t o = off[i], p = poff[i];
+	const int L = (int)(off[i + 1] - o), PL = (int)(poff[i + 1] - p);
+	rd_len[i] = L;
+	for (int j = 0; j < PL; ++j) { pseq[p + j] = j < L ? seq[o + j] : 4; prseq[p + j] = j < L ? rseq[o + j] : 4; }
+}
+
+extern "C" void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
+									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len);
 }
 
 // ids of the reads whose first pass was abandoned (arena or hit list outgrown)

@@ -10,8 +10,9 @@
 struct SearchParams {
 	DevBwt bwt[2];
 	// reads (device): codes 0-3, 4 = N; seq = read reversed, rseq = reverse complement
-	const uint8_t *seq, *rseq;
-	const int64_t *off;
+	const uint8_t *seq, *rseq;                // padded layout: read i starts at poff[i], a multiple of 16
+	const int64_t *poff;
+	const int32_t *rd_len;
 	const uint8_t *rd_maxdiff, *rd_maxgapo;   // per read: max_diff and clamped max_gapo (host-side FP, bwtaln.c:104-105,125)
 	const int32_t *ids;                       // work item -> read id (wide pass), or null
 	int n;
@@ -20,8 +21,8 @@ struct SearchParams {
 	// per-lane scratch
 	uint8_t *scratch;
 	size_t lane_stride;
-	uint32_t off_link, off_free, off_head, off_w, off_sw, off_bid, off_sbid;
-	uint32_t cap, WL, SL, NS;
+	uint32_t off_link, off_free, off_head, off_w, off_bid, off_sbid;
+	uint32_t cap, WL, WLB, SLB, NS;           // WL: u32 widths per strand; WLB/SLB: bound bytes per strand (search / seed)
 	// outputs, indexed by work item
 	int32_t *n_aln, *max_ent;
 	uint8_t *status;

@@ -26,7 +26,9 @@ void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2
 void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, const uint4 *aln, int aln_cap,
 						 const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						 uint4 *out, hipStream_t s);
-int nabwa_search_occupancy(int wide);
+int nabwa_search_occupancy(int wide, int ns);
+void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
+							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -193,7 +195,7 @@ struct nabwa_batch {
 	hipEvent_t ev0, ev1;
 	float last_ms;
 	// device inputs
-	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_off;
+	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; int max_len;
 	// first pass
 	SearchParams P; int n_blocks; uint8_t *d_scratch;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
@@ -212,20 +214,20 @@ static int env_int(const char *name, int dflt)
 
 static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-static void layout(SearchParams &P, uint32_t cap, uint32_t link_bytes, bool reuse, int max_len, int seed_len, uint32_t NS)
+static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int seed_len, uint32_t NS)
 {
 	P.cap = cap;
-	P.WL = align_up((uint32_t)max_len + 1, 4);
-	P.SL = align_up((uint32_t)seed_len + 1, 4);
+	P.WL = align_up((uint32_t)max_len + 1, 16);
+	P.WLB = P.WL + 16;
+	P.SLB = align_up((uint32_t)seed_len + 1, 16) + 16;
 	P.NS = NS;
 	uint32_t o = cap * 16;
-	P.off_link = o; o = align_up(o + cap * link_bytes, 16);
-	P.off_free = o; if (reuse) o = align_up(o + cap * link_bytes, 16);
-	P.off_head = o; o = align_up(o + NS * link_bytes, 16);
+	P.off_link = o; if (wide) o = align_up(o + cap * 4, 16);
+	P.off_free = o; if (wide) o = align_up(o + cap * 4, 16);
+	P.off_head = o; if (wide) o = align_up(o + NS * 4, 16);
 	P.off_w = o; o += 2 * P.WL * 4;
-	P.off_sw = o; o += 2 * P.SL * 4;
-	P.off_bid = o; o += 2 * P.WL;
-	P.off_sbid = o; o += 2 * P.SL;
+	P.off_bid = o; o += 2 * P.WLB;
+	P.off_sbid = o; o += 2 * P.SLB;
 	P.lane_stride = align_up(o, 64);
 }
 
@@ -233,7 +235,7 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->ix->device);
-	void *ptrs[] = { b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_off, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+	void *ptrs[] = { b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -268,12 +270,13 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		const int md_sizing = md_of[per_read ? L : max_len];
 		int g = opt->max_gapo; if (md_sizing < g) g = md_sizing;
 		const int d = md_of[L];
-		if (d < 0 || d > 254 || g < 0 || g > 254) return fail(NABWA_EINVAL, "max_diff / max_gapo outside 0..254");
+		/* first-pass arena entries keep n_mm / n_gapo in 4 bits and n_gape in 5 (fm_search.hip) */
+		if (d < 0 || d > 14 || g < 0 || g > 15) return fail(NABWA_EINVAL, "max_diff > 14 or max_gapo > 15 (unsupported)");
 		md[i] = (uint8_t)d; mg[i] = (uint8_t)g;
 		const long ns = (long)(md_sizing + 1) * opt->s_mm + (long)(g + 1) * opt->s_gapo + (long)(opt->max_gape + 1) * opt->s_gape;
 		if (ns > (long)NS) NS = (uint32_t)ns;
 	}
-	if (NS > 128 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 254)
+	if (NS > 128 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 31)
 		return fail(NABWA_EINVAL, "option block needs more than 128 score levels (unsupported)");
 	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
 
@@ -283,22 +286,33 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipStreamCreate(&b->stream));
 	BCHK(hipEventCreate(&b->ev0));
 	BCHK(hipEventCreate(&b->ev1));
-	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1;
-	BCHK(hipMalloc(&b->d_seq, nb)); BCHK(hipMalloc(&b->d_rseq, nb));
-	BCHK(hipMalloc(&b->d_off, (size_t)(n + 1) * 8));
+	// reads: upload as given, then re-lay out on the device with 16-byte aligned starts
+	std::vector<int64_t> poff(n + 1);
+	poff[0] = 0;
+	for (int i = 0; i < n; ++i) poff[i + 1] = poff[i] + ((off[i + 1] - off[i] + 15) / 16) * 16;
+	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1, pnb = (size_t)poff[n] + 64;
+	b->max_len = max_len;
+	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
+	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
 	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1));
+	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
-		BCHK(hipMemcpy(b->d_seq, seq, (size_t)off[n], hipMemcpyHostToDevice));
-		BCHK(hipMemcpy(b->d_rseq, rseq, (size_t)off[n], hipMemcpyHostToDevice));
+		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
+		BCHK(hipMalloc(&raw_s, nb)); BCHK(hipMalloc(&raw_r, nb)); BCHK(hipMalloc(&raw_off, (size_t)(n + 1) * 8));
+		BCHK(hipMemcpy(raw_s, seq, (size_t)off[n], hipMemcpyHostToDevice));
+		BCHK(hipMemcpy(raw_r, rseq, (size_t)off[n], hipMemcpyHostToDevice));
+		BCHK(hipMemcpy(raw_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->stream);
+		BCHK(hipStreamSynchronize(b->stream));
+		BCHK(hipFree(raw_s)); BCHK(hipFree(raw_r)); BCHK(hipFree(raw_off));
 		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));
 		BCHK(hipMemcpy(b->d_mg, mg.data(), n, hipMemcpyHostToDevice));
 	}
-	BCHK(hipMemcpy(b->d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 
 	SearchParams &P = b->P;
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
-	P.seq = b->d_seq; P.rseq = b->d_rseq; P.off = b->d_off; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg;
+	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg;
 	P.ids = 0; P.n = n;
 	P.s_mm = opt->s_mm; P.s_gapo = opt->s_gapo; P.s_gape = opt->s_gape; P.mode = opt->mode;
 	P.indel_end_skip = opt->indel_end_skip; P.max_del_occ = opt->max_del_occ; P.max_entries = opt->max_entries;
@@ -306,13 +320,13 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	int cap1 = env_int("NABWA_CAP1", 4096);
 	if (cap1 < 16) cap1 = 16;
 	if (cap1 > 65534) cap1 = 65534;
-	layout(P, (uint32_t)cap1, 2, false, max_len, opt->seed_len, NS);
+	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, NS);
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	if (P.aln_cap < 1) P.aln_cap = 1;
 
 	hipDeviceProp_t prop;
 	BCHK(hipGetDeviceProperties(&prop, ix->device));
-	int occ = nabwa_search_occupancy(0);
+	int occ = nabwa_search_occupancy(0, (int)NS);
 	if (occ < 1) occ = 1;
 	const int occ_env = env_int("NABWA_BLOCKS_PER_CU", 0);
 	if (occ_env > 0) occ = occ_env;
@@ -374,8 +388,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	}
 	SearchParams Q = b->P;
 	uint64_t cap2 = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
-	const int max_len = (int)Q.WL - 1;
-	layout(Q, (uint32_t)cap2, 4, true, max_len, b->opt.seed_len, Q.NS);
+	layout(Q, (uint32_t)cap2, true, b->max_len, b->opt.seed_len, Q.NS);
 	long blocks2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
 	const long max_blocks2 = env_int("NABWA_WIDE_BLOCKS", 2);
 	if (blocks2 > max_blocks2) blocks2 = max_blocks2;
