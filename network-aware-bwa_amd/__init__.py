@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnabwa.so")
+LIB_PATH = os.environ.get("NABWA_LIB", os.path.join(_HERE, "libnabwa.so"))   # NABWA_LIB: A/B builds
 
 OK, ENODEV, EINVAL, EIO, ENOMEM, ECAP = 0, -1, -2, -3, -4, -5
 

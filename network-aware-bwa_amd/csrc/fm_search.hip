@@ -75,8 +75,12 @@ __device__ __forceinline__ void set_word(uint4 &q, uint32_t c, uint32_t v)
 
 extern __shared__ uint16_t s_head[];   // first pass only: [score][lane of the block]
 
+#ifndef NABWA_MIN_WAVES
+#define NABWA_MIN_WAVES 4   // 128 VGPRs: 4 blocks per CU (measured +10 % over 3)
+#endif
+
 template <bool WIDE, bool COUNT>
-__global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_search_kernel(const SearchParams P)
+__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P)
 {
 	const uint32_t NIL = WIDE ? 0xffffffffu : 0xffffu;
 	const uint32_t lane = threadIdx.x & 63u;
