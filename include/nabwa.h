@@ -95,9 +95,12 @@ int nabwa_batch_run(nabwa_batch_t *b);
 int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass);
 /* HIP-event time of the most recent run of the dominant kernel (fm_search, first pass), ms */
 float nabwa_batch_last_kernel_ms(nabwa_batch_t *b);
+/* same for the width kernel (fm_width) that precedes it */
+float nabwa_batch_last_width_ms(nabwa_batch_t *b);
 /* untimed instrumented run: Occ-bucket touches the reference algorithm performs on this batch
- * (1 per bwt_occ/bwt_occ4 body, 1 per same-block bwt_2occ/bwt_2occ4) */
-int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket);
+ * (1 per bwt_occ/bwt_occ4 body, 1 per same-block bwt_2occ/bwt_2occ4), split into
+ * those of bwt_match_gap (search kernel) and of the bwt_cal_width passes (width kernel) */
+int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, uint64_t *n_bucket_width);
 int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
 					  int32_t *max_entries);
 /* order-independent 64-bit checksum of (read id, row index, row) over all hits, computed on the device */

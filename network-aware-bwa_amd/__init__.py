@@ -77,9 +77,11 @@ def lib():
     L.nabwa_batch_sync.argtypes = [_P, _P]
     L.nabwa_batch_last_kernel_ms.restype = C.c_float
     L.nabwa_batch_last_kernel_ms.argtypes = [_P]
+    L.nabwa_batch_last_width_ms.restype = C.c_float
+    L.nabwa_batch_last_width_ms.argtypes = [_P]
     L.nabwa_batch_fetch.argtypes = [_P, _P, _P, C.c_int64, _P, _P]
     L.nabwa_batch_checksum.argtypes = [_P, _P, _P]
-    L.nabwa_batch_count_touches.argtypes = [_P, _P]
+    L.nabwa_batch_count_touches.argtypes = [_P, _P, _P]
     L.nabwa_batch_destroy.argtypes = [_P]
     L.nabwa_batch_destroy.restype = None
     L.nabwa_sa_lookup.argtypes = [_P, C.c_int, _P, _P, _P]
@@ -202,6 +204,9 @@ class Batch:
     def last_kernel_ms(self):
         return float(lib().nabwa_batch_last_kernel_ms(self._h))
 
+    def last_width_ms(self):
+        return float(lib().nabwa_batch_last_width_ms(self._h))
+
     def checksum(self):
         s = C.c_uint64()
         r = C.c_int64()
@@ -210,9 +215,9 @@ class Batch:
 
     def count_touches(self):
         """Occ-bucket touches of the reference algorithm on this batch (untimed instrumented run)."""
-        v = C.c_uint64()
-        _chk(lib().nabwa_batch_count_touches(self._h, C.byref(v)))
-        return v.value
+        v, w = C.c_uint64(), C.c_uint64()
+        _chk(lib().nabwa_batch_count_touches(self._h, C.byref(v), C.byref(w)))
+        return v.value, w.value   # (search kernel, width kernel)
 
     def fetch(self):
         n_aln = np.zeros(max(self.n, 1), np.int32)

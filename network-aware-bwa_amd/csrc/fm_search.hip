@@ -5,12 +5,14 @@
 // pop/push order of the reference's per-score LIFO stacks (bwtgap.c:46-79) because that order
 // decides which hits are found and in which order they are reported.
 //
-// Execution model: a persistent grid; every lane runs its own state machine and draws the
-// next read from a global work counter when it finishes one (wave ballot + one atomic per
-// wave).  Every trip of the wave loop performs at most ONE "rank step" per lane -- Occ of all
-// four bases at rows (k-1, l) of one index, one or two 64-byte bucket fetches -- whatever the
-// lane is doing (width pass, exact tail match, node expansion), so lanes in different phases
-// stay converged on the expensive part: the bucket gathers.
+// Execution model: two persistent kernels per batch.  Kernel W (fm_width_kernel) runs the width
+// passes: every lane executes the same code on every trip (one step of two passes = two rank
+// queries), so its waves are fully converged.  Kernel S (fm_search_kernel) runs the search:
+// every lane is its own state machine (pop / exact-tail step / node expansion) and performs at
+// most ONE rank query -- Occ of all four bases at rows (k-1, l), one or two 64-byte bucket
+// fetches -- per trip.  In both, a lane that finishes a read draws the next one from a global
+// work counter (wave ballot + one atomic per wave).  v2 had both phases in one loop and ran at
+// 31 % VALU lane utilisation, issue-bound (profiles/r01_v2_pmc.json); hence the split.
 //
 // Memory discipline (v2).  With ~260 k reads in flight the caches hold ~128 B of L2 and ~1 KB of
 // Infinity Cache per lane, so every touch of lane-private state in HBM costs a 64-byte
@@ -73,12 +75,127 @@ __device__ __forceinline__ void set_word(uint4 &q, uint32_t c, uint32_t v)
 	q.x = c == 0 ? v : q.x; q.y = c == 1 ? v : q.y; q.z = c == 2 ? v : q.z; q.w = c == 3 ? v : q.w;
 }
 
-extern __shared__ uint16_t s_head[];   // first pass only: [score][lane of the block]
+extern __shared__ uint16_t s_head[];   // search kernel, first pass only: [score][lane of the block]
 
 #ifndef NABWA_MIN_WAVES
 #define NABWA_MIN_WAVES 4   // 128 VGPRs: 4 blocks per CU (measured +10 % over 3)
 #endif
 
+// =====================================================================================
+// Kernel W: the four bwt_cal_width passes (bwtaln.c:52-76,123-130) of every read.
+// All lanes run the same code on every trip (one width step of TWO passes: the forward-index
+// pass on seq and the reverse-index pass on rseq, then the same for the seed suffix), so the
+// wave stays converged; results go to the read's own record in HBM in 16-byte chunks:
+//   Wd [2][WL]  u32 interval widths (only gap_shadow reads them later)
+//   Bd [2][WLB] bound bytes: min(bid,127) | (w[i-1]==w[i]) << 7
+//   SBd[2][SLB] the same for the seed passes
+// =====================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const SearchParams P)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	bool run = false, done = false;
+	uint32_t rid = 0; int len = 0, phase = 0, wi = 0, n = 0, sbase = 0, nN = 0;
+	const uint8_t *sq[2] = { 0, 0 }; uint8_t *rec = 0;
+	uint32_t kk[2] = { 0, 0 }, ll[2] = { 0, 0 }, pw[2] = { 0, 0 }; int bid[2] = { 0, 0 };
+	uint4 wacc[2]; uint64_t blo[2] = { 0, 0 }, bhi[2] = { 0, 0 }, slo[2] = { 0, 0 }, shi[2] = { 0, 0 }; int stag[2] = { -1, -1 };
+	unsigned long long touches = 0;
+	wacc[0] = wacc[1] = make_uint4(0, 0, 0, 0);
+
+	for (;;) {
+		const unsigned long long need = __ballot(!run && !done);
+		if (need) {
+			unsigned int base = 0;
+			if (lane == 0) base = atomicAdd(P.work_counter + 1, (unsigned int)__popcll(need));
+			base = __shfl(base, 0);
+			if (!run && !done) {
+				const unsigned int idx = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+				if (idx < (unsigned int)P.n) {
+					rid = P.ids ? (uint32_t)P.ids[idx] : idx;
+					const int64_t o = P.poff[rid];
+					len = P.rd_len[rid];
+					sq[0] = P.seq + o; sq[1] = P.rseq + o;
+					rec = P.wdata + (size_t)rid * P.wstride;
+					nN = 0; stag[0] = stag[1] = -1;
+					if (len > 0) {
+						run = true; phase = 0; wi = 0; n = len; sbase = 0;
+#pragma unroll
+						for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; blo[x] = bhi[x] = 0; }
+					} else P.rd_nN[rid] = 0;
+				} else done = true;
+			}
+		}
+		if (__ballot(!done) == 0ull) break;
+		if (run) {
+			const int pos = sbase + wi;
+			int c[2]; Occ4 ck[2], cl[2];
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+				const int tag = pos >> 4;
+				if (tag != stag[x]) { const uint4 q = *(const uint4*)(sq[x] + (pos & ~15)); WIN_SET(slo[x], shi[x], q.x, q.y, q.z, q.w); stag[x] = tag; }
+				c[x] = (int)byte_of(slo[x], shi[x], (uint32_t)pos & 15u);
+			}
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+				if (c[x] < 4) {
+					nabwa_occ4_pair(P.bwt[x], kk[x] - 1u, ll[x], ck[x], cl[x]);
+					if (COUNT) touches += ref_touches(P.bwt[x], kk[x] - 1u, ll[x], false);
+				}
+			}
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+				const int cc = c[x];
+				if (cc < 4) {
+					const uint32_t L2c = cc == 0 ? P.bwt[x].L2[0] : (cc == 1 ? P.bwt[x].L2[1] : (cc == 2 ? P.bwt[x].L2[2] : P.bwt[x].L2[3]));
+					const uint32_t ok = cc == 0 ? ck[x].c[0] : (cc == 1 ? ck[x].c[1] : (cc == 2 ? ck[x].c[2] : ck[x].c[3]));
+					const uint32_t ol = cc == 0 ? cl[x].c[0] : (cc == 1 ? cl[x].c[1] : (cc == 2 ? cl[x].c[2] : cl[x].c[3]));
+					kk[x] = L2c + ok + 1u; ll[x] = L2c + ol;
+				} else if (x == 0 && phase == 0) ++nN;
+				if (kk[x] > ll[x] || cc > 3) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; }
+			}
+			uint32_t *const wbase = (uint32_t*)rec;
+			uint8_t *const bbase = rec + (phase ? P.woff_sbid : P.woff_bid);
+			const uint32_t bstride = phase ? P.SLB : P.WLB;
+			// position wi, and after the last one the terminator {w = 0, bid = ++bid} (bwtaln.c:73-74)
+			const bool at_end = wi + 1 == n;
+#pragma unroll
+			for (int rep = 0; rep < 2; ++rep) {
+				if (rep == 1 && !at_end) break;
+				const int p = wi + rep; const bool last = rep == 1;
+#pragma unroll
+				for (int x = 0; x < 2; ++x) {
+					if (last) ++bid[x];
+					const uint32_t wv = last ? 0u : ll[x] - kk[x] + 1u;
+					const uint32_t bv = (uint32_t)(bid[x] > 127 ? 127 : bid[x]) | ((p > 0 && wv == pw[x]) ? 128u : 0u);
+					set_word(wacc[x], (uint32_t)p & 3u, wv);
+					{ const uint64_t sh = (uint64_t)bv << (((uint32_t)p & 7u) << 3); if (p & 8) bhi[x] |= sh; else blo[x] |= sh; }
+					pw[x] = wv;
+					if (phase == 0 && ((p & 3) == 3 || last)) *(uint4*)(wbase + x * P.WL + (p & ~3)) = wacc[x];
+					if ((p & 15) == 15 || last) {
+						*(uint4*)(bbase + x * bstride + (p & ~15)) = make_uint4((uint32_t)blo[x], (uint32_t)(blo[x] >> 32), (uint32_t)bhi[x], (uint32_t)(bhi[x] >> 32));
+						blo[x] = bhi[x] = 0;
+					}
+				}
+			}
+			++wi;
+			if (wi == n) {
+				if (phase == 0 && len > P.seed_len) {
+					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len;
+#pragma unroll
+					for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; }
+				} else { P.rd_nN[rid] = (uint8_t)(nN > 255 ? 255 : nN); run = false; }
+			}
+		}
+	}
+	if (COUNT) {
+		for (int o = 32; o > 0; o >>= 1) touches += __shfl_down(touches, o);
+		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter + 1, touches);
+	}
+}
+
+// =====================================================================================
+// Kernel S: bwt_match_gap (bwtgap.c:104-266), one read per lane, exact pop/push order.
+// =====================================================================================
 template <bool WIDE, bool COUNT>
 __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P)
 {
@@ -90,17 +207,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint32_t *const lnk = (uint32_t*)(sc + P.off_link);     // WIDE only
 	uint32_t *const freel = (uint32_t*)(sc + P.off_free);   // WIDE only
 	uint32_t *const ghead = (uint32_t*)(sc + P.off_head);   // WIDE only
-	uint32_t *const Wd = (uint32_t*)(sc + P.off_w);         // [2][WL] interval widths (gap_shadow only)
-	uint8_t *const Bd = sc + P.off_bid;                     // [2][WLB] bound | weq<<7
-	uint8_t *const SBd = sc + P.off_sbid;                   // [2][SLB] seed bound | weq<<7
 	const bool gape_mode = P.mode & 0x01, nonstop = P.mode & 0x10, loggap = P.mode & 0x04;
 
 	int st = ST_IDLE;
 	// per-read
 	uint32_t item = 0; int len = 0, md_read = 0, mg_read = 0; const uint8_t *sq0 = 0, *sq1 = 0;
-	// width passes
-	int pass = 0, wi = 0, wbid = 0, nN = 0; uint32_t prev_w = 0;
-	uint4 wacc = make_uint4(0, 0, 0, 0); uint64_t bacc_lo = 0, bacc_hi = 0;
+	uint32_t *Wd = 0; uint8_t *Bd = 0, *SBd = 0;            // this read's width record (kernel W)
 	// current interval
 	uint32_t k = 0, l = 0;
 	// search globals
@@ -112,9 +224,9 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	bool p_valid = false; uint32_t p_k = 0, p_l = 0;
 	int p_i = 0, p_ldp = 0, p_mm = 0, p_go = 0, p_ge = 0, p_state = 0, p_a = 0, p_score = 0;
 	// register windows over lane-private / read data
-	uint64_t sqw_lo = 0, sqw_hi = 0; int sq_tag = -1;                 // 16 read bases
-	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;      // 16 bound bytes of strand bw_a from bw_base
-	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;      // same for the seed bounds
+	uint64_t sqw_lo = 0, sqw_hi = 0; int sq_tag = -1;                    // 16 read bases
+	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;          // 16 bound bytes of strand bw_a from bw_base
+	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;          // same for the seed bounds
 	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
 	bool ovf = false;
 
@@ -167,6 +279,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	};
 
 	for (;;) {
+		bool finish = false;
 		// ---------------------------------------------------------------- refill
 		const unsigned long long need = __ballot(st == ST_IDLE);
 		if (need) {
@@ -181,19 +294,29 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
 					sq0 = P.seq + o; sq1 = P.rseq + o;
+					uint8_t *const rec = P.wdata + (size_t)rid * P.wstride;
+					Wd = (uint32_t*)rec; Bd = rec + P.woff_bid; SBd = rec + P.woff_sbid;
 					md_read = P.rd_maxdiff[rid]; mg_read = P.rd_maxgapo[rid];
-					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; nN = 0; rd_touch = 0; ovf = false;
+					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false;
-					if (len > 0) {
-						pass = 0; wi = 0; wbid = 0; k = 0; l = P.bwt[0].seq_len; prev_w = 0;
-						bacc_lo = bacc_hi = 0; st = ST_WIDTH;
+					if (len > 0 && (int)P.rd_nN[rid] <= md_read) {      // too many N: no search (bwtgap.c:118-123)
+						// ---- start of bwt_match_gap (bwtgap.c:104-128)
+						seeded = len > P.seed_len;
+						max_diff = md_read;
+						best_score = (md_read + 1) * P.s_mm + (mg_read + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
+						best_cnt = 0;
+						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
+						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
+						push_mem(0, 0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0);
+						p_valid = true; p_k = 0u; p_l = P.bwt[0].seq_len; p_i = len; p_ldp = 0; p_mm = p_go = p_ge = 0;
+						p_state = STATE_M; p_a = 1; p_score = 0;
+						n_entries = 2;
+						st = ST_POP;
 					} else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
 				} else st = ST_EXIT;
 			}
 		}
 		if (__ballot(st != ST_EXIT) == 0ull) break;
-
-		bool finish = false;
 
 		// ---------------------------------------------------------------- A: pop + pre-checks
 		if (st == ST_POP) {
@@ -249,17 +372,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		}
 
 		// ---------------------------------------------------------------- B: the rank step
-		int qb = 0, c = 4; bool query = false;
-		if (st == ST_WIDTH) {
-			const int sbase = pass < 2 ? 0 : len - P.seed_len;
-			qb = pass & 1;
-			c = seq_at(qb, sbase + wi);
-			query = c < 4;
-		} else if (st == ST_EXACT) {
-			qb = 1 - e_a;
+		const int qb = 1 - e_a; int c = 4; bool query = false;
+		if (st == ST_EXACT) {
 			if (xt >= 0) { c = seq_at(e_a, xt); query = c < 4; }
 		} else if (st == ST_EXPAND) {
-			qb = 1 - e_a; query = true;
+			query = true;
 			c = seq_at(e_a, e_i);
 		}
 		Occ4 ck, cl;
@@ -273,52 +390,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #define CL(cc) ((cc) == 0 ? cl.c[0] : ((cc) == 1 ? cl.c[1] : ((cc) == 2 ? cl.c[2] : cl.c[3])))
 
 		// ---------------------------------------------------------------- C: consume the counts
-		if (st == ST_WIDTH) {
-			// one step of bwt_cal_width (bwtaln.c:52-76) on index `pass&1`
-			const int n = pass < 2 ? len : P.seed_len;
-			if (c < 4) { k = L2Q(c) + CK(c) + 1u; l = L2Q(c) + CL(c); }
-			else if (pass == 0) ++nN;
-			if (k > l || c > 3) { k = 0; l = seqlen_q; ++wbid; }
-			uint32_t *const wp = Wd + qb * P.WL;
-			uint8_t *const bp = pass < 2 ? Bd + qb * P.WLB : SBd + qb * P.SLB;
-			// results are gathered in registers and stored 16 bytes at a time
-			auto record = [&](uint32_t wv, bool last) {
-				const uint32_t bv = (uint32_t)(wbid > 127 ? 127 : wbid) | ((wi > 0 && wv == prev_w) ? 128u : 0u);
-				set_word(wacc, (uint32_t)wi & 3u, wv);
-				{ const uint64_t sh = (uint64_t)bv << (((uint32_t)wi & 7u) << 3); if (wi & 8) bacc_hi |= sh; else bacc_lo |= sh; }
-				prev_w = wv;
-				if (pass < 2 && ((wi & 3) == 3 || last)) *(uint4*)(wp + (wi & ~3)) = wacc;
-				if ((wi & 15) == 15 || last) {
-					*(uint4*)(bp + (wi & ~15)) = make_uint4((uint32_t)bacc_lo, (uint32_t)(bacc_lo >> 32), (uint32_t)bacc_hi, (uint32_t)(bacc_hi >> 32));
-					bacc_lo = bacc_hi = 0;
-				}
-				++wi;
-			};
-			record(l - k + 1u, false);
-			if (wi == n) {
-				++wbid; record(0u, true);      // terminator: width[len] = {0, ++bid} (bwtaln.c:73-74)
-				++pass;
-				if (pass == 2 && len <= P.seed_len) pass = 4;
-				if (pass < 4) { wi = 0; wbid = 0; k = 0; l = (pass & 1) ? P.bwt[1].seq_len : P.bwt[0].seq_len; prev_w = 0; }
-				else {
-					// ---- start of bwt_match_gap (bwtgap.c:104-128)
-					seeded = len > P.seed_len;
-					if (nN > md_read) finish = true;             // too many N: no search (bwtgap.c:118-123)
-					else {
-						max_diff = md_read;
-						best_score = (md_read + 1) * P.s_mm + (mg_read + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
-						best_cnt = 0;
-						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
-						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
-						push_mem(0, 0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0);
-						p_valid = true; p_k = 0u; p_l = P.bwt[0].seq_len; p_i = len; p_ldp = 0; p_mm = p_go = p_ge = 0;
-						p_state = STATE_M; p_a = 1; p_score = 0;
-						n_entries = 2;
-						st = ST_POP;
-					}
-				}
-			}
-		} else if (st == ST_EXACT) {
+		if (st == ST_EXACT) {
 			bool hit = false;
 			if (xt < 0) hit = true;
 			else if (c > 3) st = ST_POP;                          // an N in the tail: no match
@@ -457,6 +529,18 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		for (int o = 32; o > 0; o >>= 1) touches += __shfl_down(touches, o);
 		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter, touches);
 	}
+}
+
+extern "C" void nabwa_launch_fm_width(const SearchParams *P, int n_blocks, hipStream_t s)
+{
+	if (P->touch_counter) hipLaunchKernelGGL((fm_width_kernel<true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+	else hipLaunchKernelGGL((fm_width_kernel<false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
+}
+
+extern "C" int nabwa_width_occupancy(void)
+{
+	int nb = 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_width_kernel<false>, NABWA_SEARCH_BLOCK, 0) == hipSuccess ? nb : 0;
 }
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)

@@ -18,16 +18,22 @@ struct SearchParams {
 	int n;
 	// gap_opt_t fields that are uniform over the batch
 	int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries, max_gape, max_seed_diff, seed_len, max_top2;
-	// per-lane scratch
+	// per-READ width record written by kernel W: [2][WL] u32 widths, then [2][WLB] and [2][SLB] bound bytes
+	uint8_t *wdata;
+	size_t wstride;
+	uint32_t woff_bid, woff_sbid;
+	uint32_t WL, WLB, SLB;
+	uint8_t *rd_nN;                           // per read: number of N in the read, saturated at 255
+	// per-lane scratch of kernel S: the arena (and, wide pass only, links / free list / heads)
 	uint8_t *scratch;
 	size_t lane_stride;
-	uint32_t off_link, off_free, off_head, off_w, off_bid, off_sbid;
-	uint32_t cap, WL, WLB, SLB, NS;           // WL: u32 widths per strand; WLB/SLB: bound bytes per strand (search / seed)
+	uint32_t off_link, off_free, off_head;
+	uint32_t cap, NS;
 	// outputs, indexed by work item
 	int32_t *n_aln, *max_ent;
 	uint8_t *status;
 	uint4 *aln;
 	int aln_cap;
-	unsigned int *work_counter;
+	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
 };

@@ -16,6 +16,8 @@ void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets
 void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s);
+void nabwa_launch_fm_width(const SearchParams *P, int n_blocks, hipStream_t s);
+int nabwa_width_occupancy(void);
 void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
 						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
@@ -192,12 +194,12 @@ struct nabwa_batch {
 	nabwa_gap_opt_t opt;
 	int n;
 	hipStream_t stream;
-	hipEvent_t ev0, ev1;
+	hipEvent_t ev0, ev1, evw;
 	float last_ms;
 	// device inputs
 	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; int max_len;
 	// first pass
-	SearchParams P; int n_blocks; uint8_t *d_scratch;
+	SearchParams P; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
 	unsigned int *d_counter, *d_novf; int32_t *d_ovf_ids;
 	// wide pass (allocated on demand)
@@ -216,18 +218,19 @@ static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int seed_len, uint32_t NS)
 {
-	P.cap = cap;
+	// per-read width record
 	P.WL = align_up((uint32_t)max_len + 1, 16);
 	P.WLB = P.WL + 16;
 	P.SLB = align_up((uint32_t)seed_len + 1, 16) + 16;
-	P.NS = NS;
+	P.woff_bid = 2 * P.WL * 4;
+	P.woff_sbid = P.woff_bid + 2 * P.WLB;
+	P.wstride = align_up(P.woff_sbid + 2 * P.SLB, 64);
+	// per-lane search scratch
+	P.cap = cap; P.NS = NS;
 	uint32_t o = cap * 16;
 	P.off_link = o; if (wide) o = align_up(o + cap * 4, 16);
 	P.off_free = o; if (wide) o = align_up(o + cap * 4, 16);
 	P.off_head = o; if (wide) o = align_up(o + NS * 4, 16);
-	P.off_w = o; o += 2 * P.WL * 4;
-	P.off_bid = o; o += 2 * P.WLB;
-	P.off_sbid = o; o += 2 * P.SLB;
 	P.lane_stride = align_up(o, 64);
 }
 
@@ -235,12 +238,13 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->ix->device);
-	void *ptrs[] = { b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+	void *ptrs[] = { b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (b->ev0) (void)hipEventDestroy(b->ev0);
 	if (b->ev1) (void)hipEventDestroy(b->ev1);
+	if (b->evw) (void)hipEventDestroy(b->evw);
 	if (b->stream) (void)hipStreamDestroy(b->stream);
 	delete b;
 }
@@ -286,6 +290,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipStreamCreate(&b->stream));
 	BCHK(hipEventCreate(&b->ev0));
 	BCHK(hipEventCreate(&b->ev1));
+	BCHK(hipEventCreate(&b->evw));
 	// reads: upload as given, then re-lay out on the device with 16-byte aligned starts
 	std::vector<int64_t> poff(n + 1);
 	poff[0] = 0;
@@ -336,10 +341,18 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	if (blocks < 1) blocks = 1;
 	b->n_blocks = (int)blocks;
 	BCHK(hipMalloc(&b->d_scratch, (size_t)blocks * NABWA_SEARCH_BLOCK * P.lane_stride));
+	int occw = nabwa_width_occupancy(); if (occw < 1) occw = 1;
+	long blocks_w = (long)prop.multiProcessorCount * occw;
+	if (blocks_w > need) blocks_w = need;
+	if (blocks_w < 1) blocks_w = 1;
+	b->n_blocks_w = (int)blocks_w;
+	BCHK(hipMalloc(&b->d_wdata, (size_t)(n ? n : 1) * P.wstride));
+	BCHK(hipMalloc(&b->d_nN, n ? n : 1));
+	P.wdata = b->d_wdata; P.rd_nN = b->d_nN;
 	const size_t n1 = n ? n : 1;
 	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
 	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
-	BCHK(hipMalloc(&b->d_counter, 4)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
+	BCHK(hipMalloc(&b->d_counter, 8)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
 	BCHK(hipMalloc(&b->d_sum, 16));
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
@@ -353,8 +366,10 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	HIPCHK(hipSetDevice(b->ix->device));
 	b->unresolved = 0;
 	if (b->n == 0) return NABWA_OK;
-	HIPCHK(hipMemsetAsync(b->d_counter, 0, 4, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
 	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
+	HIPCHK(hipEventRecord(b->evw, b->stream));
+	nabwa_launch_fm_width(&b->P, b->n_blocks_w, b->stream);
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
 	nabwa_launch_fm_search(&b->P, b->n_blocks, 0, b->stream);
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
@@ -373,6 +388,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	HIPCHK(hipMemcpyAsync(&novf, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
 	HIPCHK(hipStreamSynchronize(b->stream));
 	HIPCHK(hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+	HIPCHK(hipEventElapsedTime(&b->last_ms_w, b->evw, b->ev0));
 	if (n_second_pass) *n_second_pass = (int)novf;
 	if (novf == 0) return NABWA_OK;
 	// ---- wide pass: the flagged reads again, from scratch, with slot reuse and an arena that holds
@@ -396,7 +412,13 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	if (!b->d_scratch2) HIPCHK(hipMalloc(&b->d_scratch2, need));   // size only depends on the option block
 	Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)novf;
 	Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2;
-	HIPCHK(hipMemsetAsync(b->d_counter, 0, 4, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
+	{	// the first pass edited these reads' width records in place (gap_shadow): rebuild them
+		SearchParams QW = Q; QW.touch_counter = 0;
+		long bw2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
+		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
+		nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
+	}
 	nabwa_launch_fm_search(&Q, (int)blocks2, 1, b->stream);
 	nabwa_launch_scatter_wide((int)novf, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
 							  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
@@ -413,10 +435,11 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 }
 
 extern "C" float nabwa_batch_last_kernel_ms(nabwa_batch_t *b) { return b ? b->last_ms : 0.f; }
+extern "C" float nabwa_batch_last_width_ms(nabwa_batch_t *b) { return b ? b->last_ms_w : 0.f; }
 
 /* One extra, untimed run of both passes with the instrumented kernel: total Occ-bucket touches the
  * REFERENCE algorithm performs on this batch (the "algorithmic bytes" of the roofline are 48 B each). */
-extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket)
+extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, uint64_t *n_bucket_width)
 {
 	if (!b || !n_bucket) return fail(NABWA_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(b->ix->device));
@@ -426,9 +449,10 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket)
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
 	b->P.touch_counter = 0;
 	if (r != NABWA_OK) return r;
-	unsigned long long v = 0;
-	HIPCHK(hipMemcpy(&v, b->d_sum, 8, hipMemcpyDeviceToHost));
-	*n_bucket = v;
+	unsigned long long v[2] = { 0, 0 };
+	HIPCHK(hipMemcpy(v, b->d_sum, 16, hipMemcpyDeviceToHost));
+	*n_bucket = v[0];                          /* search kernel (bwt_match_gap) */
+	if (n_bucket_width) *n_bucket_width = v[1];  /* width kernel (bwt_cal_width) */
 	return NABWA_OK;
 }
 
