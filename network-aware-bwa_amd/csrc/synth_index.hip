@@ -347,3 +347,63 @@ extern "C" int nabwa_synth_build_index(int device, const uint8_t *d_text, uint64
 extern "C" int nabwa_synth_malloc(int device, uint64_t bytes, void **p) { SCHK(hipSetDevice(device)); SCHK(hipMalloc(p, bytes)); return 0; }
 extern "C" int nabwa_synth_d2h(void *dst, const void *src, uint64_t bytes) { SCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
 extern "C" int nabwa_synth_h2d(void *dst, const void *src, uint64_t bytes) { SCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+
+// ---------------------------------------------------------------- random-gather ceiling (micro-benchmark)
+// What the memory system sustains for the access pattern of the FM search: every lane walks a chain of
+// DEPENDENT random reads of `bytes_per_access` (16/32/64/128, naturally aligned) from a table far larger
+// than the Infinity Cache, `chains` independent chains per lane.  Reported by bench.py next to the
+// roofline as the attainable bound for 64-byte random gathers.
+template <int VEC, int CHAINS>
+__global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ table, uint64_t n_units, int steps, uint64_t seed,
+												 unsigned long long *sink)
+{
+	const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t idx[CHAINS]; uint32_t acc = 0;
+#pragma unroll
+	for (int c = 0; c < CHAINS; ++c) idx[c] = splitmix(seed + tid * CHAINS + c) % n_units;
+	for (int s = 0; s < steps; ++s) {
+		uint4 v[CHAINS][VEC];
+#pragma unroll
+		for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+			for (int u = 0; u < VEC; ++u) v[c][u] = table[idx[c] * VEC + u];
+#pragma unroll
+		for (int c = 0; c < CHAINS; ++c) {
+			uint32_t x = 0;
+#pragma unroll
+			for (int u = 0; u < VEC; ++u) x += v[c][u].x ^ v[c][u].y ^ v[c][u].z ^ v[c][u].w;
+			acc += x;
+			idx[c] = splitmix(idx[c] * 0x9E3779B97F4A7C15ULL + x + s) % n_units;   // next address depends on the data
+		}
+	}
+	if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
+extern "C" int nabwa_synth_gather_bench(int device, uint64_t table_bytes, int bytes_per_access, int chains, int n_blocks, int steps,
+										double *gbps, double *maccess_per_s)
+{
+	SCHK(hipSetDevice(device));
+	uint4 *table = 0; unsigned long long *sink = 0;
+	SCHK(hipMalloc(&table, table_bytes)); SCHK(hipMalloc(&sink, 8));
+	hipLaunchKernelGGL(text_kernel, GRID(table_bytes), 0, 0, (uint8_t*)table, (size_t)table_bytes, 12345ull);
+	SCHK(hipMemset(sink, 0, 8));
+	const int vec = bytes_per_access / 16;
+	const uint64_t n_units = table_bytes / bytes_per_access;
+	hipEvent_t e0, e1; SCHK(hipEventCreate(&e0)); SCHK(hipEventCreate(&e1));
+	for (int rep = 0; rep < 2; ++rep) {   // first repetition warms up
+		SCHK(hipEventRecord(e0, 0));
+#define GK(V, C) hipLaunchKernelGGL((gather_kernel<V, C>), dim3(n_blocks), dim3(256), 0, 0, table, n_units, steps, 777ull + rep, sink)
+		if (vec == 1 && chains == 1) GK(1, 1); else if (vec == 2 && chains == 1) GK(2, 1); else if (vec == 4 && chains == 1) GK(4, 1);
+		else if (vec == 8 && chains == 1) GK(8, 1); else if (vec == 4 && chains == 2) GK(4, 2); else if (vec == 2 && chains == 2) GK(2, 2);
+		else if (vec == 4 && chains == 4) GK(4, 4); else if (vec == 8 && chains == 2) GK(8, 2); else if (vec == 1 && chains == 4) GK(1, 4);
+		else { s_err = "unsupported gather_bench shape"; return -1; }
+#undef GK
+		SCHK(hipEventRecord(e1, 0)); SCHK(hipEventSynchronize(e1));
+	}
+	float ms = 0; SCHK(hipEventElapsedTime(&ms, e0, e1));
+	const double acc = (double)n_blocks * 256 * chains * steps;
+	*gbps = acc * bytes_per_access / (ms * 1e-3) / 1e9;
+	*maccess_per_s = acc / (ms * 1e-3) / 1e6;
+	SCHK(hipFree(table)); SCHK(hipFree(sink)); SCHK(hipEventDestroy(e0)); SCHK(hipEventDestroy(e1));
+	return 0;
+}

@@ -27,6 +27,7 @@ def lib():
                                         _P, _P, _P]
         L.nabwa_synth_build_index.argtypes = [C.c_int, _P, C.c_uint64, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]
         L.nabwa_synth_free.argtypes = [_P]
+        L.nabwa_synth_gather_bench.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
         L.nabwa_synth_malloc.argtypes = [C.c_int, C.c_uint64, _P]
         L.nabwa_synth_d2h.argtypes = [_P, _P, C.c_uint64]
         L.nabwa_synth_h2d.argtypes = [_P, _P, C.c_uint64]
@@ -101,3 +102,11 @@ def synth_reads(d_text, n, n_reads, length, sub_ppm, indel_ppm, seed, device=0):
     dr.free()
     do.free()
     return seq, rseq, off
+
+
+def gather_ceiling(table_bytes=2 << 30, bytes_per_access=64, chains=1, n_blocks=1024, steps=2000, device=0):
+    """measured throughput of dependent random gathers (GB/s, M accesses/s): the attainable bound of the FM search"""
+    g, m = C.c_double(), C.c_double()
+    _chk(lib().nabwa_synth_gather_bench(device, int(table_bytes), int(bytes_per_access), int(chains), int(n_blocks),
+                                        int(steps), C.byref(g), C.byref(m)))
+    return g.value, m.value
