@@ -195,7 +195,22 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 
 // =====================================================================================
 // Kernel S: bwt_match_gap (bwtgap.c:104-266), one read per lane, exact pop/push order.
+//
+// Every trip of the wave loop has three phases so that it pays ONE memory latency:
+//   1. decide (registers + LDS only): pop the pending entry or pick the arena slot to pop,
+//      run the pre-checks that need no memory, choose what this lane does in this trip;
+//   2. issue every global load the lane needs -- arena entry, bound-byte window, read-base
+//      window, seed-bound window, one or two Occ buckets -- back to back, no use in between;
+//   3. consume: decode the entry, finish the pre-check, take an exact-tail step or expand.
+// When the bound window is stale at pop time the rank query is issued speculatively together
+// with the window; if the entry then turns out to be pruned (bwtgap.c:156) the counts are dropped.
 // =====================================================================================
+#define LS_IDLE  0
+#define LS_POP   1   // needs to pop
+#define LS_HAVE  2   // the entry popped from the arena in the previous trip is in e_*
+#define LS_EXACT 3   // inside an exact tail (bwt.c:237-252), next position xt
+#define LS_EXIT  4
+
 template <bool WIDE, bool COUNT>
 __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P)
 {
@@ -209,50 +224,28 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint32_t *const ghead = (uint32_t*)(sc + P.off_head);   // WIDE only
 	const bool gape_mode = P.mode & 0x01, nonstop = P.mode & 0x10, loggap = P.mode & 0x04;
 
-	int st = ST_IDLE;
+	int st = LS_IDLE;
 	// per-read
 	uint32_t item = 0; int len = 0, md_read = 0, mg_read = 0; const uint8_t *sq0 = 0, *sq1 = 0;
-	uint32_t *Wd = 0; uint8_t *Bd = 0, *SBd = 0;            // this read's width record (kernel W)
+	uint8_t *rec = 0;                                       // this read's width record (kernel W)
 	// current interval
 	uint32_t k = 0, l = 0;
 	// search globals
 	int max_diff = 0, best_score = 0, best_cnt = 0, n_aln = 0, max_ent = 0, n_entries = 0;
 	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;
 	// current entry
-	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, m = 0, m_seed = 0, xt = 0;
+	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, e_score = 0, m = 0, m_seed = 0, xt = 0;
 	// pending entry: the last child pushed by the previous expansion, still in registers
 	bool p_valid = false; uint32_t p_k = 0, p_l = 0;
 	int p_i = 0, p_ldp = 0, p_mm = 0, p_go = 0, p_ge = 0, p_state = 0, p_a = 0, p_score = 0;
-	// register windows over lane-private / read data
+	// register windows over read data / the width record
 	uint64_t sqw_lo = 0, sqw_hi = 0; int sq_tag = -1;                    // 16 read bases
 	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;          // 16 bound bytes of strand bw_a from bw_base
 	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;          // same for the seed bounds
 	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
+	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0;
 	bool ovf = false;
 
-	auto seq_at = [&](int a, int pos) -> int {
-		const int tag = (a << 20) | (pos >> 4);
-		if (tag != sq_tag) { const uint4 q = *(const uint4*)((a ? sq1 : sq0) + (pos & ~15)); WIN_SET(sqw_lo, sqw_hi, q.x, q.y, q.z, q.w); sq_tag = tag; }
-		return (int)byte_of(sqw_lo, sqw_hi, (uint32_t)pos & 15u);
-	};
-	auto bid_at = [&](int a, int pos) -> uint32_t {
-		if (a != bw_a || pos < bw_base || pos >= bw_base + 16) {
-			int base = (pos | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(Bd + a * P.WLB + base);
-			const uint2 u = p[0], v = p[1];
-			WIN_SET(bw_lo, bw_hi, u.x, u.y, v.x, v.y); bw_base = base; bw_a = a;
-		}
-		return byte_of(bw_lo, bw_hi, (uint32_t)(pos - bw_base));
-	};
-	auto sbid_at = [&](int a, int pos) -> uint32_t {
-		if (a != sw_a || pos < sw_base || pos >= sw_base + 16) {
-			int base = (pos | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(SBd + a * P.SLB + base);
-			const uint2 u = p[0], v = p[1];
-			WIN_SET(sw_lo, sw_hi, u.x, u.y, v.x, v.y); sw_base = base; sw_a = a;
-		}
-		return byte_of(sw_lo, sw_hi, (uint32_t)(pos - sw_base));
-	};
 	auto head_get = [&](int score) -> uint32_t {
 		return WIDE ? ghead[score] : (uint32_t)s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x];
 	};
@@ -260,9 +253,13 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (WIDE) ghead[score] = v; else s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x] = (uint16_t)v;
 	};
 	auto mask_has = [&](int score) -> bool { return score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull); };
+	// After the first hit best_score is final (bwtgap.c:170), and the loop ends at the first pop whose score
+	// exceeds best_score + s_mm (bwtgap.c:144): such a child can never be expanded.  It is still COUNTED
+	// (n_entries feeds max_entries and the bwtgap.c:140 cut-off) but never written to the arena.
+	auto never_popped = [&](int score) -> bool { return !nonstop && n_aln > 0 && score > best_score + P.s_mm; };
 	// append an entry to the in-memory list of its score (n_entries is maintained by the callers)
 	auto push_mem = [&](int score, uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int na) {
-		if (ovf) return;
+		if (ovf || never_popped(score)) return;
 		uint32_t s;
 		if (WIDE && nfree) s = freel[--nfree];
 		else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
@@ -281,12 +278,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	for (;;) {
 		bool finish = false;
 		// ---------------------------------------------------------------- refill
-		const unsigned long long need = __ballot(st == ST_IDLE);
+		const unsigned long long need = __ballot(st == LS_IDLE);
 		if (need) {
 			unsigned int base = 0;
 			if (lane == 0) base = atomicAdd(P.work_counter, (unsigned int)__popcll(need));
 			base = __shfl(base, 0);
-			if (st == ST_IDLE) {
+			if (st == LS_IDLE) {
 				const unsigned int idx = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
 				if (idx < (unsigned int)P.n) {
 					item = idx;
@@ -294,8 +291,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
 					sq0 = P.seq + o; sq1 = P.rseq + o;
-					uint8_t *const rec = P.wdata + (size_t)rid * P.wstride;
-					Wd = (uint32_t*)rec; Bd = rec + P.woff_bid; SBd = rec + P.woff_sbid;
+					rec = P.wdata + (size_t)rid * P.wstride;
 					md_read = P.rd_maxdiff[rid]; mg_read = P.rd_maxgapo[rid];
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false;
@@ -311,15 +307,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						p_valid = true; p_k = 0u; p_l = P.bwt[0].seq_len; p_i = len; p_ldp = 0; p_mm = p_go = p_ge = 0;
 						p_state = STATE_M; p_a = 1; p_score = 0;
 						n_entries = 2;
-						st = ST_POP;
+						st = LS_POP;
 					} else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
-				} else st = ST_EXIT;
+				} else st = LS_EXIT;
 			}
 		}
-		if (__ballot(st != ST_EXIT) == 0ull) break;
+		if (__ballot(st != LS_EXIT) == 0ull) break;
 
-		// ---------------------------------------------------------------- A: pop + pre-checks
-		if (st == ST_POP) {
+		// ================================================================ phase 1: decide (no global loads)
+		bool want_ent = false; uint32_t ent_slot = 0;
+		bool have = st == LS_HAVE;
+		if (st == LS_POP) {
 			if (n_entries == 0) finish = true;
 			else {
 				if (max_ent < n_entries) max_ent = n_entries;
@@ -328,60 +326,133 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			if (!finish) {
 				const int best_mem = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1
 											 : (mask_hi ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff);
-				int pscore;
 				if (p_valid && p_score <= best_mem) {
 					// the pending child is the newest entry of the lowest score: it is the pop
 					k = p_k; l = p_l; e_i = p_i; e_ldp = p_ldp; e_mm = p_mm; e_go = p_go; e_ge = p_ge; e_state = p_state; e_a = p_a;
-					pscore = p_score; p_valid = false;
+					e_score = p_score; p_valid = false;
+					--n_entries;
+					if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
+					else have = true;
+				} else if (best_mem == 0x7fffffff) {
+					finish = true;      // only never-stored children are left: the reference pops one of them and stops (bwtgap.c:144)
 				} else {
 					if (p_valid) { push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a); p_valid = false; }
-					const uint32_t s = head_get(best_mem);
-					const uint4 e = ent[s];
-					uint32_t nx;
-					k = e.x; l = e.y; e_i = (int)(e.z & 0xffffu); e_ldp = (int)(e.z >> 16);
-					if (WIDE) {
-						nx = lnk[s];
-						e_mm = (int)(e.w & 0xffu); e_go = (int)(e.w >> 8 & 0xffu); e_ge = (int)(e.w >> 16 & 0xffu);
-						e_state = (int)(e.w >> 24 & 3u); e_a = (int)(e.w >> 26 & 1u);
-						freel[nfree++] = s;
-					} else {
-						nx = e.w & 0xffffu;
-						e_mm = (int)(e.w >> 16 & 15u); e_go = (int)(e.w >> 20 & 15u); e_ge = (int)(e.w >> 24 & 31u);
-						e_state = (int)(e.w >> 29 & 3u); e_a = (int)(e.w >> 31);
-					}
-					head_set(best_mem, nx);
-					if (nx == NIL) { if (best_mem < 64) mask_lo &= ~(1ull << best_mem); else mask_hi &= ~(1ull << (best_mem - 64)); }
-					pscore = best_mem;
-				}
-				--n_entries;
-				if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
-				else if (!nonstop && pscore > best_score + P.s_mm) finish = true;   // bwtgap.c:144
-				else {
-					m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
-					m_seed = P.max_seed_diff - (e_mm + e_go); if (gape_mode) m_seed -= e_ge;
-					bool skip = m < 0;
-					if (!skip && e_i > 0 && m < (int)(bid_at(e_a, e_i - 1) & 127u)) skip = true;   // bwtgap.c:156
-					if (!skip) {
-						if (e_i == 0) { st = ST_EXACT; xt = -1; }       // a hit as it stands; stage C, no query
-						else if (m == 0 && (e_state == STATE_M || gape_mode || e_ge == P.max_gape)) {
-							st = ST_EXACT; xt = e_i - 1;                 // nothing may differ any more: exact tail (bwt.c:237-252)
-						} else { st = ST_EXPAND; --e_i; }
-					}
+					if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
+					else { ent_slot = head_get(best_mem); want_ent = true; e_score = best_mem; }
 				}
 			}
 		}
+		// what this lane does with its current entry in this trip
+		int kind = 0;                 // 1 expand, 2 exact-tail step, 3 hit without query (i == 0)
+		bool need_win = false, spec = false; int win_hi = 0;
+		if (have && !finish) {
+			st = LS_POP;
+			m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
+			m_seed = P.max_seed_diff - (e_mm + e_go); if (gape_mode) m_seed -= e_ge;
+			if (m >= 0) {
+				if (e_i == 0) kind = 3;
+				else {
+					// the pre-check needs bound[e_i-1]; an expansion then needs bound[e_i-2] as well
+					const bool tail = m == 0 && (e_state == STATE_M || gape_mode || e_ge == P.max_gape);
+					win_hi = e_i - 1;
+					const int win_lo = (tail || e_i < 2) ? e_i - 1 : e_i - 2;
+					bool go = true;
+					if (bw_a == e_a && win_lo >= bw_base && win_hi < bw_base + 16) {
+						if (m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) go = false;   // bwtgap.c:156
+					} else { need_win = true; spec = true; }
+					if (go) {
+						if (tail) { kind = 2; xt = e_i - 1; }       // nothing may differ any more: exact tail (bwt.c:237-252)
+						else { kind = 1; --e_i; }
+					}
+				}
+			}
+		} else if (st == LS_EXACT) kind = 2;
 
-		// ---------------------------------------------------------------- B: the rank step
-		const int qb = 1 - e_a; int c = 4; bool query = false;
-		if (st == ST_EXACT) {
-			if (xt >= 0) { c = seq_at(e_a, xt); query = c < 4; }
-		} else if (st == ST_EXPAND) {
-			query = true;
-			c = seq_at(e_a, e_i);
+		const int qb = 1 - e_a;
+		const int spos = kind == 2 ? xt : e_i;
+		const int stag = (e_a << 20) | (spos >> 4);
+		const bool need_seq = (kind == 1 || kind == 2) && stag != sq_tag;
+		bool query = kind == 1 || kind == 2;
+		if (kind == 2 && !need_seq && byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u) > 3u) query = false;   // an N: no query
+		const int ii = e_i - (len - P.seed_len);
+		const bool use_seed = kind == 1 && e_i > 0 && seeded && ii > 0;
+		const bool need_seed = use_seed && !(sw_a == e_a && ii - 1 >= sw_base && ii < sw_base + 16);
+
+		// ================================================================ phase 2: issue every load
+		uint4 r_ent = make_uint4(0, 0, 0, 0); uint32_t r_lnk = 0;
+		if (want_ent) { r_ent = ent[ent_slot]; if (WIDE) r_lnk = lnk[ent_slot]; }
+		if (need_win) {
+			int base = (win_hi | 7) - 15; if (base < 0) base = 0;
+			const uint2 *p = (const uint2*)(rec + P.woff_bid + e_a * P.WLB + base);
+			const uint2 u = p[0], v = p[1];
+			WIN_SET(bw_lo, bw_hi, u.x, u.y, v.x, v.y); bw_base = base; bw_a = e_a;
 		}
+		if (need_seq) {
+			const uint4 q = *(const uint4*)((e_a ? sq1 : sq0) + (spos & ~15));
+			WIN_SET(sqw_lo, sqw_hi, q.x, q.y, q.z, q.w); sq_tag = stag;
+		}
+		if (need_seed) {
+			int base = (ii | 7) - 15; if (base < 0) base = 0;
+			const uint2 *p = (const uint2*)(rec + P.woff_sbid + e_a * P.SLB + base);
+			const uint2 u = p[0], v = p[1];
+			WIN_SET(sw_lo, sw_hi, u.x, u.y, v.x, v.y); sw_base = base; sw_a = e_a;
+		}
+		// the rank query: Occ of all four bases at rows k-1 and l of index qb (bwt.c:159-216 conventions)
+		uint4 a0, a1, a2, a3, b0, b1, b2, b3; uint32_t rk = 0, rl = 0; bool kvalid = false, two = false;
+		a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = make_uint4(0, 0, 0, 0);
+		if (query) {
+			const uint32_t primary = qb ? P.bwt[1].primary : P.bwt[0].primary;
+			const uint4 *bk = qb ? P.bwt[1].bk : P.bwt[0].bk;
+			const uint32_t kq = k - 1u, lq = l;
+			const uint32_t kp = kq - (kq >= primary ? 1u : 0u), lp = lq - (lq >= primary ? 1u : 0u);
+			const uint32_t bl = lp / NABWA_INTV; rl = lp - bl * NABWA_INTV;
+			kvalid = kq != 0xffffffffu;
+			const uint32_t bkk = kvalid ? kp / NABWA_INTV : bl; rk = kp - bkk * NABWA_INTV;
+			two = bkk != bl;
+			const uint4 *pl = bk + (size_t)bl * 4;
+			a0 = pl[0]; a1 = pl[1]; a2 = pl[2]; a3 = pl[3];
+			if (two) { const uint4 *pk = bk + (size_t)bkk * 4; b0 = pk[0]; b1 = pk[1]; b2 = pk[2]; b3 = pk[3]; }
+		}
+
+		if (COUNT) {   // trip statistics (instrumented build only): [2] trips, [3..] lane-trips by activity
+			const unsigned long long bx = __ballot(kind == 1), be = __ballot(kind == 2), bm = __ballot(want_ent),
+				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT);
+			if (lane == 0) {
+				st_trips += 1; st_expand += __popcll(bx); st_exact += __popcll(be); st_ent += __popcll(bm); st_spec += __popcll(bs);
+				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi);
+			}
+		}
+		// ================================================================ phase 3: consume
+		if (want_ent) {
+			uint32_t nx;
+			k = r_ent.x; l = r_ent.y; e_i = (int)(r_ent.z & 0xffffu); e_ldp = (int)(r_ent.z >> 16);
+			if (WIDE) {
+				nx = r_lnk;
+				e_mm = (int)(r_ent.w & 0xffu); e_go = (int)(r_ent.w >> 8 & 0xffu); e_ge = (int)(r_ent.w >> 16 & 0xffu);
+				e_state = (int)(r_ent.w >> 24 & 3u); e_a = (int)(r_ent.w >> 26 & 1u);
+				freel[nfree++] = ent_slot;
+			} else {
+				nx = r_ent.w & 0xffffu;
+				e_mm = (int)(r_ent.w >> 16 & 15u); e_go = (int)(r_ent.w >> 20 & 15u); e_ge = (int)(r_ent.w >> 24 & 31u);
+				e_state = (int)(r_ent.w >> 29 & 3u); e_a = (int)(r_ent.w >> 31);
+			}
+			head_set(e_score, nx);
+			if (nx == NIL) { if (e_score < 64) mask_lo &= ~(1ull << e_score); else mask_hi &= ~(1ull << (e_score - 64)); }
+			--n_entries;
+			if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
+			else st = LS_HAVE;                                                  // pre-checks + query in the next trip
+		}
+		if (spec && m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) kind = 0;   // pruned after all (bwtgap.c:156)
+		int c = 4;
+		if (kind == 1 || kind == 2) c = (int)byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u);
+		if (kind == 2 && c > 3) query = false;
 		Occ4 ck, cl;
-		if (query) nabwa_occ4_pair(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, ck, cl);
-		if (COUNT && query) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, st == ST_EXPAND);
+		ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0; cl = ck;
+		if (query && kind) {
+			cl = nabwa_count4(a0, a1, a2, a3, rl);
+			if (kvalid) ck = two ? nabwa_count4(b0, b1, b2, b3, rk) : nabwa_count4(a0, a1, a2, a3, rk);
+			if (COUNT) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);
+		}
 		const uint32_t L2q0 = qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0], L2q1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1];
 		const uint32_t L2q2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], L2q3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
 		const uint32_t seqlen_q = qb ? P.bwt[1].seq_len : P.bwt[0].seq_len;
@@ -389,19 +460,19 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #define CK(cc) ((cc) == 0 ? ck.c[0] : ((cc) == 1 ? ck.c[1] : ((cc) == 2 ? ck.c[2] : ck.c[3])))
 #define CL(cc) ((cc) == 0 ? cl.c[0] : ((cc) == 1 ? cl.c[1] : ((cc) == 2 ? cl.c[2] : cl.c[3])))
 
-		// ---------------------------------------------------------------- C: consume the counts
-		if (st == ST_EXACT) {
+		if (kind == 2 || kind == 3) {
 			bool hit = false;
-			if (xt < 0) hit = true;
-			else if (c > 3) st = ST_POP;                          // an N in the tail: no match
+			if (kind == 3) hit = true;
+			else if (c > 3) st = LS_POP;                          // an N in the tail: no match
 			else {
 				k = L2Q(c) + CK(c) + 1u; l = L2Q(c) + CL(c);
-				if (k > l) st = ST_POP;
+				if (k > l) st = LS_POP;
 				else if (--xt < 0) hit = true;
+				else st = LS_EXACT;
 			}
 			if (hit) {
 				// ---- hit bookkeeping (bwtgap.c:166-199)
-				st = ST_POP;
+				st = LS_POP;
 				const int score = e_mm * P.s_mm + e_go * P.s_gapo + e_ge * P.s_gape;
 				bool do_add = true;
 				if (n_aln == 0) {
@@ -421,7 +492,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						// gap_shadow (bwtgap.c:81-91) on this strand's bounds, positions < last_diff_pos;
 						// 8 positions per trip; the weq flags of positions 1..last_diff_pos are refreshed
 						const uint32_t x = l - k + 1u, mx = seqlen_q; uint32_t jj = 0, pw = 0;
-						uint32_t *const wp = Wd + e_a * P.WL; uint8_t *const bp = Bd + e_a * P.WLB;
+						uint32_t *const wp = (uint32_t*)rec + e_a * P.WL; uint8_t *const bp = rec + P.woff_bid + e_a * P.WLB;
 						for (int t0 = 0; t0 <= e_ldp && e_ldp > 0; t0 += 8) {
 							const uint4 w0 = *(const uint4*)(wp + t0), w1 = *(const uint4*)(wp + t0 + 4);
 							const uint2 bq = *(const uint2*)(bp + t0);
@@ -452,19 +523,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					}
 				}
 			}
-		} else if (st == ST_EXPAND) {
+		} else if (kind == 1) {
 			// ---- node expansion (bwtgap.c:201-260); e_i is already decremented
-			st = ST_POP;
 			const uint32_t occ = l - k + 1u;
 			bool allow_diff = true, allow_M = true;
 			if (e_i > 0) {
-				const uint32_t B1 = bid_at(e_a, e_i - 1), B0 = bid_at(e_a, e_i);
-				const int b1 = (int)(B1 & 127u), b0 = (int)(B0 & 127u);
+				const uint32_t B1 = byte_of(bw_lo, bw_hi, (uint32_t)(e_i - 1 - bw_base)), B0 = byte_of(bw_lo, bw_hi, (uint32_t)(e_i - bw_base));
+				const int b1 = (int)(B1 & 127u), b0v = (int)(B0 & 127u);
 				if (b1 > m - 1) allow_diff = false;
-				else if (b1 == m - 1 && b0 == m - 1 && (B0 & 128u)) allow_M = false;
-				const int ii = e_i - (len - P.seed_len);
-				if (seeded && ii > 0) {
-					const uint32_t S1 = sbid_at(e_a, ii - 1), S0 = sbid_at(e_a, ii);
+				else if (b1 == m - 1 && b0v == m - 1 && (B0 & 128u)) allow_M = false;
+				if (use_seed) {
+					const uint32_t S1 = byte_of(sw_lo, sw_hi, (uint32_t)(ii - 1 - sw_base)), S0 = byte_of(sw_lo, sw_hi, (uint32_t)(ii - sw_base));
 					const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
 					if (s1 > m_seed - 1) allow_diff = false;
 					else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
@@ -522,12 +591,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (finish) {
 			P.n_aln[item] = n_aln; P.max_ent[item] = max_ent; P.status[item] = (uint8_t)status;
 			if (COUNT && status == NABWA_ST_OK) touches += rd_touch;   // abandoned reads are counted by the wide pass
-			st = ST_IDLE;
+			st = LS_IDLE;
 		}
 	}
 	if (COUNT) {
 		for (int o = 32; o > 0; o >>= 1) touches += __shfl_down(touches, o);
-		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter, touches);
+		if (lane == 0 && P.touch_counter) {
+			atomicAdd(P.touch_counter, touches);
+			atomicAdd(P.touch_counter + 2, st_trips); atomicAdd(P.touch_counter + 3, st_expand); atomicAdd(P.touch_counter + 4, st_exact);
+			atomicAdd(P.touch_counter + 5, st_ent); atomicAdd(P.touch_counter + 6, st_spec); atomicAdd(P.touch_counter + 7, st_query);
+			atomicAdd(P.touch_counter + 8, st_two); atomicAdd(P.touch_counter + 9, st_exit);
+		}
 	}
 }
 

@@ -353,7 +353,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
 	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
 	BCHK(hipMalloc(&b->d_counter, 8)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
-	BCHK(hipMalloc(&b->d_sum, 16));
+	BCHK(hipMalloc(&b->d_sum, 128));
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
 	*out = b;
@@ -443,7 +443,7 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 {
 	if (!b || !n_bucket) return fail(NABWA_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(b->ix->device));
-	HIPCHK(hipMemsetAsync(b->d_sum, 0, 16, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_sum, 0, 128, b->stream));
 	b->P.touch_counter = b->d_sum;
 	int r = nabwa_batch_run(b);
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
@@ -453,6 +453,12 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	HIPCHK(hipMemcpy(v, b->d_sum, 16, hipMemcpyDeviceToHost));
 	*n_bucket = v[0];                          /* search kernel (bwt_match_gap) */
 	if (n_bucket_width) *n_bucket_width = v[1];  /* width kernel (bwt_cal_width) */
+	if (getenv("NABWA_TRIP_STATS")) {
+		unsigned long long t[16];
+		HIPCHK(hipMemcpy(t, b->d_sum, 128, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu\n",
+				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+	}
 	return NABWA_OK;
 }
 
