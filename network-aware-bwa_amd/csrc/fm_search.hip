@@ -135,11 +135,37 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 				if (tag != stag[x]) { const uint4 q = *(const uint4*)(sq[x] + (pos & ~15)); WIN_SET(slo[x], shi[x], q.x, q.y, q.z, q.w); stag[x] = tag; }
 				c[x] = (int)byte_of(slo[x], shi[x], (uint32_t)pos & 15u);
 			}
+			// issue the bucket loads of BOTH passes before consuming any (one memory latency per trip)
+			uint4 qa[2][4], qb[2][4]; uint32_t rk[2], rl[2]; bool kval[2], two[2];
 #pragma unroll
 			for (int x = 0; x < 2; ++x) {
+				const uint32_t primary = P.bwt[x].primary, kq = kk[x] - 1u, lq = ll[x];
+				const uint32_t kp = kq - (kq >= primary ? 1u : 0u), lp = lq - (lq >= primary ? 1u : 0u);
+				const uint32_t bl = lp / NABWA_INTV; rl[x] = lp - bl * NABWA_INTV;
+				kval[x] = kq != 0xffffffffu;
+				const uint32_t bkk = kval[x] ? kp / NABWA_INTV : bl; rk[x] = kp - bkk * NABWA_INTV;
+				two[x] = bkk != bl;
+				const bool q = c[x] < 4;
+				const uint4 *pl = P.bwt[x].bk + (size_t)bl * 4, *pk = P.bwt[x].bk + (size_t)bkk * 4;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { qa[x][u] = make_uint4(0, 0, 0, 0); qb[x][u] = make_uint4(0, 0, 0, 0); }
+				if (q) {
+#pragma unroll
+					for (int u = 0; u < 4; ++u) qa[x][u] = pl[u];
+					if (two[x]) {
+#pragma unroll
+						for (int u = 0; u < 4; ++u) qb[x][u] = pk[u];
+					}
+					if (COUNT) touches += ref_touches(P.bwt[x], kq, lq, false);
+				}
+			}
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+				ck[x].c[0] = ck[x].c[1] = ck[x].c[2] = ck[x].c[3] = 0; cl[x] = ck[x];
 				if (c[x] < 4) {
-					nabwa_occ4_pair(P.bwt[x], kk[x] - 1u, ll[x], ck[x], cl[x]);
-					if (COUNT) touches += ref_touches(P.bwt[x], kk[x] - 1u, ll[x], false);
+					cl[x] = nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rl[x]);
+					if (kval[x]) ck[x] = two[x] ? nabwa_count4(qb[x][0], qb[x][1], qb[x][2], qb[x][3], rk[x])
+											   : nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rk[x]);
 				}
 			}
 #pragma unroll
