@@ -64,11 +64,11 @@ __device__ __forceinline__ uint32_t ref_touches(const DevBwt &B, uint32_t kq, ui
 // scratch and load one piece back.
 __device__ __forceinline__ uint32_t byte_of(uint64_t lo, uint64_t hi, uint32_t idx)
 {
+	asm volatile("" : "+v"(lo), "+v"(hi));   // opaque at the USE: no dynamic vector extract, and no wait at the load
 	const uint64_t h = (idx & 8u) ? hi : lo;
 	return (uint32_t)(h >> ((idx & 7u) << 3)) & 0xffu;
 }
-#define WIN_SET(lo_, hi_, a_, b_, c_, d_) do { lo_ = (uint64_t)(b_) << 32 | (a_); hi_ = (uint64_t)(d_) << 32 | (c_); \
-	asm volatile("" : "+v"(lo_), "+v"(hi_)); } while (0)
+#define WIN_SET(lo_, hi_, a_, b_, c_, d_) do { lo_ = (uint64_t)(b_) << 32 | (a_); hi_ = (uint64_t)(d_) << 32 | (c_); } while (0)
 
 __device__ __forceinline__ void set_word(uint4 &q, uint32_t c, uint32_t v)
 {
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi);
 			}
 		}
+		asm volatile("" ::: "memory");   // keep every consumer below every load above (no block merging across)
 		// ================================================================ phase 3: consume
 		if (want_ent) {
 			uint32_t nx;
