@@ -111,6 +111,46 @@ void nabwa_batch_destroy(nabwa_batch_t *b);
  * sa_out[i] = SA value of row k[i] in index `which[i]` (0 forward, 1 reversed text). */
 int nabwa_sa_lookup(nabwa_index_t *ix, int n, const uint8_t *which, const uint32_t *k, uint32_t *sa_out);
 
+/* Batch form of aln_global_core + aln_path2cigar32 (stdaln.c:345-525, :1009-1039; caller
+ * refine_gapped_core, bwase.c:212): task i aligns ref[ref_off[i]..ref_off[i+1]) (seq1) with
+ * qry[qry_off[i]..qry_off[i+1]) (seq2), codes 0-4, under {gap_open, gap_ext, gap_end, 5x5 matrix,
+ * band_width} (AlnParam, stdaln.h:86-95).  cigar32 rows are max_cigar wide (len<<4 | op);
+ * n_cigar[i] > max_cigar means the row was truncated. */
+int nabwa_global_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
+					   const uint8_t *qry, int gap_open, int gap_ext, int gap_end, const int *matrix25, int band,
+					   int32_t *score, int32_t *n_cigar, uint32_t *cigar32, int max_cigar);
+
+/* ---- single-end finishing chain: everything between the FM search and the BAM record -------- */
+#define NABWA_MAX_CIGAR 64
+#define NABWA_MAX_MD    512
+#define NABWA_MAX_MULTI 16
+typedef struct { uint32_t pos; int32_t gap, mm, strand, n_cigar; uint16_t cigar[NABWA_MAX_CIGAR]; } nabwa_multi_t;
+typedef struct {
+	int32_t type, strand, n_mm, n_gapo, n_gape, score;     /* bwa_seq_t fields of the same names (bwtaln.h:64-90) */
+	uint32_t sa, pos, c1, c2;
+	int32_t mapQ, seQ, len, full_len, clip_len;
+	int32_t n_cigar; uint16_t cigar[NABWA_MAX_CIGAR];       /* bwa_cigar_t: op<<14 | len (bwtaln.h:47-56) */
+	int32_t nm; char md[NABWA_MAX_MD];
+	int32_t n_multi; nabwa_multi_t multi[NABWA_MAX_MULTI];
+	/* what bwa_print_sam1 / bwa_update_bam1 derive (bwase.c:458-571, bam2bam.c:430-593) */
+	int32_t flag, seqid, nn; int64_t rpos; char xt;
+} nabwa_se_t;
+
+/* Annotation side of the index (replaces bns_restore + bwt_restore_pac, bntseq.c:88-148): <prefix>.ann,
+ * .amb and .pac are read into host memory and attached to the index. */
+int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefix);
+
+/* bwa_aln2seq_core (bwase.c:19-95) -> bwa_cal_pac_pos_core + multi-hit positions (bwase.c:139-181,
+ * bam2bam.c:629-637) -> bwa_refine_gapped (bwase.c:356-423: gap refinement, MD/NM, trimmed-tail clip) for
+ * n single-end reads IN RECORD ORDER.  The hit choice consumes the caller's drand48 stream: *rng48 is the
+ * 48-bit state (srand48(seed) == ((uint64_t)seed << 16) | 0x330E) and is updated, so that successive
+ * batches continue the reference's process-global stream.  SA lookups and the gap-refinement
+ * DP run on the GPU in batches; the rest is host bookkeeping.
+ * full_len[i] >= len: untrimmed read length (bwa_seq_t.full_len).  n_occ: max_occ_se (bam2bam.c:629; <= 15). */
+int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const uint8_t *seq,
+					const uint8_t *rseq, const int32_t *full_len, const int32_t *n_aln, const nabwa_aln1_t *aln,
+					int n_occ, uint64_t *rng48, nabwa_se_t *out);
+
 /* Rank primitives for tests: Occ of all four bases at rows k[i] (bwt_occ4, bwt.c:159-176). */
 int nabwa_occ4(nabwa_index_t *ix, int which, int n, const uint32_t *k, uint32_t *cnt_out /* n x 4 */);
 

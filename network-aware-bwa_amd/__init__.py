@@ -31,6 +31,47 @@ class GapOpt(C.Structure):
                 ("max_top2", C.c_int), ("trim_qual", C.c_int)]
 
 
+MAX_CIGAR, MAX_MD, MAX_MULTI = 64, 512, 16
+
+
+class SeMulti(C.Structure):
+    """nabwa_multi_t"""
+    _fields_ = [("pos", C.c_uint32), ("gap", C.c_int32), ("mm", C.c_int32), ("strand", C.c_int32),
+                ("n_cigar", C.c_int32), ("cigar", C.c_uint16 * MAX_CIGAR)]
+
+
+class SeRec(C.Structure):
+    """nabwa_se_t: a finished single-end alignment"""
+    _fields_ = [("type", C.c_int32), ("strand", C.c_int32), ("n_mm", C.c_int32), ("n_gapo", C.c_int32),
+                ("n_gape", C.c_int32), ("score", C.c_int32), ("sa", C.c_uint32), ("pos", C.c_uint32),
+                ("c1", C.c_uint32), ("c2", C.c_uint32), ("mapQ", C.c_int32), ("seQ", C.c_int32),
+                ("len", C.c_int32), ("full_len", C.c_int32), ("clip_len", C.c_int32),
+                ("n_cigar", C.c_int32), ("cigar", C.c_uint16 * MAX_CIGAR), ("nm", C.c_int32), ("md", C.c_char * MAX_MD),
+                ("n_multi", C.c_int32), ("multi", SeMulti * MAX_MULTI),
+                ("flag", C.c_int32), ("seqid", C.c_int32), ("nn", C.c_int32), ("rpos", C.c_int64), ("xt", C.c_char)]
+
+
+def srand48_state(seed):
+    """state of the reference's process-global drand48 stream right after srand48(seed)"""
+    return ((seed & 0xffffffff) << 16) | 0x330E
+
+
+def global_align(ref, ref_off, qry, qry_off, gap_open, gap_ext, gap_end, matrix25, band, device=0, max_cigar=MAX_CIGAR):
+    """aln_global_core + aln_path2cigar32 (reference stdaln.c:345-525, :1009-1039) for a batch of pairs"""
+    n = len(ref_off) - 1
+    ref = np.ascontiguousarray(ref, np.uint8)
+    qry = np.ascontiguousarray(qry, np.uint8)
+    ref_off = np.ascontiguousarray(ref_off, np.int64)
+    qry_off = np.ascontiguousarray(qry_off, np.int64)
+    mat = np.ascontiguousarray(matrix25, np.int32)
+    score = np.zeros(max(n, 1), np.int32)
+    ncig = np.zeros(max(n, 1), np.int32)
+    cig = np.zeros((max(n, 1), max_cigar), np.uint32)
+    _chk(lib().nabwa_global_align(device, n, _ptr(ref_off), _ptr(ref), _ptr(qry_off), _ptr(qry), gap_open, gap_ext,
+                                  gap_end, _ptr(mat), band, _ptr(score), _ptr(ncig), _ptr(cig), max_cigar))
+    return score[:n], [cig[i, :ncig[i]] for i in range(n)]
+
+
 class NabwaError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libnabwa error %d: %s" % (code, msg))
@@ -86,6 +127,10 @@ def lib():
     L.nabwa_batch_destroy.restype = None
     L.nabwa_sa_lookup.argtypes = [_P, C.c_int, _P, _P, _P]
     L.nabwa_occ4.argtypes = [_P, C.c_int, C.c_int, _P, _P]
+    L.nabwa_global_align.argtypes = [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P,
+                                     C.c_int]
+    L.nabwa_index_attach_reference.argtypes = [_P, C.c_char_p]
+    L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
     _lib = L
     return L
 
@@ -119,9 +164,9 @@ class Index:
         self._h = handle
 
     @classmethod
-    def load(cls, prefix, device=0, with_sa=True):
+    def load(cls, prefix, device=0, with_sa=True, with_ref=False):
         h = _P()
-        _chk(lib().nabwa_index_load(prefix.encode(), device, int(with_sa), 0, C.byref(h)))
+        _chk(lib().nabwa_index_load(prefix.encode(), device, int(with_sa), int(with_ref), C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -142,6 +187,25 @@ class Index:
         s1, m1 = pn(sa1)
         _chk(lib().nabwa_index_from_arrays(device, int(device_ptrs), p0, n0, p1, n1, s0, m0, s1, m1, C.byref(h)))
         return cls(h)
+
+    def attach_reference(self, prefix):
+        """.ann/.amb/.pac of the index (reference bns_restore + bwt_restore_pac)"""
+        _chk(lib().nabwa_index_attach_reference(self._h, prefix.encode()))
+
+    def se_finish(self, opt, seq, rseq, off, full_len, hits, n_occ, rng_state):
+        """aln2seq + positions + mapQ + gap refinement + MD/NM for a batch, in record order.
+        hits: per-read arrays of bwt_aln1_t rows.  Returns (array of SeRec, new rng state)."""
+        n = len(off) - 1
+        n_aln = np.array([len(h) for h in hits], np.int32)
+        rows = np.concatenate([np.asarray(h, ALN_DT) for h in hits] + [np.zeros(0, ALN_DT)]) if n else np.zeros(0, ALN_DT)
+        rows = np.ascontiguousarray(rows)
+        out = (SeRec * max(n, 1))()
+        st = C.c_uint64(rng_state)
+        fl = np.ascontiguousarray(full_len, np.int32)
+        _chk(lib().nabwa_se_finish(self._h, C.byref(opt), n, _ptr(np.ascontiguousarray(off, np.int64)),
+                                   _ptr(np.ascontiguousarray(seq, np.uint8)), _ptr(np.ascontiguousarray(rseq, np.uint8)),
+                                   _ptr(fl), _ptr(n_aln), _ptr(rows), n_occ, C.byref(st), out))
+        return out, st.value
 
     def seq_len(self, which=0):
         return lib().nabwa_index_seq_len(self._h, which)

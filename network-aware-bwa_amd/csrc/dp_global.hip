@@ -1,0 +1,146 @@
+// dp_global.hip -- banded global alignment with traceback, one (reference window, read) pair per lane.
+//
+// Semantics of aln_global_core (stdaln.c:345-525) + aln_path2cigar32 (stdaln.c:1009-1039):
+// three-state (M/I/D) affine-gap DP over int32 scores, band b1/b2 derived from band_width and the
+// length difference (stdaln.c:372-380), end-gap penalty on column 0, column len1 and row len2
+// (set_end_I / set_end_D, stdaln.c:286-319), tie-breaking of set_M (M >= I, M >= D, else I > D:
+// stdaln.c:260-275), backtrace preferring M, then I, then D on strictly greater (stdaln.c:491-493).
+// Stated through per-row column ranges: row j covers columns max(0,j-b2) .. min(len1, j+b1-1);
+// row 0 covers 0 .. b1-1.
+//
+// Layout: every lane owns two score rows (M,I,D) and a traceback matrix in HBM, interleaved by lane
+// inside the wave ([cell][lane]) so that lanes walking the same cell index coalesce.
+// Used for gap refinement (refine_gapped_core, bwase.c:189-237): only reads whose best hit has a gap
+// open come here, so this kernel is small next to the FM search.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NINF (-1073741823)   // MINOR_INF, stdaln.h:84
+#define FM 0
+#define FI 1
+#define FD 2
+
+struct DpParams {
+	int n;
+	const int64_t *ref_off, *qry_off;
+	const uint8_t *ref, *qry;
+	int gap_open, gap_ext, gap_end, band;
+	int matrix[25];
+	int W;                 // max_l1 + 1
+	int H;                 // max_l2 + 1
+	int32_t *rows;         // per wave: [6][W][64]
+	uint8_t *tb;           // per wave: [H][W][64], byte = Mt | It<<2 | Dt<<4
+	uint8_t *path;         // per wave: [W+H][64]
+	int32_t *score, *n_cigar; uint32_t *cigar; int max_cigar;
+};
+
+__global__ __launch_bounds__(256) void dp_global_kernel(const DpParams P)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= P.n) return;
+	const uint8_t *s1 = P.ref + P.ref_off[t], *s2 = P.qry + P.qry_off[t];
+	const int l1 = (int)(P.ref_off[t + 1] - P.ref_off[t]), l2 = (int)(P.qry_off[t + 1] - P.qry_off[t]);
+	P.n_cigar[t] = 0; P.score[t] = 0;
+	if (l1 == 0 || l2 == 0) return;
+	const int W = P.W;
+	int32_t *R = P.rows + wave * 6 * (size_t)W * 64 + lane;
+	uint8_t *TB = P.tb + wave * (size_t)P.H * W * 64 + lane;
+	uint8_t *PATH = P.path + wave * (size_t)(W + P.H) * 64 + lane;
+#define ROW(arr, par, i) R[(((arr) * 2 + (par)) * (size_t)W + (i)) * 64]     // arr: 0 M, 1 I, 2 D; par: row parity
+#define TBC(j, i) TB[((size_t)(j) * W + (i)) * 64]
+	const int gap_open = P.gap_open, gap_ext = P.gap_ext;
+	const int end_pen = P.gap_end >= 0 ? P.gap_end : P.gap_ext;
+	int b1, b2;
+	if (l1 > l2) { b1 = l1 - l2 + P.band; b2 = P.band; } else { b1 = P.band; b2 = l2 - l1 + P.band; }
+	if (b1 > l1) b1 = l1;
+	if (b2 > l2) b2 = l2;
+	// row 0
+	ROW(0, 0, 0) = 0; ROW(1, 0, 0) = NINF; ROW(2, 0, 0) = NINF;
+	{
+		int pm = 0, pd = NINF;
+		for (int i = 1; i < b1; ++i) {
+			int d, tt;
+			if (pm - gap_open > pd) { tt = FM; d = pm - gap_open - end_pen; } else { tt = FD; d = pd - end_pen; }
+			ROW(0, 0, i) = NINF; ROW(1, 0, i) = NINF; ROW(2, 0, i) = d;
+			TBC(0, i) = (uint8_t)(tt << 4);
+			pm = NINF; pd = d;
+		}
+	}
+	for (int j = 1; j <= l2; ++j) {
+		const int cur = j & 1, prv = cur ^ 1;
+		const int left = j > b2 ? j - b2 : 0, right = j + b1 - 1 < l1 ? j + b1 - 1 : l1;
+		const int *mat = P.matrix + s2[j - 1] * 5;
+		const int dpen = j == l2 ? end_pen : gap_ext;
+		int cm_l = NINF, cd_l = NINF;          // M and D of the cell to the left in this row
+		ROW(0, cur, left) = NINF; ROW(1, cur, left) = NINF; ROW(2, cur, left) = NINF; TBC(j, left) = 0;
+		if (left == 0) {                       // column 0: end-gap insertion chain
+			const int pm0 = ROW(0, prv, 0), pi0 = ROW(1, prv, 0);
+			int v, tt;
+			if (pm0 - gap_open > pi0) { tt = FM; v = pm0 - gap_open - end_pen; } else { tt = FI; v = pi0 - end_pen; }
+			ROW(1, cur, 0) = v; TBC(j, 0) = (uint8_t)(tt << 2);
+		}
+		int pm_d = ROW(0, prv, left), pi_d = ROW(1, prv, left), pd_d = ROW(2, prv, left);   // diagonal cell (i-1) of the previous row
+		for (int i = left + 1; i <= right; ++i) {
+			const int sc = mat[s1[i - 1]];
+			int m, mt, iv = NINF, it = 0, dv, dt;
+			if (pm_d >= pi_d) { if (pm_d >= pd_d) { m = pm_d + sc; mt = FM; } else { m = pd_d + sc; mt = FD; } }
+			else { if (pi_d > pd_d) { m = pi_d + sc; mt = FI; } else { m = pd_d + sc; mt = FD; } }
+			// the cell above (row j-1, column i): needed for I, and it is the next column's diagonal
+			const bool above = !(i == right && !(j + b1 - 1 > l1));
+			int pm_u = NINF, pi_u = NINF, pd_u = NINF;
+			if (above || i < right) { pm_u = ROW(0, prv, i); pi_u = ROW(1, prv, i); pd_u = ROW(2, prv, i); }
+			if (above) {
+				const int ipen = i == l1 ? end_pen : gap_ext;
+				if (pm_u - gap_open > pi_u) { it = FM; iv = pm_u - gap_open - ipen; } else { it = FI; iv = pi_u - ipen; }
+			}
+			if (cm_l - gap_open > cd_l) { dt = FM; dv = cm_l - gap_open - dpen; } else { dt = FD; dv = cd_l - dpen; }
+			ROW(0, cur, i) = m; ROW(1, cur, i) = iv; ROW(2, cur, i) = dv;
+			TBC(j, i) = (uint8_t)(mt | it << 2 | dt << 4);
+			cm_l = m; cd_l = dv;
+			pm_d = pm_u; pi_d = pi_u; pd_d = pd_u;
+		}
+	}
+	// backtrace
+	int i = l1, j = l2, score, type, ctype;
+	{
+		const int lm = ROW(0, l2 & 1, l1), li = ROW(1, l2 & 1, l1), ld = ROW(2, l2 & 1, l1);
+		const uint8_t q = TBC(l2, l1);
+		score = lm; type = q & 3; ctype = FM;
+		if (li > score) { score = li; type = q >> 2 & 3; ctype = FI; }
+		if (ld > score) { score = ld; type = q >> 4 & 3; ctype = FD; }
+	}
+	int plen = 0;
+	PATH[(size_t)plen++ * 64] = (uint8_t)ctype;
+	do {
+		if (ctype == FM) { --i; --j; } else if (ctype == FI) --j; else --i;
+		const uint8_t q = TBC(j, i);
+		ctype = type;
+		type = type == FM ? (q & 3) : (type == FI ? (q >> 2 & 3) : (q >> 4 & 3));
+		PATH[(size_t)plen++ * 64] = (uint8_t)ctype;
+	} while (i || j);
+	--plen;                        // the entry written at (0,0) is not part of the path
+	// run-length encode from the path's end: cigar32 = len<<4 | op
+	uint32_t *cg = P.cigar + (size_t)t * P.max_cigar;
+	int n = 0; uint32_t curc = 0;
+	for (int p = plen - 1; p >= 0; --p) {
+		const uint32_t op = PATH[(size_t)p * 64];
+		if (n && (curc & 0xf) == op) curc += 1u << 4;
+		else {
+			if (n && n <= P.max_cigar) cg[n - 1] = curc;
+			curc = 1u << 4 | op; ++n;
+		}
+	}
+	if (n && n <= P.max_cigar) cg[n - 1] = curc;
+	P.n_cigar[t] = n;              // n > max_cigar signals truncation to the host
+	P.score[t] = score;
+#undef ROW
+#undef TBC
+}
+
+extern "C" void nabwa_launch_dp_global(const DpParams *P, hipStream_t s)
+{
+	if (P->n <= 0) return;
+	hipLaunchKernelGGL(dp_global_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
+}

@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../include/nabwa.h"
 #include "fm_search.hpp"
+#include "nabwa_internal.hpp"
 
 extern "C" {
 void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets, uint4 *out, hipStream_t s);
@@ -38,6 +39,7 @@ static int fail(int code, const char *fmt, const char *a = "")
 {
 	char buf[512]; snprintf(buf, sizeof buf, fmt, a); g_err = buf; return code;
 }
+int nabwa_fail(int code, const char *fmt, const char *a) { return fail(code, fmt, a); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 	char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
 	g_err = b_; return NABWA_ENODEV; } } while (0)
@@ -78,14 +80,6 @@ extern "C" int nabwa_cal_maxdiff(int l, double err, double thres)
 }
 
 /* ------------------------------------------------------------------ index */
-
-struct nabwa_index {
-	int device;
-	DevBwt bwt[2];
-	uint4 *bk[2];
-	uint32_t *sa[2];
-	uint64_t bytes;
-};
 
 static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_words, bool on_device,
 					 const uint32_t *sa_words, uint64_t n_sa_words)
@@ -140,7 +134,7 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
-	memset(ix, 0, sizeof(*ix));
+	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
 	if (r == NABWA_OK) r = build_one(ix, 1, bwt1, nw1, is_device != 0, sa1, ns1);
@@ -162,7 +156,6 @@ static bool slurp(const std::string &fn, std::vector<uint32_t> &v)
 
 extern "C" int nabwa_index_load(const char *prefix, int device, int with_sa, int with_pac, nabwa_index_t **out)
 {
-	(void)with_pac;
 	if (!prefix || !out) return fail(NABWA_EINVAL, "null argument");
 	std::vector<uint32_t> b0, b1, s0, s1;
 	std::string p(prefix);
@@ -172,8 +165,13 @@ extern "C" int nabwa_index_load(const char *prefix, int device, int with_sa, int
 		if (!slurp(p + ".sa", s0)) return fail(NABWA_EIO, "cannot read %s.sa", prefix);
 		if (!slurp(p + ".rsa", s1)) return fail(NABWA_EIO, "cannot read %s.rsa", prefix);
 	}
-	return nabwa_index_from_arrays(device, 0, b0.data(), b0.size(), b1.data(), b1.size(),
-								   with_sa ? s0.data() : 0, s0.size(), with_sa ? s1.data() : 0, s1.size(), out);
+	int r = nabwa_index_from_arrays(device, 0, b0.data(), b0.size(), b1.data(), b1.size(),
+									with_sa ? s0.data() : 0, s0.size(), with_sa ? s1.data() : 0, s1.size(), out);
+	if (r == NABWA_OK && with_pac) {
+		r = nabwa_index_attach_reference(*out, prefix);
+		if (r != NABWA_OK) { nabwa_index_destroy(*out); *out = 0; }
+	}
+	return r;
 }
 
 extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
@@ -181,6 +179,7 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
 	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); }
+	delete ix->ref;
 	delete ix;
 }
 

@@ -1,0 +1,27 @@
+// nabwa_internal.hpp -- host-side structures shared by the translation units of libnabwa.so
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "fm_search.hpp"
+
+struct nabwa_ann { int64_t offset; int32_t len, n_ambs; std::string name; };    // bntann1_t, bntseq.h:39-45
+struct nabwa_hole { int64_t offset; int32_t len; char amb; };                   // bntamb1_t, bntseq.h:47-51
+
+struct nabwa_reference {          // bntseq_t + the packed reference (bntseq.h:53-61, bwtio.c pac)
+	int64_t l_pac; uint32_t seed;
+	std::vector<nabwa_ann> anns;
+	std::vector<nabwa_hole> holes;
+	std::vector<uint8_t> pac;     // 2 bits per base, 4 bases per byte, first base in the top bits (bwtaln.h:33)
+};
+
+struct nabwa_index {
+	int device;
+	DevBwt bwt[2];
+	uint4 *bk[2];
+	uint32_t *sa[2];
+	uint64_t bytes;
+	nabwa_reference *ref;
+};
+
+int nabwa_fail(int code, const char *fmt, const char *a = "");

@@ -1,0 +1,119 @@
+"""GPU tests of the single-end finishing chain through the product's C ABI:
+ * nabwa_global_align (HIP aln_global_core) against the DP vectors the reference produced;
+ * FM search -> nabwa_se_finish (host RNG in record order, GPU bwt_sa batch, GPU gap refinement, MD/NM, flags)
+   against the reference's own `samse` output for the same reads: position, CIGAR, MAPQ, NM, MD, X0/X1/XM/XO/XG,
+   XA, XT, flags (contig bridging, trimming)."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+
+pytestmark = pytest.mark.gpu
+nabwa = importlib.import_module("network-aware-bwa_amd")
+
+SM = [np.array([11, -19, -19, -19, -13, -19, 11, -19, -19, -13, -19, -19, 11, -19, -13,
+                -19, -19, -19, 11, -13, -13, -13, -13, -13, -13], np.int32),
+      np.array([1, -3, -3, -3, -2, -3, 1, -3, -3, -2, -3, -3, 1, -3, -2,
+                -3, -3, -3, 1, -2, -2, -2, -2, -2, -2], np.int32)]
+
+
+def test_global_align_golden():
+    vec = np.load(os.path.join(T.GOLDEN, "vectors.npz"))
+    n = int(vec["dp_n"])
+    for pid in range(len(vec["dp_params"])):
+        go, ge, gend, band, smid = [int(x) for x in vec["dp_params"][pid]]
+        idx = [t for t in range(n) if vec["dp_pid"][t] == pid]
+        refs = [vec["dp_ref"][vec["dp_ref_off"][t]:vec["dp_ref_off"][t + 1]] for t in idx]
+        qrys = [vec["dp_qry"][vec["dp_qry_off"][t]:vec["dp_qry_off"][t + 1]] for t in idx]
+        ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+        qo = np.concatenate([[0], np.cumsum([len(q) for q in qrys])]).astype(np.int64)
+        score, cigs = nabwa.global_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, go, ge, gend, SM[smid], band,
+                                         max_cigar=512)
+        for j, t in enumerate(idx):
+            want = vec["dp_cig"][vec["dp_cig_off"][t]:vec["dp_cig_off"][t + 1]]
+            assert score[j] == vec["dp_score"][t], (pid, t)
+            assert list(cigs[j]) == list(want), (pid, t)
+
+
+def test_global_align_random_vs_oracle():
+    """fresh random pairs incl. length-1 and very unequal lengths, several parameter blocks"""
+    olib = T.load_oracle()
+    rng = np.random.default_rng(5)
+    refs, qrys = [], []
+    for _ in range(700):
+        l2 = int(rng.integers(1, 160))
+        q = rng.integers(0, 5, l2).astype(np.uint8)
+        if rng.random() < 0.6:
+            r = list(q)
+            for _ in range(int(rng.integers(0, 5))):
+                p = int(rng.integers(0, len(r) + 1))
+                if rng.random() < 0.5 and len(r) > 1:
+                    del r[min(p, len(r) - 1)]
+                else:
+                    r.insert(p, int(rng.integers(0, 4)))
+            r = np.array(r if r else [0], np.uint8)
+        else:
+            r = rng.integers(0, 5, int(rng.integers(1, 200))).astype(np.uint8)
+        refs.append(r)
+        qrys.append(q)
+    ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+    qo = np.concatenate([[0], np.cumsum([len(q) for q in qrys])]).astype(np.int64)
+    cig = (C.c_uint32 * 1024)()
+    ncig = C.c_int()
+    for go, ge, gend, sm, band in ((26, 9, 5, SM[0], 50), (26, 9, -1, SM[0], 50), (5, 2, 2, SM[1], 7), (8, 2, 2, SM[1], 3)):
+        score, cigs = nabwa.global_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, go, ge, gend, sm, band,
+                                         max_cigar=512)
+        for i, (r, q) in enumerate(zip(refs, qrys)):
+            r = np.ascontiguousarray(r)
+            q = np.ascontiguousarray(q)
+            sc = olib.orc_global(T.ptr(r), len(r), T.ptr(q), len(q), go, ge, gend, T.ptr(sm), 5, band, cig, C.byref(ncig))
+            assert score[i] == sc, (i, band)
+            assert list(cigs[i]) == list(cig[:ncig.value]), (i, band)
+
+
+@pytest.mark.parametrize("name", ["default", "adna", "q20"])
+def test_se_chain_matches_reference_sam(name):
+    opt, _ = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    sam = T.parse_sam(os.path.join(T.GOLDEN, "se_%s.sam" % name))
+    seq, rseq, off, full = T.encode_reads(reads, opt.trim_qual)
+    g = nabwa.GapOpt()
+    C.memmove(C.byref(g), C.byref(opt), 64)
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    hits, _ = ix.cal_sa_reg_gap(g, seq, rseq, off, per_read=False)          # bwa aln semantics (one call for the file)
+    # two batches, to check that the RNG stream continues across calls exactly as the process-global one does
+    cut = 301
+    st = nabwa.srand48_state(11)                                           # srand48(bns->seed), seed 11 (bntseq.c:181)
+    recs = []
+    for lo, hi in ((0, cut), (cut, len(reads))):
+        o = off[lo:hi + 1] - off[lo]
+        out, st = ix.se_finish(g, seq[off[lo]:off[hi]], rseq[off[lo]:off[hi]], o, full[lo:hi], hits[lo:hi], 3, st)
+        recs.extend(out[i] for i in range(hi - lo))
+    names = ["chr1", "chr2", "chr3"]
+    offs = [0, 60000, 100000]
+    for rd, r, gsam in zip(reads, recs, sam):
+        assert gsam["name"] == rd[0]
+        assert r.flag == gsam["flag"], rd[0]
+        if r.type == 0:
+            continue
+        assert names[r.seqid] == gsam["rname"] and r.rpos == gsam["pos"] and r.mapQ == gsam["mapq"], rd[0]
+        cig = T.cigar16_str(r.cigar[:r.n_cigar]) if r.n_cigar else "%dM" % r.len
+        assert cig == gsam["cigar"], rd[0]
+        tg = gsam["tags"]
+        assert r.xt.decode() == tg["XT"] and r.nm == tg["NM"] and r.md.decode() == tg["MD"], rd[0]
+        assert r.c1 == tg["X0"], rd[0]
+        if r.c1 <= opt.max_top2:
+            assert r.c2 == tg["X1"], rd[0]
+        assert (r.n_mm, r.n_gapo, r.n_gapo + r.n_gape) == (tg["XM"], tg["XO"], tg["XG"]), rd[0]
+        xa = ""
+        for j in range(r.n_multi):
+            m = r.multi[j]
+            mc = T.cigar16_str(m.cigar[:m.n_cigar]) if m.n_cigar else "%dM" % r.len
+            sid = max(k for k, o in enumerate(offs) if m.pos >= o)
+            xa += "%s,%s%d,%s,%d;" % (names[sid], "-" if m.strand else "+", m.pos - offs[sid] + 1, mc, m.gap + m.mm)
+        assert xa == tg.get("XA", ""), rd[0]
+    ix.close()
