@@ -51,13 +51,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    backend = os.environ.get("NABWA_BENCH_BACKEND", "nccl")          # "gloo": rehearsal of the N>1 path on one GPU
+    one_dev = os.environ.get("NABWA_BENCH_SINGLE_DEVICE") == "1"
+    dev = local_rank if (world > 1 and not one_dev) else 0
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     nabwa = importlib.import_module("network-aware-bwa_amd")
     synth = importlib.import_module("network-aware-bwa_amd.synth")
@@ -107,7 +111,7 @@ def main():
     barrier()
     elapsed = time.time() - t1
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     checksum, n_rows = batch.checksum()
