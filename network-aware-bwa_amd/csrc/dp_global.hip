@@ -144,3 +144,89 @@ extern "C" void nabwa_launch_dp_global(const DpParams *P, hipStream_t s)
 	if (P->n <= 0) return;
 	hipLaunchKernelGGL(dp_global_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Forward pass of aln_extend_core (stdaln.c:862-976): left-anchored extension with a packed row
+// eh[i] = h[j-1,i-1] << 16 | e[j,i], an adaptive column window [start, end) that follows the
+// positive cells, 16-bit overflow rebasing (LOCAL_OVERFLOW_*, stdaln.c:230-231) and the seed score
+// G0 in eh[1].  Produces score (+of_base-1) and the end cell; the path is then filled by the global
+// kernel on the two prefixes with a doubling band (stdaln.c:985-1000), driven from the host.
+// ---------------------------------------------------------------------------------------------
+struct ExtParams {
+	int n;
+	const int64_t *ref_off, *qry_off;
+	const uint8_t *ref, *qry;
+	const int32_t *g0;
+	int gap_open, gap_ext, band;
+	int matrix[25];
+	int W;                 // max_l1 + 2
+	uint32_t *eh;          // per wave: [W][64]
+	int32_t *score, *end_i, *end_j;
+};
+
+__global__ __launch_bounds__(256) void dp_extend_fwd_kernel(const ExtParams P)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= P.n) return;
+	const uint8_t *s1 = P.ref + P.ref_off[t] - 1, *s2 = P.qry + P.qry_off[t] - 1;   // 1-based as in the reference
+	const int l1 = (int)(P.ref_off[t + 1] - P.ref_off[t]), l2 = (int)(P.qry_off[t + 1] - P.qry_off[t]);
+	P.score[t] = -1; P.end_i[t] = 0; P.end_j[t] = 0;
+	if (l1 == 0 || l2 == 0) return;
+	uint32_t *EH = P.eh + wave * (size_t)P.W * 64 + lane;
+#define E(i) EH[(size_t)(i) * 64]
+	const int r = P.gap_ext, qr = P.gap_open + P.gap_ext;
+	for (int i = 0; i < l1 + 2; ++i) E(i) = 0;
+	E(1) = (uint32_t)P.g0[t] << 16;
+	int start = 1, end = 2, end_i = 0, end_j = 0, score = 0, is_overflow = 0, of_base = 0;
+	for (int j = 1; j <= l2; ++j) {
+		int h1 = 0, f = 0;
+		const int *mat = P.matrix + s2[j] * 5;
+		int _start = j - P.band; if (_start < 1) _start = 1;
+		if (_start > start) start = _start;
+		int _end = j + P.band; if (_end > l1 + 1) _end = l1 + 1;
+		if (_end < end) end = _end;
+		if (start == end) break;
+		if (is_overflow) {
+			score -= 16000; of_base += 16000; is_overflow = 0;
+			for (int i = start; i <= end; ++i) {
+				const uint32_t v = E(i);
+				int a = (int)(v >> 16), b = (int)(v & 0xffff);
+				b = b < 16000 ? 0 : b - 16000;
+				a = a < 16000 ? 0 : a - 16000;
+				E(i) = (uint32_t)a << 16 | (uint32_t)b;
+			}
+		}
+		_start = _end = 0;
+		for (int i = start; i < end; ++i) {
+			const uint32_t v = E(i);
+			int h = (int)(v >> 16), e = (int)(v & 0xffff);
+			uint32_t nv = (uint32_t)h1 << 16;
+			h += h ? mat[s1[i]] : 0;
+			h = h > e ? h : e;
+			h = h > f ? h : f;
+			h1 = h;
+			if (h > 0) {
+				if (_start == 0) _start = i;
+				_end = i;
+				if (score < h) { score = h; end_i = i; end_j = j; if (score > 32000) is_overflow = 1; }
+			}
+			h -= qr; h = h > 0 ? h : 0;
+			e -= r; e = e > h ? e : h;
+			f -= r; f = f > h ? f : h;
+			E(i) = nv | (uint32_t)e;
+		}
+		E(end) = (uint32_t)h1 << 16;
+		if (_end <= 0) break;
+		start = _start; end = _end + 3;
+	}
+	P.score[t] = score + of_base - 1; P.end_i[t] = end_i; P.end_j[t] = end_j;
+#undef E
+}
+
+extern "C" void nabwa_launch_dp_extend_fwd(const ExtParams *P, hipStream_t s)
+{
+	if (P->n <= 0) return;
+	hipLaunchKernelGGL(dp_extend_fwd_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
+}

@@ -84,6 +84,86 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 	return NABWA_OK;
 }
 
+/* ------------------------------------------------------------------ batched aln_extend_core */
+
+struct ExtParams {
+	int n;
+	const int64_t *ref_off, *qry_off;
+	const uint8_t *ref, *qry;
+	const int32_t *g0;
+	int gap_open, gap_ext, band;
+	int matrix[25];
+	int W;
+	uint32_t *eh;
+	int32_t *score, *end_i, *end_j;
+};
+extern "C" void nabwa_launch_dp_extend_fwd(const ExtParams *P, hipStream_t s);
+
+extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
+								  const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, const int32_t *G0,
+								  int32_t *score, int32_t *n_cigar, uint32_t *cigar32, int max_cigar)
+{
+	if (n < 0 || (n && (!ref_off || !qry_off || !ref || !qry || !matrix25 || !G0 || !score || !n_cigar || !cigar32)) || max_cigar < 1 || band < 1)
+		return nabwa_fail(NABWA_EINVAL, "bad argument");
+	if (n == 0) return NABWA_OK;
+	if (nabwa_device_count() <= device) return nabwa_fail(NABWA_ENODEV, "no such HIP device");
+	SCHK(hipSetDevice(device));
+	/* forward pass on the GPU */
+	int W = 2;
+	for (int i = 0; i < n; ++i) W = std::max<int64_t>(W, ref_off[i + 1] - ref_off[i] + 2);
+	std::vector<int32_t> fs(n), ei(n), ej(n);
+	{
+		ExtParams P; memset(&P, 0, sizeof(P));
+		const size_t waves = (size_t)((n + 255) / 256) * 4;
+		int64_t *d_ro = 0, *d_qo = 0; uint8_t *d_ref = 0, *d_qry = 0; int32_t *d_g0 = 0;
+		SCHK(hipMalloc(&d_ro, (size_t)(n + 1) * 8)); SCHK(hipMalloc(&d_qo, (size_t)(n + 1) * 8));
+		SCHK(hipMalloc(&d_ref, ref_off[n] + 16)); SCHK(hipMalloc(&d_qry, qry_off[n] + 16)); SCHK(hipMalloc(&d_g0, (size_t)n * 4));
+		SCHK(hipMalloc(&P.eh, waves * (size_t)W * 64 * 4));
+		SCHK(hipMalloc(&P.score, (size_t)n * 4)); SCHK(hipMalloc(&P.end_i, (size_t)n * 4)); SCHK(hipMalloc(&P.end_j, (size_t)n * 4));
+		SCHK(hipMemcpy(d_ro, ref_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		SCHK(hipMemcpy(d_qo, qry_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		if (ref_off[n]) SCHK(hipMemcpy(d_ref, ref, ref_off[n], hipMemcpyHostToDevice));
+		if (qry_off[n]) SCHK(hipMemcpy(d_qry, qry, qry_off[n], hipMemcpyHostToDevice));
+		SCHK(hipMemcpy(d_g0, G0, (size_t)n * 4, hipMemcpyHostToDevice));
+		P.n = n; P.ref_off = d_ro; P.qry_off = d_qo; P.ref = d_ref; P.qry = d_qry; P.g0 = d_g0;
+		P.gap_open = gap_open; P.gap_ext = gap_ext; P.band = band; memcpy(P.matrix, matrix25, sizeof(P.matrix)); P.W = W;
+		nabwa_launch_dp_extend_fwd(&P, 0);
+		SCHK(hipGetLastError());
+		SCHK(hipMemcpy(fs.data(), P.score, (size_t)n * 4, hipMemcpyDeviceToHost));
+		SCHK(hipMemcpy(ei.data(), P.end_i, (size_t)n * 4, hipMemcpyDeviceToHost));
+		SCHK(hipMemcpy(ej.data(), P.end_j, (size_t)n * 4, hipMemcpyDeviceToHost));
+		void *fr[] = { d_ro, d_qo, d_ref, d_qry, d_g0, P.eh, P.score, P.end_i, P.end_j };
+		for (void *p : fr) SCHK(hipFree(p));
+	}
+	/* path: global alignment of the two prefixes with gap_end = -1 and a doubling band (stdaln.c:985-1000) */
+	std::vector<int> act;
+	for (int i = 0; i < n; ++i) { score[i] = fs[i]; n_cigar[i] = 0; if (fs[i] > 0) act.push_back(i); }
+	for (int bw = band; !act.empty(); bw <<= 1) {
+		std::vector<int64_t> ro(act.size() + 1, 0), qo(act.size() + 1, 0); std::vector<uint8_t> rb, qb;
+		for (size_t t = 0; t < act.size(); ++t) {
+			const int i = act[t];
+			rb.insert(rb.end(), ref + ref_off[i], ref + ref_off[i] + ei[i]);
+			qb.insert(qb.end(), qry + qry_off[i], qry + qry_off[i] + ej[i]);
+			ro[t + 1] = (int64_t)rb.size(); qo[t + 1] = (int64_t)qb.size();
+		}
+		rb.push_back(0); qb.push_back(0);
+		std::vector<int32_t> sg(act.size()), nc(act.size()); std::vector<uint32_t> cg(act.size() * (size_t)max_cigar);
+		int r = nabwa_global_align(device, (int)act.size(), ro.data(), rb.data(), qo.data(), qb.data(), gap_open, gap_ext, -1,
+								   matrix25, bw, sg.data(), nc.data(), cg.data(), max_cigar);
+		if (r != NABWA_OK) return r;
+		std::vector<int> next;
+		for (size_t t = 0; t < act.size(); ++t) {
+			const int i = act[t], jmax = std::max(ei[i], ej[i]);
+			if (sg[t] == fs[i] || bw > jmax) {
+				score[i] = sg[t]; n_cigar[i] = nc[t];
+				memcpy(cigar32 + (size_t)i * max_cigar, cg.data() + t * (size_t)max_cigar, (size_t)std::min(nc[t], max_cigar) * 4);
+			} else next.push_back(i);
+		}
+		act.swap(next);
+	}
+	return NABWA_OK;
+}
+
 /* ------------------------------------------------------------------ reference annotations */
 
 extern "C" int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefix)

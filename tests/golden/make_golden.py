@@ -323,7 +323,65 @@ def main():
     out["dp_cig_off"] = np.cumsum([0] + [len(x[4]) for x in dp_rows]).astype(np.int64)
     out["dp_params"] = np.array([[p[0], p[1], p[2], p[4], 0 if p[3] is sm_maq else 1] for p in params], np.int32)
     np.savez_compressed(os.path.join(HERE, "vectors.npz"), **out)
+    make_sw_vectors(lib, sm_maq, sm_blast)
     print("golden fixtures written to", HERE, "reads:", len(reads))
+
+
+def make_sw_vectors(lib, sm_maq, sm_blast):
+    """aln_extend_core (stdaln.c:862) and aln_local_core (stdaln.c:529) known answers -> vectors_sw.npz"""
+    rng = np.random.default_rng(424242)
+    lib.ref_extend.restype = C.c_int
+    lib.ref_local.restype = C.c_int
+    params = [(26, 9, 5, sm_maq, 50, 0), (5, 2, 2, sm_blast, 50, 1), (26, 9, 5, sm_maq, 8, 0), (5, 2, 2, sm_blast, 4, 1)]
+    refs, qrys, pids, g0s, e_score, e_cig, l_score, l_cig, l_subo = [], [], [], [], [], [], [], [], []
+    cig = (C.c_uint32 * 4096)()
+    ncig = C.c_int()
+    plen = C.c_int()
+    subo = C.c_int()
+    for t in range(240):
+        l2 = int(rng.integers(1, 150))
+        q = rng.integers(0, 4, l2).astype(np.uint8)
+        r = list(q)
+        for _ in range(int(rng.integers(0, 6))):
+            pos = int(rng.integers(0, len(r) + 1))
+            k = int(rng.integers(0, 3))
+            if k == 0 and len(r) > 1:
+                del r[min(pos, len(r) - 1)]
+            elif k == 1:
+                r.insert(pos, int(rng.integers(0, 4)))
+            elif len(r):
+                r[min(pos, len(r) - 1)] = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            r = list(rng.integers(0, 4, int(rng.integers(1, 200))))
+        elif kind == 1:
+            r = list(rng.integers(0, 4, int(rng.integers(0, 60)))) + r + list(rng.integers(0, 4, int(rng.integers(0, 60))))
+        elif kind == 2:
+            r = r + list(rng.integers(0, 4, int(rng.integers(1, 80))))
+        if not r:
+            r = [0]
+        if rng.integers(0, 10) == 0:
+            r[int(rng.integers(0, len(r)))] = 4
+        r = np.array(r, np.uint8)
+        pid = t % len(params)
+        go, ge, gend, sm, band, _ = params[pid]
+        g0 = int(rng.integers(1, 60))
+        sc = lib.ref_extend(r.ctypes.data_as(C.c_void_p), len(r), q.ctypes.data_as(C.c_void_p), len(q), go, ge, gend,
+                            sm.ctypes.data_as(C.c_void_p), 5, band, g0, cig, C.byref(ncig), None, C.byref(plen))
+        refs.append(r); qrys.append(q); pids.append(pid); g0s.append(g0)
+        e_score.append(sc); e_cig.append(np.array(cig[:ncig.value], np.uint32))
+        sc = lib.ref_local(r.ctypes.data_as(C.c_void_p), len(r), q.ctypes.data_as(C.c_void_p), len(q), go, ge, gend,
+                           sm.ctypes.data_as(C.c_void_p), 5, band, 1, cig, C.byref(ncig), None, C.byref(plen), C.byref(subo))
+        l_score.append(sc); l_cig.append(np.array(cig[:ncig.value], np.uint32)); l_subo.append(subo.value)
+    cat = lambda xs, dt: np.concatenate([np.asarray(x, dt) for x in xs]) if xs else np.zeros(0, dt)
+    offs = lambda xs: np.cumsum([0] + [len(x) for x in xs]).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "vectors_sw.npz"),
+                        ref=cat(refs, np.uint8), ref_off=offs(refs), qry=cat(qrys, np.uint8), qry_off=offs(qrys),
+                        pid=np.array(pids, np.int32), g0=np.array(g0s, np.int32),
+                        params=np.array([[p[0], p[1], p[2], p[4], p[5]] for p in params], np.int32),
+                        ext_score=np.array(e_score, np.int32), ext_cig=cat(e_cig, np.uint32), ext_cig_off=offs(e_cig),
+                        loc_score=np.array(l_score, np.int32), loc_cig=cat(l_cig, np.uint32), loc_cig_off=offs(l_cig),
+                        loc_subo=np.array(l_subo, np.int32))
 
 
 if __name__ == "__main__":

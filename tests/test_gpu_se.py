@@ -117,3 +117,22 @@ def test_se_chain_matches_reference_sam(name):
             xa += "%s,%s%d,%s,%d;" % (names[sid], "-" if m.strand else "+", m.pos - offs[sid] + 1, mc, m.gap + m.mm)
         assert xa == tg.get("XA", ""), rd[0]
     ix.close()
+
+
+def test_extend_align_golden():
+    """aln_extend_core (named by the north star; reached from bwasw in the reference): known answers from the reference"""
+    v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
+    n = len(v["pid"])
+    for pid in range(len(v["params"])):
+        go, ge, gend, band, smid = [int(x) for x in v["params"][pid]]
+        idx = [t for t in range(n) if v["pid"][t] == pid]
+        refs = [v["ref"][v["ref_off"][t]:v["ref_off"][t + 1]] for t in idx]
+        qrys = [v["qry"][v["qry_off"][t]:v["qry_off"][t + 1]] for t in idx]
+        ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+        qo = np.concatenate([[0], np.cumsum([len(q) for q in qrys])]).astype(np.int64)
+        score, cigs = nabwa.extend_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, go, ge, SM[smid], band,
+                                         v["g0"][idx], max_cigar=512)
+        for j, t in enumerate(idx):
+            assert score[j] == v["ext_score"][t], (pid, t)
+            want = v["ext_cig"][v["ext_cig_off"][t]:v["ext_cig_off"][t + 1]]
+            assert list(cigs[j]) == list(want), (pid, t)
