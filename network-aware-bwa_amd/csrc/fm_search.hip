@@ -304,7 +304,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	for (;;) {
 		bool finish = false;
 		// ---------------------------------------------------------------- refill
-		const unsigned long long need = __ballot(st == LS_IDLE);
+		unsigned long long need = __ballot(st == LS_IDLE);
+		if (P.sync_refill && __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull) need = 0ull;   // experiment: refill only when the whole wave is idle
 		if (need) {
 			unsigned int base = 0;
 			if (lane == 0) base = atomicAdd(P.work_counter, (unsigned int)__popcll(need));

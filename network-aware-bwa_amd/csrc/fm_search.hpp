@@ -35,5 +35,6 @@ struct SearchParams {
 	uint4 *aln;
 	int aln_cap;
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
+	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
 };

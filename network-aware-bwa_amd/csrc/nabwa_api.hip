@@ -326,6 +326,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	if (cap1 > 65534) cap1 = 65534;
 	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, NS);
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
+	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
 	if (P.aln_cap < 1) P.aln_cap = 1;
 
 	hipDeviceProp_t prop;
