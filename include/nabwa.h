@@ -127,6 +127,14 @@ int nabwa_extend_align(int device, int n, const int64_t *ref_off, const uint8_t 
 					   const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, const int32_t *G0,
 					   int32_t *score, int32_t *n_cigar, uint32_t *cigar32, int max_cigar);
 
+/* Batch form of aln_local_core (stdaln.c:529-761; caller bwa_sw_core, bwape.c:456, mate rescue) with
+ * _thres = thres > 0: forward and reverse Smith-Waterman passes, then the path by global alignment of the
+ * sub-matrix (gap_end = -1, doubling band).  coords rows: start_i, start_j, end_i, end_j (1-based);
+ * subo (may be NULL): sub-optimal score as stdaln.c:700-709. */
+int nabwa_local_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
+					  const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, int thres,
+					  int32_t *score, int32_t *coords, int32_t *subo, int32_t *n_cigar, uint32_t *cigar32, int max_cigar);
+
 /* ---- single-end finishing chain: everything between the FM search and the BAM record -------- */
 #define NABWA_MAX_CIGAR 64
 #define NABWA_MAX_MD    512

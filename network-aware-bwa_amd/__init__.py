@@ -72,6 +72,24 @@ def global_align(ref, ref_off, qry, qry_off, gap_open, gap_ext, gap_end, matrix2
     return score[:n], [cig[i, :ncig[i]] for i in range(n)]
 
 
+def local_align(ref, ref_off, qry, qry_off, gap_open, gap_ext, matrix25, band, thres=1, device=0, max_cigar=MAX_CIGAR):
+    """aln_local_core (reference stdaln.c:529-761) for a batch of pairs -> (score, coords[n,4], subo, cigars)"""
+    n = len(ref_off) - 1
+    ref = np.ascontiguousarray(ref, np.uint8)
+    qry = np.ascontiguousarray(qry, np.uint8)
+    ref_off = np.ascontiguousarray(ref_off, np.int64)
+    qry_off = np.ascontiguousarray(qry_off, np.int64)
+    mat = np.ascontiguousarray(matrix25, np.int32)
+    score = np.zeros(max(n, 1), np.int32)
+    coords = np.zeros((max(n, 1), 4), np.int32)
+    subo = np.zeros(max(n, 1), np.int32)
+    ncig = np.zeros(max(n, 1), np.int32)
+    cig = np.zeros((max(n, 1), max_cigar), np.uint32)
+    _chk(lib().nabwa_local_align(device, n, _ptr(ref_off), _ptr(ref), _ptr(qry_off), _ptr(qry), gap_open, gap_ext, _ptr(mat),
+                                 band, thres, _ptr(score), _ptr(coords), _ptr(subo), _ptr(ncig), _ptr(cig), max_cigar))
+    return score[:n], coords[:n], subo[:n], [cig[i, :ncig[i]] for i in range(n)]
+
+
 def extend_align(ref, ref_off, qry, qry_off, gap_open, gap_ext, matrix25, band, g0, device=0, max_cigar=MAX_CIGAR):
     """aln_extend_core (reference stdaln.c:862-1007) for a batch of pairs"""
     n = len(ref_off) - 1
@@ -147,6 +165,8 @@ def lib():
     L.nabwa_global_align.argtypes = [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P,
                                      C.c_int]
     L.nabwa_extend_align.argtypes = [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int]
+    L.nabwa_local_align.argtypes = [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P,
+                                    C.c_int]
     L.nabwa_index_attach_reference.argtypes = [_P, C.c_char_p]
     L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
     _lib = L

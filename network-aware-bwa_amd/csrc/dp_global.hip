@@ -230,3 +230,130 @@ extern "C" void nabwa_launch_dp_extend_fwd(const ExtParams *P, hipStream_t s)
 	if (P->n <= 0) return;
 	hipLaunchKernelGGL(dp_extend_fwd_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
 }
+
+// ---------------------------------------------------------------------------------------------
+// aln_local_core (stdaln.c:529-761), passes 1 and 2: forward Smith-Waterman over a packed row
+// eh[i] = h << 16 | e with 16-bit overflow rebasing, giving score_f and the end cell (plus the
+// per-row maxima suba[] used for the sub-optimal score); then the reverse pass from the end cell
+// over an adaptive column band [end, start], giving score_r and the start cell.  The path is
+// filled by the global kernel on the sub-matrix with a doubling band (stdaln.c:723-735), driven
+// from the host.  Used by mate rescue (bwa_sw_core, bwape.c:456).
+// ---------------------------------------------------------------------------------------------
+struct LocParams {
+	int n;
+	const int64_t *ref_off, *qry_off;
+	const uint8_t *ref, *qry;
+	int gap_open, gap_ext, thres;
+	int matrix[25], max_score;
+	int W;                 // max_l1 + 2
+	int H;                 // max_l2 + 1
+	int32_t *eh;           // per wave: [W][64]
+	int32_t *suba;         // per task: [H]
+	int32_t *out;          // per task: score_f, score_r, start_i, start_j, end_i, end_j
+};
+
+__global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= P.n) return;
+	const uint8_t *s1 = P.ref + P.ref_off[t] - 1, *s2 = P.qry + P.qry_off[t] - 1;   // 1-based as in the reference
+	const int l1 = (int)(P.ref_off[t + 1] - P.ref_off[t]), l2 = (int)(P.qry_off[t + 1] - P.qry_off[t]);
+	int32_t *out = P.out + (size_t)t * 6;
+	out[0] = -1; out[1] = 0; out[2] = out[3] = out[4] = out[5] = 0;
+	if (l1 == 0 || l2 == 0) return;
+	int32_t *EH = P.eh + wave * (size_t)P.W * 64 + lane;
+	int32_t *suba = P.suba + (size_t)t * P.H;
+#define E(i) EH[(size_t)(i) * 64]
+	const int q = P.gap_open, r = P.gap_ext, qr = q + r, qr_shift = (qr + 1) << 16, tmp_len = l1 + 1;
+	int end_i = 0, end_j = 0, score_f = 0, is_overflow = 0, of_base = 0;
+	for (int i = 0; i < tmp_len; ++i) E(i) = 0;
+	suba[0] = 0;
+	// ---- forward pass
+	for (int j = 1; j <= l2; ++j) {
+		int subo = 0, last_h = 0, f = 0;
+		const int *mat = P.matrix + s2[j] * 5;
+		if (is_overflow) {
+			score_f -= 16000; of_base += 16000; is_overflow = 0;
+			for (int i = 0; i < tmp_len; ++i) {
+				const int v = E(i); int a = v >> 16, b = v & 0xffff;
+				b = b < 16000 ? 0 : b - 16000; a = a < 16000 ? 0 : a - 16000;
+				E(i) = a << 16 | b;
+			}
+		}
+		int sv = E(0);                                   // *s with s = &eh[i-1]
+		for (int i = 1; i != tmp_len; ++i) {
+			const int sn = E(i);                         // *(s+1)
+			int curr_h = (sv >> 16) + mat[s1[i]];
+			if (curr_h < 0) curr_h = 0;
+			if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
+			if (sn >= qr_shift) {
+				const int curr_last_h = sn >> 16;
+				const int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
+				if (curr_h < e) curr_h = e;
+				E(i - 1) = last_h << 16 | e;
+			} else E(i - 1) = last_h << 16;
+			last_h = curr_h;
+			if (subo < curr_h) subo = curr_h;
+			if (score_f < curr_h) { score_f = curr_h; end_i = i; end_j = j; if (score_f > 32000) is_overflow = 1; }
+			sv = sn;
+		}
+		E(l1) = last_h << 16;
+		suba[j] = subo + of_base;
+	}
+	score_f += of_base;
+	out[0] = score_f; out[4] = end_i; out[5] = end_j;
+	if (score_f < P.thres || end_i == 0 || end_j == 0) return;
+	// ---- reverse pass
+	for (int i = end_i; i >= 0; --i) E(i) = 0;
+	int score_r = P.matrix[s1[end_i] * 5 + s2[end_j]];
+	is_overflow = of_base = 0;
+	int start_i = end_i, start_j = end_j;
+	E(end_i) = (qr + score_r) << 16;
+	int start = end_i - 1, end = end_i - 3;
+	if (end <= 0) end = 0;
+	for (int j = end_j - 1; j != 0; --j) {
+		int last_h = 0, f = 0;
+		const int *mat = P.matrix + s2[j] * 5;
+		if (is_overflow) {
+			score_r -= 16000; of_base += 16000; is_overflow = 0;
+			for (int i = start; i >= end; --i) {
+				const int v = E(i + 1); int a = v >> 16, b = v & 0xffff;
+				b = b < 16000 ? 0 : b - 16000; a = a < 16000 ? 0 : a - 16000;
+				E(i + 1) = a << 16 | b;
+			}
+		}
+		int i = start;
+		for (; i != end && i >= 0; --i) {                // s = &eh[i+1]
+			const int sv = E(i + 1), sp = E(i);          // *s and *(s-1)
+			int curr_h = (sv >> 16) + mat[s1[i]];
+			if (curr_h < 0) curr_h = 0;
+			if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
+			const int curr_last_h = sp >> 16;
+			int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
+			if (e < 0) e = 0;
+			if (curr_h < e) curr_h = e;
+			E(i + 1) = last_h << 16 | e;
+			last_h = curr_h;
+			if (score_r < curr_h) {
+				score_r = curr_h; start_i = i; start_j = j;
+				if (score_r + of_base - qr == score_f) { j = 1; break; }
+				if (score_r > 32000) is_overflow = 1;
+			}
+		}
+		E(i + 1) = last_h << 16;                         // on the break, s was not advanced: same cell
+		if ((E(start) >> 16) <= qr) --start;
+		if (start <= 0) start = 0;
+		end = start_i - (start_j - j) - (score_r + of_base + (start_j - j) * P.max_score) / r - 1;
+		if (end <= 0) end = 0;
+	}
+	out[1] = score_r + of_base - qr; out[2] = start_i; out[3] = start_j;
+#undef E
+}
+
+extern "C" void nabwa_launch_dp_local(const LocParams *P, hipStream_t s)
+{
+	if (P->n <= 0) return;
+	hipLaunchKernelGGL(dp_local_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
+}

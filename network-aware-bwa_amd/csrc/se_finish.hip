@@ -164,6 +164,101 @@ extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, con
 	return NABWA_OK;
 }
 
+/* ------------------------------------------------------------------ batched aln_local_core */
+
+struct LocParams {
+	int n;
+	const int64_t *ref_off, *qry_off;
+	const uint8_t *ref, *qry;
+	int gap_open, gap_ext, thres;
+	int matrix[25], max_score;
+	int W, H;
+	int32_t *eh, *suba, *out;
+};
+extern "C" void nabwa_launch_dp_local(const LocParams *P, hipStream_t s);
+
+extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
+								 const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, int thres,
+								 int32_t *score, int32_t *coords /* n x 4: start_i,start_j,end_i,end_j (1-based) */, int32_t *subo,
+								 int32_t *n_cigar, uint32_t *cigar32, int max_cigar)
+{
+	if (n < 0 || (n && (!ref_off || !qry_off || !ref || !qry || !matrix25 || !score || !coords || !n_cigar || !cigar32)) || max_cigar < 1 || band < 1 || thres < 1)
+		return nabwa_fail(NABWA_EINVAL, "bad argument");
+	if (n == 0) return NABWA_OK;
+	if (nabwa_device_count() <= device) return nabwa_fail(NABWA_ENODEV, "no such HIP device");
+	SCHK(hipSetDevice(device));
+	int W = 2, H = 2, max_score = 0;
+	for (int i = 0; i < n; ++i) { W = std::max<int64_t>(W, ref_off[i + 1] - ref_off[i] + 2); H = std::max<int64_t>(H, qry_off[i + 1] - qry_off[i] + 1); }
+	for (int i = 0; i < 25; ++i) max_score = std::max(max_score, matrix25[i]);
+	std::vector<int32_t> o((size_t)n * 6), sub((size_t)n * H);
+	{
+		LocParams P; memset(&P, 0, sizeof(P));
+		const size_t waves = (size_t)((n + 255) / 256) * 4;
+		int64_t *d_ro = 0, *d_qo = 0; uint8_t *d_ref = 0, *d_qry = 0;
+		SCHK(hipMalloc(&d_ro, (size_t)(n + 1) * 8)); SCHK(hipMalloc(&d_qo, (size_t)(n + 1) * 8));
+		SCHK(hipMalloc(&d_ref, ref_off[n] + 16)); SCHK(hipMalloc(&d_qry, qry_off[n] + 16));
+		SCHK(hipMalloc(&P.eh, waves * (size_t)W * 64 * 4)); SCHK(hipMalloc(&P.suba, (size_t)n * H * 4)); SCHK(hipMalloc(&P.out, (size_t)n * 24));
+		SCHK(hipMemcpy(d_ro, ref_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		SCHK(hipMemcpy(d_qo, qry_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		if (ref_off[n]) SCHK(hipMemcpy(d_ref, ref, ref_off[n], hipMemcpyHostToDevice));
+		if (qry_off[n]) SCHK(hipMemcpy(d_qry, qry, qry_off[n], hipMemcpyHostToDevice));
+		P.n = n; P.ref_off = d_ro; P.qry_off = d_qo; P.ref = d_ref; P.qry = d_qry;
+		P.gap_open = gap_open; P.gap_ext = gap_ext; P.thres = thres; memcpy(P.matrix, matrix25, 100); P.max_score = max_score; P.W = W; P.H = H;
+		nabwa_launch_dp_local(&P, 0);
+		SCHK(hipGetLastError());
+		SCHK(hipMemcpy(o.data(), P.out, (size_t)n * 24, hipMemcpyDeviceToHost));
+		SCHK(hipMemcpy(sub.data(), P.suba, (size_t)n * H * 4, hipMemcpyDeviceToHost));
+		void *fr[] = { d_ro, d_qo, d_ref, d_qry, P.eh, P.suba, P.out };
+		for (void *p : fr) SCHK(hipFree(p));
+	}
+	std::vector<int> act;
+	for (int i = 0; i < n; ++i) {
+		const int32_t *v = &o[(size_t)i * 6];
+		const int l2 = (int)(qry_off[i + 1] - qry_off[i]);
+		score[i] = v[0]; n_cigar[i] = 0;
+		coords[4 * i] = v[2]; coords[4 * i + 1] = v[3]; coords[4 * i + 2] = v[4]; coords[4 * i + 3] = v[5];
+		if (subo) subo[i] = 0;
+		if (l2 == 0 || ref_off[i + 1] == ref_off[i]) { score[i] = -1; continue; }
+		if (v[0] < thres || v[4] == 0 || v[5] == 0) continue;
+		if (subo) {                                             /* stdaln.c:700-709 */
+			int tmp2 = 0, tmp = (int)(v[3] - .33 * (v[5] - v[3]) + .499);
+			const int32_t *sa = &sub[(size_t)i * H];
+			for (int j = 1; j <= tmp; ++j) if (tmp2 < sa[j]) tmp2 = sa[j];
+			tmp = (int)(v[5] + .33 * (v[5] - v[3]) + .499);
+			for (int j = tmp; j <= l2; ++j) if (tmp2 < sa[j]) tmp2 = sa[j];
+			subo[i] = tmp2;
+		}
+		act.push_back(i);
+	}
+	/* path: global alignment of the sub-matrix, gap_end = -1, doubling band (stdaln.c:723-735) */
+	for (int bw = band; !act.empty(); bw <<= 1) {
+		std::vector<int64_t> ro(act.size() + 1, 0), qo(act.size() + 1, 0); std::vector<uint8_t> rb, qb;
+		for (size_t t = 0; t < act.size(); ++t) {
+			const int i = act[t]; const int32_t *v = &o[(size_t)i * 6];
+			rb.insert(rb.end(), ref + ref_off[i] + v[2] - 1, ref + ref_off[i] + v[4]);
+			qb.insert(qb.end(), qry + qry_off[i] + v[3] - 1, qry + qry_off[i] + v[5]);
+			ro[t + 1] = (int64_t)rb.size(); qo[t + 1] = (int64_t)qb.size();
+		}
+		rb.push_back(0); qb.push_back(0);
+		std::vector<int32_t> sg(act.size()), nc(act.size()); std::vector<uint32_t> cg(act.size() * (size_t)max_cigar);
+		int r = nabwa_global_align(device, (int)act.size(), ro.data(), rb.data(), qo.data(), qb.data(), gap_open, gap_ext, -1,
+								   matrix25, bw, sg.data(), nc.data(), cg.data(), max_cigar);
+		if (r != NABWA_OK) return r;
+		std::vector<int> next;
+		for (size_t t = 0; t < act.size(); ++t) {
+			const int i = act[t]; const int32_t *v = &o[(size_t)i * 6];
+			const int jmax = std::max(v[4] - v[2], v[5] - v[3]) + 1;
+			if (sg[t] == v[1] || sg[t] == v[0] || bw > jmax) {
+				score[i] = (v[1] > sg[t] && v[0] > sg[t]) ? -1 : sg[t];     /* "potential bug" branch, stdaln.c:737-740 */
+				n_cigar[i] = nc[t];
+				memcpy(cigar32 + (size_t)i * max_cigar, cg.data() + t * (size_t)max_cigar, (size_t)std::min(nc[t], max_cigar) * 4);
+			} else next.push_back(i);
+		}
+		act.swap(next);
+	}
+	return NABWA_OK;
+}
+
 /* ------------------------------------------------------------------ reference annotations */
 
 extern "C" int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefix)

@@ -136,3 +136,24 @@ def test_extend_align_golden():
             assert score[j] == v["ext_score"][t], (pid, t)
             want = v["ext_cig"][v["ext_cig_off"][t]:v["ext_cig_off"][t + 1]]
             assert list(cigs[j]) == list(want), (pid, t)
+
+
+def test_local_align_golden():
+    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference"""
+    v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
+    n = len(v["pid"])
+    for pid in range(len(v["params"])):
+        go, ge, gend, band, smid = [int(x) for x in v["params"][pid]]
+        idx = [t for t in range(n) if v["pid"][t] == pid]
+        refs = [v["ref"][v["ref_off"][t]:v["ref_off"][t + 1]] for t in idx]
+        qrys = [v["qry"][v["qry_off"][t]:v["qry_off"][t + 1]] for t in idx]
+        ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+        qo = np.concatenate([[0], np.cumsum([len(q) for q in qrys])]).astype(np.int64)
+        score, coords, subo, cigs = nabwa.local_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, go, ge, SM[smid],
+                                                      band, 1, max_cigar=512)
+        for j, t in enumerate(idx):
+            assert score[j] == v["loc_score"][t], (pid, t)
+            want = v["loc_cig"][v["loc_cig_off"][t]:v["loc_cig_off"][t + 1]]
+            assert list(cigs[j]) == list(want), (pid, t)
+            if len(want):
+                assert subo[j] == v["loc_subo"][t], (pid, t)
