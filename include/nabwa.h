@@ -107,6 +107,40 @@ int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, i
 int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows);
 void nabwa_batch_destroy(nabwa_batch_t *b);
 
+/* ---- the reference's own record struct ------------------------------------------------------ */
+/* bwa_seq_t (bwtaln.h:64-90), 200 bytes; bit-fields kept as the words the compiler packs them into:
+ * bits0 = len:20 | strand:1 | type:2 | dummy:1 | extra_flag:8 ; bits1 = n_mm:8 | n_gapo:8 | n_gape:8 | mapQ:8 ;
+ * c1c2seq = c1:28 | c2:28 | seQ:8 ; lenbits = full_len:20 | nm:12 */
+typedef struct {
+	char *name;
+	uint8_t *seq, *rseq, *qual;
+	uint32_t bits0, bits1;
+	int32_t score, clip_len;
+	int32_t n_aln; int32_t pad0;
+	nabwa_aln1_t *aln;
+	int32_t n_multi; int32_t pad1;
+	void *multi;
+	uint32_t sa, pos;
+	uint64_t c1c2seq;
+	int32_t n_cigar; int32_t pad2;
+	uint16_t *cigar;
+	int32_t tid;
+	char bc[64];
+	uint32_t lenbits;
+	char *md;
+	int32_t max_entries; int32_t pad3;
+} nabwa_bwa_seq_t;
+
+/* Drop-in for bwa_cal_sa_reg_gap(bwt, n_seqs, seqs, opt) (bwtaln.h:187; callers bam2bam.c:616,676, bwtaln.c:235)
+ * on the reference's own records. */
+int nabwa_bwa_cal_sa_reg_gap(nabwa_index_t *ix, int n_seqs, nabwa_bwa_seq_t *seqs, const nabwa_gap_opt_t *opt);
+
+/* The encoding half of bam1_to_seq (bwaseqio.c:272-307) incl. seq_reverse (:91-108) and bwa_trim_read (:110-123):
+ * codes = bases of the BAM record (0-3, 4 = N), qual = phred values or NULL; returns the (trimmed) length and fills
+ * seq_out (read reversed) and rseq_out (its complement, i.e. the reverse complement of the read). */
+int nabwa_encode_read(int full_len, const uint8_t *codes, const uint8_t *qual, int reverse, int trim_qual, int is_comp,
+					  uint8_t *seq_out, uint8_t *rseq_out);
+
 /* Batch form of bwt_sa (bwt.c:72-81; callers bam2bam.c:635-636,752,761,786, bwase.c:146,151):
  * sa_out[i] = SA value of row k[i] in index `which[i]` (0 forward, 1 reversed text). */
 int nabwa_sa_lookup(nabwa_index_t *ix, int n, const uint8_t *which, const uint32_t *k, uint32_t *sa_out);

@@ -51,6 +51,26 @@ class SeRec(C.Structure):
                 ("flag", C.c_int32), ("seqid", C.c_int32), ("nn", C.c_int32), ("rpos", C.c_int64), ("xt", C.c_char)]
 
 
+class BwaSeq(C.Structure):
+    """bwa_seq_t (reference bwtaln.h:64-90), 200 bytes, as nabwa_bwa_seq_t declares it"""
+    _fields_ = [("name", C.c_void_p), ("seq", C.c_void_p), ("rseq", C.c_void_p), ("qual", C.c_void_p),
+                ("bits0", C.c_uint32), ("bits1", C.c_uint32), ("score", C.c_int32), ("clip_len", C.c_int32),
+                ("n_aln", C.c_int32), ("pad0", C.c_int32), ("aln", C.c_void_p), ("n_multi", C.c_int32), ("pad1", C.c_int32),
+                ("multi", C.c_void_p), ("sa", C.c_uint32), ("pos", C.c_uint32), ("c1c2seq", C.c_uint64),
+                ("n_cigar", C.c_int32), ("pad2", C.c_int32), ("cigar", C.c_void_p), ("tid", C.c_int32), ("bc", C.c_char * 64),
+                ("lenbits", C.c_uint32), ("md", C.c_void_p), ("max_entries", C.c_int32), ("pad3", C.c_int32)]
+
+
+def encode_read(codes, qual=None, reverse=False, trim_qual=0, is_comp=True):
+    """bam1_to_seq's encoding (reference bwaseqio.c:272-307): -> (seq, rseq) of the trimmed length"""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    q = np.ascontiguousarray(qual, np.uint8) if qual is not None else None
+    s = np.zeros(max(len(codes), 1), np.uint8)
+    r = np.zeros(max(len(codes), 1), np.uint8)
+    L = lib().nabwa_encode_read(len(codes), _ptr(codes), _ptr(q), int(reverse), int(trim_qual), int(is_comp), _ptr(s), _ptr(r))
+    return s[:L], r[:L]
+
+
 def srand48_state(seed):
     """state of the reference's process-global drand48 stream right after srand48(seed)"""
     return ((seed & 0xffffffff) << 16) | 0x330E
@@ -168,6 +188,9 @@ def lib():
     L.nabwa_local_align.argtypes = [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P,
                                     C.c_int]
     L.nabwa_index_attach_reference.argtypes = [_P, C.c_char_p]
+    L.nabwa_bwa_cal_sa_reg_gap.argtypes = [_P, C.c_int, _P, _P]
+    L.nabwa_encode_read.restype = C.c_int
+    L.nabwa_encode_read.argtypes = [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]
     L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
     _lib = L
     return L
@@ -225,6 +248,10 @@ class Index:
         s1, m1 = pn(sa1)
         _chk(lib().nabwa_index_from_arrays(device, int(device_ptrs), p0, n0, p1, n1, s0, m0, s1, m1, C.byref(h)))
         return cls(h)
+
+    def bwa_cal_sa_reg_gap(self, seqs, n_seqs, opt):
+        """drop-in for bwa_cal_sa_reg_gap on an array of the reference's bwa_seq_t records (BwaSeq * n)"""
+        _chk(lib().nabwa_bwa_cal_sa_reg_gap(self._h, n_seqs, seqs, C.byref(opt)))
 
     def attach_reference(self, prefix):
         """.ann/.amb/.pac of the index (reference bns_restore + bwt_restore_pac)"""

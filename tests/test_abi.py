@@ -58,3 +58,22 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(nabwa.NabwaError) as e:
         nabwa.Index.load(T.TOY)
     assert e.value.code == nabwa.ENODEV
+
+
+def test_encode_read_matches_reference_encoding():
+    """nabwa_encode_read == what bam1_to_seq / bwa_read_seq produce (checked against the test helper whose
+    output reproduces the reference's .sai files bit for bit, incl. -q trimming and the reverse-flag undo)"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    for trim in (0, 20):
+        seq, rseq, off, full = T.encode_reads(reads, trim)
+        for i in (0, 1, 7, 100, 590, 595, 600, 605):
+            name, s, q = reads[i]
+            codes = T.NT4[np.frombuffer(s.encode(), np.uint8)]
+            qual = np.frombuffer(q.encode(), np.uint8) - 33
+            a, b = nabwa.encode_read(codes, qual, False, trim)
+            assert np.array_equal(a, seq[off[i]:off[i + 1]]) and np.array_equal(b, rseq[off[i]:off[i + 1]]), name
+            # a record stored reverse-complemented with the reverse flag set decodes to the same read
+            rc = np.where(codes < 4, 3 - codes, codes)[::-1]
+            a2, b2 = nabwa.encode_read(rc, qual[::-1], True, trim)
+            assert np.array_equal(a2, a) and np.array_equal(b2, b), name
+    assert C.sizeof(nabwa.BwaSeq) == 200

@@ -223,3 +223,46 @@ def test_touch_counter_matches_oracle(gix, olib, oix):
     ts, tw = b.count_touches()
     assert ts + tw == ctr.n_bucket and ts > 0 and tw > 0
     b.close()
+
+
+def test_drop_in_on_reference_records(gix):
+    """bwa_cal_sa_reg_gap on the reference's own bwa_seq_t records: the same array goes through the
+    compiled reference (when oracle/_ref travelled) and through nabwa_bwa_cal_sa_reg_gap; every field the
+    reference's post-conditions name (bwtaln.c:82-91,113) must agree, rows byte for byte."""
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:300]
+    seq, rseq, off, _ = T.encode_reads(reads)
+    n = len(reads)
+
+    def make():
+        arr = (nabwa.BwaSeq * n)()
+        keep = []
+        for i in range(n):
+            s = np.ascontiguousarray(seq[off[i]:off[i + 1]]); r = np.ascontiguousarray(rseq[off[i]:off[i + 1]])
+            keep += [s, r]
+            L = len(s)
+            arr[i].seq = s.ctypes.data; arr[i].rseq = r.ctypes.data
+            arr[i].bits0 = L | (1 << 20) | (2 << 21)          # len, strand=1, type=REPEAT: must be reset
+            arr[i].lenbits = L; arr[i].clip_len = L
+            arr[i].sa = 12345; arr[i].c1c2seq = (7 << 56) | (5 << 28) | 9
+        return arr, keep
+
+    ours, k1 = make()
+    gix.bwa_cal_sa_reg_gap(ours, n, to_gap_opt(opt))
+    for i in range(n):
+        rows = np.frombuffer(C.string_at(ours[i].aln, 16 * ours[i].n_aln), T.ALN_DT) if ours[i].n_aln else np.zeros(0, T.ALN_DT)
+        assert rows.tobytes() == gold[i].tobytes(), reads[i][0]
+        assert ours[i].sa == 0 and (ours[i].bits0 >> 21 & 3) == 0 and ours[i].c1c2seq == (7 << 56)
+        assert (ours[i].bits0 & 0xfffff) == off[i + 1] - off[i] and (ours[i].bits0 >> 20 & 1) == 1
+    ref = T.load_ref()
+    if ref is not None:
+        ref.ref_index_load.restype = C.c_void_p
+        rix = ref.ref_index_load(T.TOY.encode(), 0)
+        theirs, k2 = make()
+        ref.bwa_cal_sa_reg_gap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        ref.bwa_cal_sa_reg_gap(C.c_void_p(rix), n, theirs, C.byref(opt))   # ref_index_t starts with bwt_t *bwt[2]
+        for i in range(n):
+            assert ours[i].n_aln == theirs[i].n_aln and ours[i].max_entries == theirs[i].max_entries, reads[i][0]
+            assert ours[i].bits0 == theirs[i].bits0 and ours[i].sa == theirs[i].sa and ours[i].c1c2seq == theirs[i].c1c2seq
+            if ours[i].n_aln:
+                assert C.string_at(ours[i].aln, 16 * ours[i].n_aln) == C.string_at(theirs[i].aln, 16 * theirs[i].n_aln)
