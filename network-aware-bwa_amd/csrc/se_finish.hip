@@ -12,9 +12,12 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
 
@@ -401,6 +404,9 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 	if (n_occ < 0 || n_occ + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
 	const nabwa_reference *R = ix->ref;
 	const uint32_t rlen = ix->bwt[1].seq_len;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t0 = now(), t1, t2, t3;
 
 	/* ---- phase 1, host, record order: hit choice with the caller's RNG stream (bwase.c:19-95) */
 	std::vector<uint8_t> which; std::vector<uint32_t> rows;           /* SA lookups: [main of each mapped read][multi...] */
@@ -408,7 +414,9 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 	size_t a0 = 0;
 	for (int i = 0; i < n; ++i) {
 		nabwa_se_t &s = out[i];
-		memset(&s, 0, sizeof(s));
+		memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
+		s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
+		for (int z = 0; z < NABWA_MAX_MULTI; ++z) s.multi[z].n_cigar = 0;
 		const int len = (int)(off[i + 1] - off[i]);
 		s.len = len; s.clip_len = len; s.full_len = full_len ? full_len[i] : len;
 		const nabwa_aln1_t *A = aln + a0; const int na = n_aln[i];
@@ -451,6 +459,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		}
 	}
 
+	t1 = now();
 	/* ---- phase 2, GPU: all bwt_sa walks of the batch (bwt.c:72-81) */
 	std::vector<uint32_t> sa(rows.size());
 	if (!rows.empty()) {
@@ -473,6 +482,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		s.mapQ = s.seQ = q;
 	}
 
+	t2 = now();
 	/* ---- phase 3, GPU: gap refinement of every gapped hit as one batch of global alignments (bwase.c:189-237) */
 	std::vector<RefineJob> jobs;
 	for (int i = 0; i < n; ++i) {
@@ -526,41 +536,54 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		}
 	}
 
-	/* ---- phase 4, host: MD / NM, trimmed tail, flags (bwase.c:253-354, :458-571) */
-	std::vector<uint8_t> fwd;
-	for (int i = 0; i < n; ++i) {
-		nabwa_se_t &s = out[i];
-		if (s.type == 0) { s.flag = 4; continue; }
-		const int len = s.len;
-		const uint8_t *q;
-		if (s.strand) q = rseq + off[i];
-		else { fwd.resize(len); for (int k = 0; k < len; ++k) fwd[k] = seq[off[i] + len - 1 - k]; q = fwd.data(); }
-		make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
-		if (len != s.full_len) {                                   /* bwa_correct_trimmed */
-			const int clip = s.full_len - len;
-			if (s.strand == 0) {
-				if (s.n_cigar && COP(s.cigar[s.n_cigar - 1]) == 3) s.cigar[s.n_cigar - 1] += clip;
-				else { if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[0] = CMAKE(0, len); } else ++s.n_cigar; s.cigar[s.n_cigar - 1] = CMAKE(3, clip); }
-			} else {
-				if (s.n_cigar && COP(s.cigar[0]) == 3) s.cigar[0] += clip;
-				else {
-					if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[1] = CMAKE(0, len); }
-					else { ++s.n_cigar; memmove(s.cigar + 1, s.cigar, (s.n_cigar - 1) * 2); }
-					s.cigar[0] = CMAKE(3, clip);
+	t3 = now();
+	/* ---- phase 4, host threads: MD / NM, trimmed tail, flags (bwase.c:253-354, :458-571); records are independent */
+	auto phase4 = [&](int lo, int hi) {
+		std::vector<uint8_t> fwd;
+		for (int i = lo; i < hi; ++i) {
+			nabwa_se_t &s = out[i];
+			if (s.type == 0) { s.flag = 4; continue; }
+			const int len = s.len;
+			const uint8_t *q;
+			if (s.strand) q = rseq + off[i];
+			else { fwd.resize(len); for (int k = 0; k < len; ++k) fwd[k] = seq[off[i] + len - 1 - k]; q = fwd.data(); }
+			make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
+			if (len != s.full_len) {                                   /* bwa_correct_trimmed */
+				const int clip = s.full_len - len;
+				if (s.strand == 0) {
+					if (s.n_cigar && COP(s.cigar[s.n_cigar - 1]) == 3) s.cigar[s.n_cigar - 1] += clip;
+					else { if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[0] = CMAKE(0, len); } else ++s.n_cigar; s.cigar[s.n_cigar - 1] = CMAKE(3, clip); }
+				} else {
+					if (s.n_cigar && COP(s.cigar[0]) == 3) s.cigar[0] += clip;
+					else {
+						if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[1] = CMAKE(0, len); }
+						else { ++s.n_cigar; memmove(s.cigar + 1, s.cigar, (s.n_cigar - 1) * 2); }
+						s.cigar[0] = CMAKE(3, clip);
+					}
 				}
+				s.len = s.full_len;
 			}
-			s.len = s.full_len;
+			int64_t end = s.pos;
+			if (s.n_cigar) { for (int k = 0; k < s.n_cigar; ++k) { const int op = COP(s.cigar[k]); if (op == 0 || op == 2) end += CLEN(s.cigar[k]); } }
+			else end += s.len;
+			const int reflen = (int)(end - s.pos);
+			s.nn = pac2real(R, s.pos, reflen, &s.seqid);
+			s.flag = 0;
+			if ((int64_t)s.pos + reflen - R->anns[s.seqid].offset > R->anns[s.seqid].len) { s.flag |= 4; s.mapQ = 0; }   /* bridges two contigs */
+			if (s.strand) s.flag |= 16;
+			s.rpos = (int64_t)s.pos - R->anns[s.seqid].offset + 1;
+			s.xt = s.nn > 10 ? 'N' : "NURM"[s.type];
 		}
-		int64_t end = s.pos;
-		if (s.n_cigar) { for (int k = 0; k < s.n_cigar; ++k) { const int op = COP(s.cigar[k]); if (op == 0 || op == 2) end += CLEN(s.cigar[k]); } }
-		else end += s.len;
-		const int reflen = (int)(end - s.pos);
-		s.nn = pac2real(R, s.pos, reflen, &s.seqid);
-		s.flag = 0;
-		if ((int64_t)s.pos + reflen - R->anns[s.seqid].offset > R->anns[s.seqid].len) { s.flag |= 4; s.mapQ = 0; }   /* bridges two contigs */
-		if (s.strand) s.flag |= 16;
-		s.rpos = (int64_t)s.pos - R->anns[s.seqid].offset + 1;
-		s.xt = s.nn > 10 ? 'N' : "NURM"[s.type];
+	};
+	{
+		int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+		if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
+		if (n < 4096) nt = 1;
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back(phase4, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+		for (auto &x : th) x.join();
 	}
+	if (timing) fprintf(stderr, "[nabwa] se_finish %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) %.3f s, refinement (%zu jobs) %.3f s, md/flags %.3f s\n",
+						n, t1 - t0, rows.size(), t2 - t1, jobs.size(), t3 - t2, now() - t3);
 	return NABWA_OK;
 }
