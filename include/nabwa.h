@@ -107,6 +107,21 @@ int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, i
 int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows);
 void nabwa_batch_destroy(nabwa_batch_t *b);
 
+/* ---- paired-end host pieces (config 3) --------------------------------------------------------- */
+/* isize_info_t without the histogram pointer (bwape.h:16-20) */
+typedef struct { double avg, std, ap_prior; uint32_t low, high, high_bayesian; } nabwa_isize_t;
+/* infer_isize_hist (insert_size.c:50-139) on a histogram of 100000 u16 bins; 0 = usable, -1 = not (fields as the
+ * reference leaves them: avg = std = -1, bounds 0) */
+int nabwa_isize_infer(const uint16_t *hist, double ap_prior, int64_t L, nabwa_isize_t *out);
+/* improve_isize_est (insert_size.c:141-165): the bin a record adds one to, or -1 */
+int nabwa_isize_bin(int kind, int mapq0, int mapq1, uint32_t pos0, int len0, uint32_t pos1, int len1);
+/* the bwa_seq_t fields pairing() reads and writes (bwape.c:180-293) */
+typedef struct { uint32_t pos; int32_t strand, mapQ, seQ, len, full_len, n_mm, n_gapo, n_gape, score, extra_flag; } nabwa_pe_end_t;
+/* pairing (bwape.c:180-293; caller finish_pair, bam2bam.c:768): hits[i] = text position << 32 | hit row << 1 | end
+ * for every position of every hit row of both ends (sorted in place); returns the number of moved ends with mapQ > 0 */
+int nabwa_pairing(nabwa_pe_end_t p[2], int n_hits, uint64_t *hits, const nabwa_aln1_t *rows0, const nabwa_aln1_t *rows1,
+				  int max_isize, int s_mm, const nabwa_isize_t *ii);
+
 /* ---- the reference's own record struct ------------------------------------------------------ */
 /* bwa_seq_t (bwtaln.h:64-90), 200 bytes; bit-fields kept as the words the compiler packs them into:
  * bits0 = len:20 | strand:1 | type:2 | dummy:1 | extra_flag:8 ; bits1 = n_mm:8 | n_gapo:8 | n_gape:8 | mapQ:8 ;

@@ -51,6 +51,35 @@ class SeRec(C.Structure):
                 ("flag", C.c_int32), ("seqid", C.c_int32), ("nn", C.c_int32), ("rpos", C.c_int64), ("xt", C.c_char)]
 
 
+class IsizeInfo(C.Structure):
+    """nabwa_isize_t = isize_info_t without the histogram pointer (reference bwape.h:16-20)"""
+    _fields_ = [("avg", C.c_double), ("std", C.c_double), ("ap_prior", C.c_double), ("low", C.c_uint32),
+                ("high", C.c_uint32), ("high_bayesian", C.c_uint32)]
+
+
+class PeEnd(C.Structure):
+    """nabwa_pe_end_t: the bwa_seq_t fields pairing() touches"""
+    _fields_ = [("pos", C.c_uint32), ("strand", C.c_int32), ("mapQ", C.c_int32), ("seQ", C.c_int32), ("len", C.c_int32),
+                ("full_len", C.c_int32), ("n_mm", C.c_int32), ("n_gapo", C.c_int32), ("n_gape", C.c_int32),
+                ("score", C.c_int32), ("extra_flag", C.c_int32)]
+
+
+def isize_infer(hist, ap_prior, L):
+    """infer_isize_hist (reference insert_size.c:50-139) -> (rc, IsizeInfo)"""
+    h = np.ascontiguousarray(hist, np.uint16)
+    ii = IsizeInfo()
+    rc = lib().nabwa_isize_infer(_ptr(h), float(ap_prior), int(L), C.byref(ii))
+    return rc, ii
+
+
+def pairing(ends, hits, rows0, rows1, max_isize, s_mm, ii):
+    """pairing (reference bwape.c:180-293); ends: (PeEnd * 2), modified in place; returns cnt_chg"""
+    hits = np.ascontiguousarray(hits, np.uint64)
+    r0 = np.ascontiguousarray(rows0, ALN_DT)
+    r1 = np.ascontiguousarray(rows1, ALN_DT)
+    return lib().nabwa_pairing(ends, len(hits), _ptr(hits), _ptr(r0), _ptr(r1), int(max_isize), int(s_mm), C.byref(ii))
+
+
 class BwaSeq(C.Structure):
     """bwa_seq_t (reference bwtaln.h:64-90), 200 bytes, as nabwa_bwa_seq_t declares it"""
     _fields_ = [("name", C.c_void_p), ("seq", C.c_void_p), ("rseq", C.c_void_p), ("qual", C.c_void_p),
@@ -189,6 +218,9 @@ def lib():
                                     C.c_int]
     L.nabwa_index_attach_reference.argtypes = [_P, C.c_char_p]
     L.nabwa_bwa_cal_sa_reg_gap.argtypes = [_P, C.c_int, _P, _P]
+    L.nabwa_isize_infer.argtypes = [_P, C.c_double, C.c_int64, _P]
+    L.nabwa_isize_bin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int]
+    L.nabwa_pairing.argtypes = [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]
     L.nabwa_encode_read.restype = C.c_int
     L.nabwa_encode_read.argtypes = [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]
     L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]

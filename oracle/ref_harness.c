@@ -270,3 +270,59 @@ long ref_cal_sa_reg_gap_mt(ref_index_t *ix, const gap_opt_t *opt, int n, const i
 	free(rows); free(jobs); free(tid);
 	return tot;
 }
+
+/* ------------------------------------------------------------------ paired-end pieces (bwape.c, insert_size.c) */
+#include "bwape.h"
+
+/* infer_isize_hist (insert_size.c:50-139; static) reached through infer_all_isizes (:167-173) on a table
+ * with one read group.  hist: 100000 counts (the function frees it, so a copy is handed over).
+ * out: avg, std, ap_prior, low, high, high_bayesian */
+void ref_infer_isize(const uint16_t *hist, double ap_prior, int64_t L, double *out)
+{
+	khash_t(isize_infos) *h = kh_init(isize_infos);
+	int ret; khiter_t it = kh_put(isize_infos, h, strdup("rg"), &ret);
+	isize_info_t *ii = &kh_value(h, it);
+	memset(ii, 0, sizeof(*ii));
+	ii->hist = (unsigned short*)malloc(100000 * 2);
+	memcpy(ii->hist, hist, 100000 * 2);
+	infer_all_isizes(h, ap_prior, L);
+	ii = &kh_value(h, it);
+	out[0] = ii->avg; out[1] = ii->std; out[2] = ii->ap_prior; out[3] = ii->low; out[4] = ii->high; out[5] = ii->high_bayesian;
+	free((char*)kh_key(h, it));
+	kh_destroy(isize_infos, h);
+}
+
+/* pairing (bwape.c:180-293).  Per end e: n_aln[e] rows aln (4 x u32 each, bwt_aln1_t), and for every row its
+ * text positions (flattened in hit_pos with hit_row giving the row index), as finish_pair builds d.arr
+ * (bam2bam.c:737-767).  p_in per end: pos, strand, mapQ, seQ, len, full_len, n_mm, n_gapo, n_gape, score, extra_flag.
+ * ii: avg, std, ap_prior, low, high, high_bayesian.  Returns cnt_chg; p_out same layout as p_in. */
+int ref_pairing(const int *n_aln, const uint32_t *aln0, const uint32_t *aln1,
+				int n_hit, const uint32_t *hit_pos, const int32_t *hit_row, const int32_t *hit_end,
+				const int64_t *p_in, int max_isize, int pet_type, int s_mm, const double *iiv, int64_t *p_out)
+{
+	bwa_seq_t s[2], *p[2] = { &s[0], &s[1] };
+	pe_data_t d; pe_opt_t *po = bwa_init_pe_opt(); isize_info_t ii; int e, i, r;
+	bwase_initialize();
+	memset(&d, 0, sizeof(d)); memset(s, 0, sizeof(s)); memset(&ii, 0, sizeof(ii));
+	d.aln[0].a = (bwt_aln1_t*)aln0; d.aln[0].n = n_aln[0];
+	d.aln[1].a = (bwt_aln1_t*)aln1; d.aln[1].n = n_aln[1];
+	for (i = 0; i < n_hit; ++i) {
+		uint64_t x = (uint64_t)hit_pos[i] << 32 | hit_row[i] << 1 | hit_end[i];
+		kv_push(uint64_t, d.arr, x);
+	}
+	for (e = 0; e < 2; ++e) {
+		const int64_t *q = p_in + 11 * e;
+		s[e].pos = q[0]; s[e].strand = q[1]; s[e].mapQ = q[2]; s[e].seQ = q[3]; s[e].len = q[4]; s[e].full_len = q[5];
+		s[e].n_mm = q[6]; s[e].n_gapo = q[7]; s[e].n_gape = q[8]; s[e].score = q[9]; s[e].extra_flag = q[10];
+	}
+	po->max_isize = max_isize; po->type = pet_type;
+	ii.avg = iiv[0]; ii.std = iiv[1]; ii.ap_prior = iiv[2]; ii.low = iiv[3]; ii.high = iiv[4]; ii.high_bayesian = iiv[5];
+	r = pairing(p, &d, po, s_mm, &ii);
+	for (e = 0; e < 2; ++e) {
+		int64_t *q = p_out + 11 * e;
+		q[0] = s[e].pos; q[1] = s[e].strand; q[2] = s[e].mapQ; q[3] = s[e].seQ; q[4] = s[e].len; q[5] = s[e].full_len;
+		q[6] = s[e].n_mm; q[7] = s[e].n_gapo; q[8] = s[e].n_gape; q[9] = s[e].score; q[10] = s[e].extra_flag;
+	}
+	kv_destroy(d.arr); free(po);
+	return r;
+}

@@ -324,6 +324,7 @@ def main():
     out["dp_params"] = np.array([[p[0], p[1], p[2], p[4], 0 if p[3] is sm_maq else 1] for p in params], np.int32)
     np.savez_compressed(os.path.join(HERE, "vectors.npz"), **out)
     make_sw_vectors(lib, sm_maq, sm_blast)
+    make_pe_vectors(lib)
     print("golden fixtures written to", HERE, "reads:", len(reads))
 
 
@@ -383,6 +384,89 @@ def make_sw_vectors(lib, sm_maq, sm_blast):
                         loc_score=np.array(l_score, np.int32), loc_cig=cat(l_cig, np.uint32), loc_cig_off=offs(l_cig),
                         loc_subo=np.array(l_subo, np.int32))
 
+
+
+
+def make_pe_vectors(lib):
+    """insert-size inference (insert_size.c) and pairing (bwape.c:180-293) known answers -> vectors_pe.npz"""
+    rng = np.random.default_rng(777)
+    out = {}
+    # ---- insert-size histograms: normal, skewed, bimodal, too few, saturated bin
+    hists, res = [], []
+    for t in range(24):
+        h = np.zeros(100000, np.int64)
+        kind = t % 6
+        n = int(rng.integers(30, 60000)) if kind != 3 else int(rng.integers(0, 19))
+        if kind in (0, 3, 5):
+            x = rng.normal(rng.integers(150, 600), rng.integers(10, 80), n)
+        elif kind == 1:
+            x = rng.gamma(4.0, rng.integers(30, 90), n)
+        elif kind == 2:
+            x = np.concatenate([rng.normal(250, 20, n // 2), rng.normal(3000, 300, n - n // 2)])
+        else:
+            x = rng.normal(400, 40, n)
+            x[: max(1, n // 50)] = rng.uniform(0, 99999, max(1, n // 50))
+        x = np.clip(np.round(x), 0, 99999).astype(np.int64)
+        np.add.at(h, x, 1)
+        if kind == 5:
+            h[int(np.argmax(h))] = 65535
+        h = np.minimum(h, 65535).astype(np.uint16)
+        o = np.zeros(6, np.float64)
+        L = int(rng.choice([4641652, 3099734149, 103000]))
+        ap = float(rng.choice([1e-5, 1e-3]))
+        lib.ref_infer_isize(h.ctypes.data_as(C.c_void_p), C.c_double(ap), C.c_int64(L), o.ctypes.data_as(C.c_void_p))
+        hists.append(np.concatenate([[L], np.nonzero(h)[0], [-1], h[np.nonzero(h)[0]]]).astype(np.int64))
+        res.append(np.concatenate([[ap], o]))
+    out["is_hist"] = np.concatenate(hists)
+    out["is_hist_off"] = np.cumsum([0] + [len(x) for x in hists]).astype(np.int64)
+    out["is_res"] = np.array(res, np.float64)
+    # ---- pairing cases
+    lib.ref_pairing.restype = C.c_int
+    pin, pout, cnts, alns, aoff, hits, hoff, misc = [], [], [], [], [0], [], [0], []
+    for t in range(400):
+        na = [int(rng.integers(1, 5)), int(rng.integers(1, 5))]
+        base = int(rng.integers(2000, 90000))
+        rows = [[], []]
+        hp, hr, he = [], [], []
+        for e in range(2):
+            for r in range(na[e]):
+                a = int(rng.integers(0, 2)); nmm = int(rng.integers(0, 4)); go = int(rng.integers(0, 2)); ge = int(rng.integers(0, 3)) if go else 0
+                score = 3 * nmm + 11 * go + 4 * ge
+                k = int(rng.integers(1, 100000)); w = int(rng.choice([1, 1, 1, 2, 3]))
+                rows[e].append([nmm | go << 8 | ge << 16 | a << 24, k, k + w - 1, score])
+                for _ in range(w):
+                    far = rng.random() < 0.3
+                    pos = int(rng.integers(0, 100000)) if far else base + int(rng.integers(-700, 700))
+                    hp.append(max(pos, 0)); hr.append(r); he.append(e)
+        ii = np.array([0, 0, 1e-5, 0, 0, 0], np.float64)
+        if t % 3:
+            avg = float(rng.integers(200, 500)); sd = float(rng.integers(10, 60))
+            ii = np.array([avg, sd, 1e-5, max(1, avg - 4 * sd), avg + 4 * sd, avg + float(rng.integers(3, 7)) * sd], np.float64)
+        p_in = np.zeros(22, np.int64)
+        for e in range(2):
+            j = int(rng.integers(0, len([1 for x in he if x == e])))
+            idx = [i for i, x in enumerate(he) if x == e][j]
+            r = rows[e][hr[idx]]
+            ln = int(rng.choice([100, 100, 76, 150]))
+            p_in[11 * e: 11 * e + 11] = [hp[idx] if rng.random() < 0.8 else hp[idx] + 3, r[0] >> 24 & 1, int(rng.choice([0, 0, 10, 23, 25, 37])),
+                                          int(rng.choice([0, 23, 37])), ln, ln, r[0] & 0xff, r[0] >> 8 & 0xff, r[0] >> 16 & 0xff, r[3], 1 | (64 if e == 0 else 128)]
+        a0 = np.array(rows[0], np.uint32).reshape(-1); a1 = np.array(rows[1], np.uint32).reshape(-1)
+        hp_ = np.array(hp, np.uint32); hr_ = np.array(hr, np.int32); he_ = np.array(he, np.int32)
+        p_out = np.zeros(22, np.int64)
+        nn = np.array(na, np.int32)
+        max_isize = int(rng.choice([500, 1000]))
+        cnt = lib.ref_pairing(nn.ctypes.data_as(C.c_void_p), a0.ctypes.data_as(C.c_void_p), a1.ctypes.data_as(C.c_void_p),
+                              len(hp), hp_.ctypes.data_as(C.c_void_p), hr_.ctypes.data_as(C.c_void_p), he_.ctypes.data_as(C.c_void_p),
+                              p_in.ctypes.data_as(C.c_void_p), max_isize, 1, 3, ii.ctypes.data_as(C.c_void_p),
+                              p_out.ctypes.data_as(C.c_void_p))
+        pin.append(p_in); pout.append(p_out); cnts.append(cnt)
+        alns.append(np.concatenate([a0, a1])); aoff.append(aoff[-1] + len(a0) + len(a1))
+        hits.append(np.stack([hp_.astype(np.int64), hr_, he_], 1).reshape(-1)); hoff.append(hoff[-1] + 3 * len(hp))
+        misc.append(np.concatenate([[na[0], na[1], max_isize], ii]))
+    out.update(pr_in=np.array(pin), pr_out=np.array(pout), pr_cnt=np.array(cnts, np.int32), pr_aln=np.concatenate(alns),
+               pr_aln_off=np.array(aoff, np.int64), pr_hit=np.concatenate(hits), pr_hit_off=np.array(hoff, np.int64),
+               pr_misc=np.array(misc, np.float64))
+    np.savez_compressed(os.path.join(HERE, "vectors_pe.npz"), **out)
 
 if __name__ == "__main__":
     main()
