@@ -215,6 +215,38 @@ int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const 
 					const uint8_t *rseq, const int32_t *full_len, const int32_t *n_aln, const nabwa_aln1_t *aln,
 					int n_occ, uint64_t *rng48, nabwa_se_t *out);
 
+/* ---- paired-end chain (config 3) ------------------------------------------------------------ */
+/* pe_opt_t (bwtaln.h:158-164), same layout; defaults as bwa_init_pe_opt (bwape.c:27-41) */
+typedef struct {
+	int32_t max_isize, force_isize, max_occ, max_occ_se, n_multi, N_multi, type, is_sw, is_preload;
+	double ap_prior;
+} nabwa_pe_opt_t;
+void nabwa_pe_opt_default(nabwa_pe_opt_t *po);
+
+/* one end of a pair: the single-end record plus what bwa_update_bam1 derives from the mate (bam2bam.c:430-525).
+ * se.flag is the final SAM flag; extra_flag is bwa_seq_t.extra_flag (paired / read1 / read2 / proper pair). */
+typedef struct {
+	nabwa_se_t se;
+	int32_t extra_flag, m_seqid, am, pad;
+	int64_t m_rpos, isize;                                 /* mate position (1-based, on contig m_seqid), template length */
+} nabwa_pe_t;
+
+/* posn_pair (bam2bam.c:683-703) for n_pairs pairs: bwa_aln2seq + bwa_cal_pac_pos_core per end, IN RECORD ORDER
+ * (pair 0 end 0, pair 0 end 1, pair 1 end 0, ...) on the caller's drand48 stream.  Reads, hit rows and records
+ * are interleaved: index 2*pair + end.  Afterwards the caller bins insert sizes (nabwa_isize_bin on pos / len /
+ * mapQ of the two ends) and, once all batches are in, calls nabwa_isize_infer -- the barrier of bam2bam. */
+int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, const int64_t *off, const int32_t *full_len,
+				  const int32_t *n_aln, const nabwa_aln1_t *aln, uint64_t *rng48, nabwa_pe_t *out);
+
+/* finish_pair (bam2bam.c:705-811) for the same pairs: hit enumeration (bwt_sa, GPU batch) + pairing (bwape.c:180-293),
+ * multi-hit lists, mate rescue (bwa_paired_sw1 / bwa_sw_core, bwape.c:433-633; local alignments as one GPU batch),
+ * bwa_refine_gapped on both ends (global alignments as one GPU batch), MD / NM, flags and mate fields.
+ * ii: the read group's insert-size estimate; all zeros = none (null_ii, bam2bam.c:715).
+ * n_tot / n_mapped (may be NULL): the counters of bwa_paired_sw1, [0] discordant pairs, [1] singletons. */
+int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+					int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
+					const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2]);
+
 /* Rank primitives for tests: Occ of all four bases at rows k[i] (bwt_occ4, bwt.c:159-176). */
 int nabwa_occ4(nabwa_index_t *ix, int which, int n, const uint32_t *k, uint32_t *cnt_out /* n x 4 */);
 

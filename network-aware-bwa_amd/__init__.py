@@ -64,6 +64,26 @@ class PeEnd(C.Structure):
                 ("score", C.c_int32), ("extra_flag", C.c_int32)]
 
 
+class PeOpt(C.Structure):
+    """nabwa_pe_opt_t = pe_opt_t (reference bwtaln.h:158-164)"""
+    _fields_ = [("max_isize", C.c_int32), ("force_isize", C.c_int32), ("max_occ", C.c_int32), ("max_occ_se", C.c_int32),
+                ("n_multi", C.c_int32), ("N_multi", C.c_int32), ("type", C.c_int32), ("is_sw", C.c_int32),
+                ("is_preload", C.c_int32), ("ap_prior", C.c_double)]
+
+
+class PeRec(C.Structure):
+    """nabwa_pe_t: one end of a finished pair"""
+    _fields_ = [("se", SeRec), ("extra_flag", C.c_int32), ("m_seqid", C.c_int32), ("am", C.c_int32), ("pad", C.c_int32),
+                ("m_rpos", C.c_int64), ("isize", C.c_int64)]
+
+
+def pe_opt_default():
+    """bwa_init_pe_opt (reference bwape.c:27-41)"""
+    po = PeOpt()
+    lib().nabwa_pe_opt_default(C.byref(po))
+    return po
+
+
 def isize_infer(hist, ap_prior, L):
     """infer_isize_hist (reference insert_size.c:50-139) -> (rc, IsizeInfo)"""
     h = np.ascontiguousarray(hist, np.uint16)
@@ -224,6 +244,10 @@ def lib():
     L.nabwa_encode_read.restype = C.c_int
     L.nabwa_encode_read.argtypes = [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]
     L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
+    L.nabwa_pe_opt_default.argtypes = [_P]
+    L.nabwa_pe_opt_default.restype = None
+    L.nabwa_pe_posn.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]
+    L.nabwa_pe_finish.argtypes = [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]
     _lib = L
     return L
 
@@ -303,6 +327,33 @@ class Index:
                                    _ptr(np.ascontiguousarray(seq, np.uint8)), _ptr(np.ascontiguousarray(rseq, np.uint8)),
                                    _ptr(fl), _ptr(n_aln), _ptr(rows), n_occ, C.byref(st), out))
         return out, st.value
+
+    def pe_posn(self, opt, off, full_len, hits, rng_state):
+        """posn_pair (reference bam2bam.c:683-703) for interleaved ends (index 2*pair + end), in record order.
+        Returns (array of PeRec, new rng state)."""
+        n = len(off) - 1
+        assert n % 2 == 0
+        n_aln = np.array([len(h) for h in hits], np.int32)
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(h, ALN_DT) for h in hits] + [np.zeros(0, ALN_DT)]))
+        out = (PeRec * max(n, 1))()
+        st = C.c_uint64(rng_state)
+        fl = np.ascontiguousarray(full_len, np.int32)
+        _chk(lib().nabwa_pe_posn(self._h, C.byref(opt), n // 2, _ptr(np.ascontiguousarray(off, np.int64)), _ptr(fl), _ptr(n_aln),
+                                 _ptr(rows), C.byref(st), out))
+        return out, st.value
+
+    def pe_finish(self, opt, popt, ii, seq, rseq, off, hits, recs):
+        """finish_pair (reference bam2bam.c:705-811) on the records pe_posn returned (updated in place).
+        Returns (n_tot, n_mapped) of the mate rescue."""
+        n = len(off) - 1
+        n_aln = np.array([len(h) for h in hits], np.int32)
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(h, ALN_DT) for h in hits] + [np.zeros(0, ALN_DT)]))
+        tot = (C.c_uint64 * 2)()
+        mp = (C.c_uint64 * 2)()
+        _chk(lib().nabwa_pe_finish(self._h, C.byref(opt), C.byref(popt), C.byref(ii), n // 2, _ptr(np.ascontiguousarray(off, np.int64)),
+                                   _ptr(np.ascontiguousarray(seq, np.uint8)), _ptr(np.ascontiguousarray(rseq, np.uint8)),
+                                   _ptr(n_aln), _ptr(rows), recs, tot, mp))
+        return list(tot), list(mp)
 
     def seq_len(self, which=0):
         return lib().nabwa_index_seq_len(self._h, which)

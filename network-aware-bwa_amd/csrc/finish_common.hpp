@@ -1,0 +1,257 @@
+// finish_common.hpp -- host pieces shared by the single-end and paired-end finishing chains.
+// Records are nabwa_se_t laid out with a caller-given stride (nabwa_pe_t starts with a nabwa_se_t).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "../../include/nabwa.h"
+#include "nabwa_internal.hpp"
+
+/* ------------------------------------------------------------------ small host pieces */
+
+static inline double rng48_next(uint64_t *x)          /* drand48: X' = 0x5DEECE66D X + 0xB mod 2^48, result X'/2^48 */
+{
+	*x = (*x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
+	return (double)*x * (1.0 / 281474976710656.0);
+}
+
+static inline int pac_at(const nabwa_reference *R, int64_t k) { return R->pac[k >> 2] >> ((~k & 3) << 1) & 3; }
+
+/* base of the reference at pos with the ambiguity codes of the .amb holes restored (bwase.c:239-251) */
+static inline int ref_char(const nabwa_reference *R, int64_t pos)
+{
+	size_t lo = 0, hi = R->holes.size();
+	while (lo < hi) {
+		size_t mid = (lo + hi) / 2;
+		if (pos >= R->holes[mid].offset + R->holes[mid].len) lo = mid + 1;
+		else if (pos < R->holes[mid].offset) hi = mid;
+		else return R->holes[mid].amb;
+	}
+	return pac_at(R, pos);
+}
+
+/* bns_coor_pac2real (bntseq.c:272-306): contig of a position and the number of ambiguous bases under [pos, pos+len) */
+static inline int pac2real(const nabwa_reference *R, int64_t pos, int len, int *seqid)
+{
+	int left = 0, mid = 0, right = (int)R->anns.size(), nn = 0;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos >= R->anns[mid].offset) {
+			if (mid == (int)R->anns.size() - 1) break;
+			if (pos < R->anns[mid + 1].offset) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	*seqid = mid;
+	left = 0; right = (int)R->holes.size();
+	while (left < right) {
+		const int m = (left + right) >> 1; const nabwa_hole &h = R->holes[m];
+		if (pos >= h.offset + h.len) left = m + 1;
+		else if (pos + len <= h.offset) right = m;
+		else {
+			if (pos >= h.offset) nn += h.offset + h.len < pos + len ? (int)(h.offset + h.len - pos) : len;
+			else nn += h.offset + h.len < pos + len ? h.len : len - (int)(h.offset - pos);
+			break;
+		}
+	}
+	return nn;
+}
+
+#define COP(c) ((c) >> 14)
+#define CLEN(c) ((c) & 0x3fff)
+#define CMAKE(op, len) ((uint16_t)((op) << 14 | (len)))
+
+/* one gap-refinement job: which record, main hit (-1) or multi index, query orientation, window */
+struct RefineJob { int rec, multi, strand, ext, len; int64_t pos; int64_t win_lo; int win_n; };
+
+/* MD string and NM of an alignment (bwa_cal_md1, bwase.c:253-315) */
+static inline void make_md(const nabwa_reference *R, int n_cigar, const uint16_t *cigar, int len, uint32_t pos0, const uint8_t *q,
+					char *md, int cap, int *nm_out)
+{
+	int64_t pos = pos0; int u = 0, nm = 0, y = 0; std::string s; char num[16];
+	auto flush_num = [&]() { snprintf(num, sizeof num, "%d", u); s += num; };
+	auto base_chr = [](int c) -> char { return c > 3 ? (char)c : "ACGT"[c]; };
+	if (n_cigar) {
+		for (int k = 0; k < n_cigar; ++k) {
+			const int l = CLEN(cigar[k]), op = COP(cigar[k]);
+			if (op == 0) {
+				for (int z = 0; z < l && pos < R->l_pac; ++z, ++y, ++pos) {
+					const int c = ref_char(R, pos);
+					if (c > 3 || q[y] > 3 || c != q[y]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
+				}
+			} else if (op == 1 || op == 3) { y += l; if (op == 1) nm += l; }
+			else {
+				flush_num(); s += '^';
+				for (int z = 0; z < l && pos < R->l_pac; ++z, ++pos) s += base_chr(ref_char(R, pos));
+				u = 0; nm += l;
+			}
+		}
+	} else {
+		for (int z = 0; z < len; ++z, ++pos) {
+			const int c = ref_char(R, pos);
+			if (c > 3 || q[z] > 3 || c != q[z]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
+		}
+	}
+	flush_num();
+	snprintf(md, cap, "%s", s.c_str());
+	*nm_out = nm;
+}
+
+
+static inline nabwa_se_t *rec_at(void *base, size_t stride, int i) { return (nabwa_se_t*)((char*)base + (size_t)i * stride); }
+
+/* bwa_aln2seq_core with set_main (bwase.c:28-46): reservoir choice among the best-score rows with the caller's
+ * drand48 stream; fills n_mm/n_gapo/n_gape/strand/score/sa/c1/c2/type. */
+static inline void choose_main(nabwa_se_t &s, int na, const nabwa_aln1_t *A, uint64_t *rng48)
+{
+	if (na == 0) { s.type = 0; s.c1 = s.c2 = 0; return; }
+	int cnt = 0, j;
+	const int best = A[0].score;
+	for (j = 0; j < na; ++j) {
+		if (A[j].score > best) break;
+		const uint32_t w = A[j].l - A[j].k + 1;
+		if (rng48_next(rng48) * (double)(w + cnt) > (double)cnt) {
+			s.n_mm = A[j].info & 0xff; s.n_gapo = A[j].info >> 8 & 0xff; s.n_gape = A[j].info >> 16 & 0xff;
+			s.strand = A[j].info >> 24 & 1; s.score = A[j].score;
+			s.sa = A[j].k + (uint32_t)((double)w * rng48_next(rng48));
+		}
+		cnt += w;
+	}
+	s.c1 = cnt & 0xfffffff;
+	for (; j < na; ++j) cnt += A[j].l - A[j].k + 1;
+	s.c2 = (cnt - s.c1) & 0xfffffff;
+	s.type = s.c1 > 1 ? 2 : 1;                                             /* BWA_TYPE_REPEAT : BWA_TYPE_UNIQUE */
+}
+
+/* bwa_aln2seq_core with n_multi (bwase.c:48-94): when the read has at most n_multi+1 hit rows in total, list them
+ * all but the chosen one (rows, still as BWT rows in .pos).  The sampling branch of the reference is unreachable
+ * under that condition ("In fact, we never come here"), so no random numbers are drawn. */
+static inline void list_multi(nabwa_se_t &s, int na, const nabwa_aln1_t *A, int n_multi)
+{
+	s.n_multi = 0;
+	if (na == 0 || n_multi <= 0) return;
+	uint64_t tot = 0;
+	for (int j = 0; j < na; ++j) tot += A[j].l - A[j].k + 1;
+	if (tot > (uint64_t)n_multi + 1) return;
+	int z = 0;
+	for (int j = 0; j < na; ++j)
+		for (uint32_t r = A[j].k; r <= A[j].l; ++r) {
+			if (r == s.sa) continue;
+			if (z == n_multi) break;
+			s.multi[z].pos = r; s.multi[z].gap = (A[j].info >> 8 & 0xff) + (A[j].info >> 16 & 0xff);
+			s.multi[z].mm = A[j].info & 0xff; s.multi[z].strand = A[j].info >> 24 & 1; s.multi[z].n_cigar = 0; ++z;
+		}
+	s.n_multi = z;
+}
+
+/* bwa_approx_mapQ (bwase.c:113-122) */
+static inline int approx_mapq(const nabwa_se_t &s, int md)
+{
+	if (s.c1 == 0) return 23;
+	if (s.c1 > 1) return 0;
+	if (s.n_mm == md) return 25;
+	if (s.c2 == 0) return 37;
+	const int nn = s.c2 >= 255 ? 255 : (int)s.c2; const int g = (int)(4.343 * log((double)nn) + 0.5);
+	return 23 < g ? 0 : 23 - g;
+}
+
+/* pos_end (bwase.c:425-436) */
+static inline int64_t rec_pos_end(const nabwa_se_t &s)
+{
+	if (!s.n_cigar) return (int64_t)s.pos + s.len;
+	int64_t x = s.pos;
+	for (int k = 0; k < s.n_cigar; ++k) { const int op = COP(s.cigar[k]); if (op == 0 || op == 2) x += CLEN(s.cigar[k]); }
+	return x;
+}
+
+/* Gap refinement of every gapped hit of the batch (main hits and multi hits) as ONE batch of banded global
+ * alignments on the GPU (refine_gapped_core, bwase.c:189-237; driver bwase.c:366-381: mate-rescued and
+ * unmapped records are skipped). */
+static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int n, const int64_t *off, const uint8_t *seq,
+							   const uint8_t *rseq, size_t *n_jobs)
+{
+	const nabwa_reference *R = ix->ref;
+	std::vector<RefineJob> jobs;
+	for (int i = 0; i < n; ++i) {
+		const nabwa_se_t &s = *rec_at(base, stride, i);
+		for (int j = 0; j < s.n_multi; ++j)
+			if (s.multi[j].gap) jobs.push_back({ i, j, s.multi[j].strand, (s.multi[j].strand ? 1 : -1) * s.multi[j].gap, s.len, s.multi[j].pos, 0, 0 });
+		if (s.type != 0 && s.type != 3 && s.n_gapo) jobs.push_back({ i, -1, s.strand, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape), s.len, s.pos, 0, 0 });
+	}
+	if (n_jobs) *n_jobs = jobs.size();
+	if (jobs.empty()) return NABWA_OK;
+	static const int maq[25] = { 11,-19,-19,-19,-13, -19,11,-19,-19,-13, -19,-19,11,-19,-13, -19,-19,-19,11,-13, -13,-13,-13,-13,-13 };  /* aln_sm_maq */
+	std::vector<int64_t> ro(jobs.size() + 1, 0), qo(jobs.size() + 1, 0);
+	std::vector<uint8_t> rbuf, qbuf;
+	for (size_t t = 0; t < jobs.size(); ++t) {
+		RefineJob &J = jobs[t];
+		const int ref_len = J.len + abs(J.ext);
+		int64_t p = (uint32_t)J.pos > R->l_pac ? (int64_t)(int32_t)(uint32_t)J.pos : (int64_t)(uint32_t)J.pos;   /* bwase.c:197 */
+		J.pos = p;
+		int64_t lo, hi;
+		if (J.ext > 0) { lo = std::max<int64_t>(p, 0); hi = std::min<int64_t>(p + ref_len, R->l_pac); }
+		else { const int64_t x = p + J.len; lo = x - ref_len > 0 ? x - ref_len : 0; hi = std::min<int64_t>(x, R->l_pac); }
+		for (int64_t k = lo; k < hi; ++k) rbuf.push_back((uint8_t)pac_at(R, k));
+		/* query in alignment orientation: reverse strand = rseq, forward = the read itself (seq is stored reversed) */
+		const uint8_t *src = (J.strand ? rseq : seq) + off[J.rec];
+		if (J.strand) qbuf.insert(qbuf.end(), src, src + J.len);
+		else for (int k = J.len - 1; k >= 0; --k) qbuf.push_back(src[k]);
+		ro[t + 1] = (int64_t)rbuf.size(); qo[t + 1] = (int64_t)qbuf.size();
+	}
+	rbuf.push_back(0); qbuf.push_back(0);
+	const int MAXC = NABWA_MAX_CIGAR;
+	std::vector<int32_t> sc(jobs.size()), nc(jobs.size()); std::vector<uint32_t> c32(jobs.size() * (size_t)MAXC);
+	int r = nabwa_global_align(ix->device, (int)jobs.size(), ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
+							   sc.data(), nc.data(), c32.data(), MAXC);                       /* aln_param_bwa, stdaln.c:227 */
+	if (r != NABWA_OK) return r;
+	for (size_t t = 0; t < jobs.size(); ++t) {
+		const RefineJob &J = jobs[t];
+		if (nc[t] > MAXC || nc[t] < 1) return nabwa_fail(NABWA_ECAP, "refined CIGAR longer than NABWA_MAX_CIGAR");
+		uint16_t cg[NABWA_MAX_CIGAR]; int m = nc[t]; int64_t p = J.pos;
+		for (int k = 0; k < m; ++k) cg[k] = CMAKE(c32[t * MAXC + k] & 0xf, c32[t * MAXC + k] >> 4);
+		if (J.ext < 0) {                       /* forward strand: the end was anchored, shift the start by the net indel */
+			int d = 0;
+			for (int k = 0; k < m; ++k) { if (COP(cg[k]) == 2) d -= CLEN(cg[k]); else if (COP(cg[k]) == 1) d += CLEN(cg[k]); }
+			p += d;
+		}
+		if (COP(cg[0]) == 2) { p += CLEN(cg[0]); for (int k = 0; k + 1 < m; ++k) cg[k] = cg[k + 1]; --m; }
+		if (COP(cg[m - 1]) == 2) --m;
+		if (COP(cg[m - 1]) == 1) cg[m - 1] = CMAKE(3, CLEN(cg[m - 1]));
+		if (COP(cg[0]) == 1) cg[0] = CMAKE(3, CLEN(cg[0]));
+		nabwa_se_t &s = *rec_at(base, stride, J.rec);
+		if (J.multi < 0) { s.pos = (uint32_t)p; s.n_cigar = m; memcpy(s.cigar, cg, 2 * m); }
+		else { s.multi[J.multi].pos = (uint32_t)p; s.multi[J.multi].n_cigar = m; memcpy(s.multi[J.multi].cigar, cg, 2 * m); }
+	}
+	return NABWA_OK;
+}
+
+/* MD / NM of a mapped record, then the quality-trimmed tail as a soft clip (bwase.c:399-419, :320-354).
+ * `fwd` is scratch for the un-reversed read. */
+static inline void md_and_trim(const nabwa_reference *R, nabwa_se_t &s, const uint8_t *seq_i, const uint8_t *rseq_i, std::vector<uint8_t> &fwd)
+{
+	const int len = s.len;
+	const uint8_t *q;
+	if (s.strand) q = rseq_i;
+	else { fwd.resize(len); for (int k = 0; k < len; ++k) fwd[k] = seq_i[len - 1 - k]; q = fwd.data(); }
+	make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
+	if (len != s.full_len) {                                   /* bwa_correct_trimmed */
+		const int clip = s.full_len - len;
+		if (s.strand == 0) {
+			if (s.n_cigar && COP(s.cigar[s.n_cigar - 1]) == 3) s.cigar[s.n_cigar - 1] += clip;
+			else { if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[0] = CMAKE(0, len); } else ++s.n_cigar; s.cigar[s.n_cigar - 1] = CMAKE(3, clip); }
+		} else {
+			if (s.n_cigar && COP(s.cigar[0]) == 3) s.cigar[0] += clip;
+			else {
+				if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[1] = CMAKE(0, len); }
+				else { ++s.n_cigar; memmove(s.cigar + 1, s.cigar, (s.n_cigar - 1) * 2); }
+				s.cigar[0] = CMAKE(3, clip);
+			}
+		}
+		s.len = s.full_len;
+	}
+}

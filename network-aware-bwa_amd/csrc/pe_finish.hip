@@ -1,0 +1,374 @@
+// pe_finish.hip -- the paired-end chain between the FM search and the BAM records (config 3).
+//
+// What the reference does per pair (bam2bam.c:683-811):
+//   posn_pair   : per end bwa_aln2seq (drand48 in record order) + bwa_cal_pac_pos_core            -> nabwa_pe_posn
+//   (barrier: insert-size histogram over all pairs, insert_size.c)                                 -> nabwa_isize_bin / _infer
+//   finish_pair : enumerate the text positions of every hit row of both ends (bwt_sa), pairing(),
+//                 multi-hit lists, bwa_paired_sw1 (mate rescue by local alignment), bwa_refine_gapped
+//                 on both ends, then the flag / mate fields of bwa_update_bam1                     -> nabwa_pe_finish
+// Here each step runs over the whole batch: all bwt_sa walks as GPU batches, all rescue alignments as ONE
+// batch of local alignments, all gap refinements as ONE batch of global alignments; the floating-point
+// decisions (windows, log-odds) stay on the host in double, in the reference's expression order.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <chrono>
+#include <thread>
+#include "finish_common.hpp"
+
+#define F_PD 1
+#define F_PP 2
+#define F_SU 4
+#define F_MU 8
+#define F_SR 16
+#define F_MR 32
+#define F_R1 64
+#define F_R2 128
+#define SW_MIN_MATCH_LEN 20       /* bwape.h:36 */
+#define SW_MIN_MAPQ 17            /* bwape.h:37 */
+
+static inline nabwa_pe_t &PE(nabwa_pe_t *out, int pair, int end) { return out[2 * (size_t)pair + end]; }
+
+static void clear_record(nabwa_pe_t &r, int len, int full_len, int end)
+{
+	nabwa_se_t &s = r.se;
+	memset(&s, 0, offsetof(nabwa_se_t, cigar));
+	s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = -1; s.nn = 0; s.rpos = 0; s.xt = 0;
+	for (int z = 0; z < NABWA_MAX_MULTI; ++z) s.multi[z].n_cigar = 0;
+	s.len = len; s.clip_len = len; s.full_len = full_len;
+	r.extra_flag = F_PD | (end ? F_R2 : F_R1);
+	r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0;
+}
+
+/* posn_pair (bam2bam.c:683-703) for n_pairs pairs; records and reads are interleaved: index 2*pair + end. */
+extern "C" int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, const int64_t *off, const int32_t *full_len,
+							 const int32_t *n_aln, const nabwa_aln1_t *aln, uint64_t *rng48, nabwa_pe_t *out)
+{
+	if (!ix || !opt || !rng48 || n_pairs < 0 || (n_pairs && (!off || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	const int n = 2 * n_pairs;
+	const uint32_t rlen = ix->bwt[1].seq_len;
+	std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look;
+	size_t a0 = 0;
+	for (int i = 0; i < n; ++i) {
+		const int len = (int)(off[i + 1] - off[i]);
+		clear_record(out[i], len, full_len ? full_len[i] : len, i & 1);
+		nabwa_se_t &s = out[i].se;
+		choose_main(s, n_aln[i], aln + a0, rng48);
+		a0 += n_aln[i];
+		if (s.type) { which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look.push_back(i); }
+	}
+	std::vector<uint32_t> sa(rows.size());
+	if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
+	for (size_t t = 0; t < rows.size(); ++t) {                                   /* bwase.c:139-154 */
+		nabwa_se_t &s = out[look[t]].se;
+		s.pos = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
+		const int md = opt->fnr > 0.0f ? nabwa_cal_maxdiff(s.len, 0.02, opt->fnr) : opt->max_diff;
+		s.mapQ = s.seQ = approx_mapq(s, md);
+	}
+	return NABWA_OK;
+}
+
+/* one mate-rescue attempt: align end `k` of pair `pair` inside [beg, beg+reglen) next to its mate (bwape.c:562-583) */
+struct SwJob { int pair, k; int64_t beg; int ref_n; bool fwd; };
+
+extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+							   int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
+							   const nabwa_aln1_t *aln, nabwa_pe_t *out, uint64_t n_tot[2], uint64_t n_mapped[2])
+{
+	if (!ix || !opt || !popt || !ii || n_pairs < 0 || (n_pairs && (!off || !seq || !rseq || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	if (popt->type != 1) return nabwa_fail(NABWA_EINVAL, "only BWA_PET_STD pairs are supported (no colour space)");
+	if (popt->n_multi < 0 || popt->N_multi < 0 || popt->n_multi > NABWA_MAX_MULTI || popt->N_multi > NABWA_MAX_MULTI)
+		return nabwa_fail(NABWA_EINVAL, "n_multi / N_multi outside 0..16");
+	const nabwa_reference *R = ix->ref;
+	const uint32_t rlen = ix->bwt[1].seq_len;
+	const int n = 2 * n_pairs;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t0 = now(), t1, t2, t3, t4;
+	std::vector<size_t> a_off((size_t)n + 1, 0);
+	for (int i = 0; i < n; ++i) a_off[i + 1] = a_off[i] + (size_t)n_aln[i];
+	uint64_t tot_dummy[2] = { 0, 0 }, map_dummy[2] = { 0, 0 };
+	if (!n_tot) n_tot = tot_dummy;
+	if (!n_mapped) n_mapped = map_dummy;
+	size_t n_hit_rows = 0, n_sw = 0, n_refine = 0;
+
+	/* ---- A. pairing: text positions of every hit row of both ends, chunked so one bwt_sa batch stays bounded
+	 *         (bam2bam.c:726-770; the position cache there only memoises bwt_sa and is not needed) */
+	const size_t CHUNK_ROWS = 1u << 25;
+	for (int p0 = 0; p0 < n_pairs;) {
+		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<size_t> pair_lo; std::vector<int> pairs;
+		int p1 = p0;
+		for (; p1 < n_pairs && (rows.size() < CHUNK_ROWS || pairs.empty()); ++p1) {
+			const nabwa_se_t &e0 = PE(out, p1, 0).se, &e1 = PE(out, p1, 1).se;
+			if (!((e0.type == 1 || e0.type == 2) && (e1.type == 1 || e1.type == 2))) continue;
+			long long n_occ[2] = { 0, 0 };
+			for (int j = 0; j < 2; ++j) {
+				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)p1 + j];
+				for (int k = 0; k < n_aln[2 * p1 + j]; ++k) n_occ[j] += (long long)A[k].l - A[k].k + 1;
+			}
+			if (n_occ[0] > popt->max_occ || n_occ[1] > popt->max_occ) continue;
+			pairs.push_back(p1); pair_lo.push_back(rows.size());
+			for (int j = 0; j < 2; ++j) {
+				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)p1 + j];
+				for (int k = 0; k < n_aln[2 * p1 + j]; ++k)
+					for (uint32_t l = A[k].k; ; ++l) { which.push_back((A[k].info >> 24 & 1) ? 0 : 1); rows.push_back(l); if (l == A[k].l) break; }
+			}
+		}
+		pair_lo.push_back(rows.size());
+		n_hit_rows += rows.size();
+		std::vector<uint32_t> sa(rows.size());
+		if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
+		std::vector<uint64_t> hits;
+		for (size_t t = 0; t < pairs.size(); ++t) {
+			const int pr = pairs[t];
+			hits.clear();
+			size_t u = pair_lo[t];
+			for (int j = 0; j < 2; ++j) {
+				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)pr + j];
+				const uint32_t len = (uint32_t)PE(out, pr, j).se.len;
+				for (int k = 0; k < n_aln[2 * pr + j]; ++k)
+					for (uint32_t l = A[k].k; ; ++l, ++u) {
+						const uint64_t x = which[u] == 0 ? sa[u] : rlen - (sa[u] + len);
+						hits.push_back(x << 32 | (uint64_t)(uint32_t)(k << 1) | (uint64_t)j);
+						if (l == A[k].l) { ++u; break; }
+					}
+			}
+			nabwa_pe_end_t e[2];
+			for (int j = 0; j < 2; ++j) {
+				const nabwa_pe_t &r = PE(out, pr, j); const nabwa_se_t &s = r.se;
+				e[j] = { s.pos, s.strand, s.mapQ, s.seQ, s.len, s.full_len, s.n_mm, s.n_gapo, s.n_gape, s.score, r.extra_flag };
+			}
+			nabwa_pairing(e, (int)hits.size(), hits.data(), aln + a_off[2 * (size_t)pr], aln + a_off[2 * (size_t)pr + 1], popt->max_isize, opt->s_mm, ii);
+			for (int j = 0; j < 2; ++j) {
+				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &s = r.se;
+				s.pos = e[j].pos; s.strand = e[j].strand; s.mapQ = e[j].mapQ; s.seQ = e[j].seQ; s.n_mm = e[j].n_mm; s.n_gapo = e[j].n_gapo;
+				s.n_gape = e[j].n_gape; s.score = e[j].score; r.extra_flag = e[j].extra_flag;
+			}
+		}
+		p0 = p1;
+	}
+	t1 = now();
+
+	/* ---- B. multi-hit lists and their positions (bam2bam.c:773-790) */
+	{
+		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look_rec, look_multi;
+		for (int pr = 0; pr < n_pairs; ++pr)
+			for (int j = 0; j < 2; ++j) {
+				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &s = r.se;
+				s.n_multi = 0;
+				if (s.type == 0) continue;
+				int nm = popt->n_multi;
+				if (!(r.extra_flag & F_PP) && PE(out, pr, 1 - j).se.type != 0)
+					nm = (int64_t)s.c1 + (int64_t)s.c2 - 1 > popt->N_multi ? popt->n_multi : popt->N_multi;
+				list_multi(s, n_aln[2 * pr + j], aln + a_off[2 * (size_t)pr + j], nm);
+				for (int z = 0; z < s.n_multi; ++z) {
+					which.push_back(s.multi[z].strand ? 0 : 1); rows.push_back(s.multi[z].pos); look_rec.push_back(2 * pr + j); look_multi.push_back(z);
+				}
+			}
+		std::vector<uint32_t> sa(rows.size());
+		if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
+		for (size_t t = 0; t < rows.size(); ++t) {
+			nabwa_se_t &s = out[look_rec[t]].se;
+			s.multi[look_multi[t]].pos = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
+		}
+	}
+	t2 = now();
+
+	/* ---- C. mate rescue (bwa_paired_sw1, bwape.c:519-633; bam2bam calls it unconditionally).
+	 *         Quirk F4 kept: a pair with an unmapped end returns before anything is changed. */
+	{
+		static const int maq[25] = { 11,-19,-19,-19,-13, -19,11,-19,-19,-13, -19,-19,11,-19,-13, -19,-19,-19,11,-13, -13,-13,-13,-13,-13 };
+		std::vector<SwJob> jobs; std::vector<int> cand;
+		std::vector<int64_t> ro(1, 0), qo(1, 0); std::vector<uint8_t> rb, qb;
+		std::vector<int64_t> begs((size_t)n, 0);                         /* beg[k] of every attempted end, by record index */
+		std::vector<int> job_of((size_t)n, -1);
+		for (int pr = 0; pr < n_pairs; ++pr) {
+			nabwa_pe_t &r0 = PE(out, pr, 0), &r1 = PE(out, pr, 1);
+			if (!((r0.se.mapQ >= SW_MIN_MAPQ || r1.se.mapQ >= SW_MIN_MAPQ) && (r0.extra_flag & F_PP) == 0)) continue;
+			const int single = (r0.se.type == 0 || r1.se.type == 0) ? 1 : 0;
+			++n_tot[single];
+			if (single) continue;
+			cand.push_back(pr);
+			for (int k = 0; k < 2; ++k) {
+				const nabwa_se_t &ref = PE(out, pr, 1 - k).se, &mate = PE(out, pr, k).se;
+				int64_t a, b;
+				if (ref.strand == 0) {                                   /* mate on the reverse strand, to the right (__set_rght_coor) */
+					a = (int64_t)((double)(int64_t)ref.pos + ii->avg - 3 * ii->std - mate.len * 1.5);
+					b = (int64_t)((double)a + 6 * ii->std + (double)(2 * mate.len));
+					if (a < (int64_t)ref.pos + ref.len) a = (int64_t)(uint32_t)(ref.pos + (uint32_t)ref.len);
+					if (b > R->l_pac) b = R->l_pac;
+				} else {                                                 /* mate on the forward strand, to the left (__set_left_coor) */
+					a = (int64_t)((double)((int64_t)ref.pos + ref.len) - ii->avg - 3 * ii->std - mate.len * 0.5);
+					b = (int64_t)((double)a + 6 * ii->std + (double)(2 * mate.len));
+					if (a < 0) a = 0;
+					if (b > (int64_t)ref.pos) b = ref.pos;
+				}
+				begs[2 * (size_t)pr + k] = a;
+				/* bwa_sw_core's guards (bwape.c:443-447) */
+				const int reglen = (int)(b - a), len = mate.len;
+				const uint32_t l_pac = (uint32_t)R->l_pac;
+				if (reglen < SW_MIN_MATCH_LEN || (int64_t)l_pac - a < len) continue;
+				const uint8_t *src = (ref.strand == 0 ? rseq : seq) + off[2 * pr + k];
+				uint32_t x = 0;
+				for (int z = 0; z < len; ++z) if (src[z] >= 4) ++x;
+				if ((float)x / len >= 0.25 || len - (int)x < SW_MIN_MATCH_LEN) continue;
+				int l = 0;
+				for (uint32_t z = (uint32_t)a; l < reglen && z < l_pac; ++z, ++l) rb.push_back((uint8_t)pac_at(R, z));
+				if (ref.strand == 0) qb.insert(qb.end(), src, src + len);
+				else for (int z = len - 1; z >= 0; --z) qb.push_back(src[z]);        /* ->seq is stored reversed */
+				ro.push_back((int64_t)rb.size()); qo.push_back((int64_t)qb.size());
+				job_of[2 * (size_t)pr + k] = (int)jobs.size();
+				jobs.push_back({ pr, k, a, l, ref.strand != 0 });
+			}
+		}
+		n_sw = jobs.size();
+		const int MAXC = NABWA_MAX_CIGAR - 2;
+		std::vector<int32_t> sc(jobs.size()), co(jobs.size() * 4), nc(jobs.size()); std::vector<uint32_t> c32(jobs.size() * (size_t)MAXC);
+		if (!jobs.empty()) {
+			rb.push_back(0); qb.push_back(0);
+			int r = nabwa_local_align(ix->device, (int)jobs.size(), ro.data(), rb.data(), qo.data(), qb.data(), 26, 9, maq, 50, 1,
+									  sc.data(), co.data(), 0, nc.data(), c32.data(), MAXC);
+			if (r != NABWA_OK) return r;
+		}
+		const int sw_isize_term = (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * 1.5) + .499));     /* bwape.c:593 */
+		for (int pr : cand) {
+			int n_cig[2] = { 0, 0 }, mq_adjust[2] = { 255, 255 }; uint16_t cig[2][NABWA_MAX_CIGAR]; uint32_t cnt[2] = { 0, 0 };
+			int64_t beg[2]; bool have[2] = { false, false };
+			for (int k = 0; k < 2; ++k) {
+				beg[k] = begs[2 * (size_t)pr + k];
+				const int t = job_of[2 * (size_t)pr + k];
+				if (t < 0) continue;
+				const nabwa_se_t &mate = PE(out, pr, k).se;
+				const int len = mate.len;
+				if (sc[t] < 0 || nc[t] < 1) continue;                       /* aln_local_core found nothing (or its "potential bug" branch) */
+				if (nc[t] > MAXC) return nabwa_fail(NABWA_ECAP, "rescue CIGAR longer than NABWA_MAX_CIGAR");
+				int m = nc[t]; uint16_t *cg = cig[k];
+				int64_t x = 0, y = 0;
+				for (int z = 0; z < m; ++z) {
+					const uint32_t c = c32[(size_t)t * MAXC + z]; const int op = c & 0xf, l = c >> 4;
+					cg[z] = CMAKE(op, l);
+					if (op == 0) { x += l; y += l; } else if (op == 2) x += l; else y += l;
+				}
+				if (x < SW_MIN_MATCH_LEN || y < SW_MIN_MATCH_LEN) continue;
+				/* first cell of the path (1-based i on the window, j on the read); a leading gap sits on row/column 0 of the sub-matrix */
+				int pi = co[4 * t], pj = co[4 * t + 1];
+				if (COP(cg[0]) == 1) pi -= 1; else if (COP(cg[0]) == 2) pj -= 1;
+				const int end_j = co[4 * t + 3];
+				beg[k] += (pi ? pi : 1) - 1;
+				const int start = (pj ? pj : 1) - 1;
+				if (start) { memmove(cg + 1, cg, 2 * (size_t)m); cg[0] = CMAKE(3, start); ++m; }
+				if (end_j < len) cg[m++] = CMAKE(3, len - end_j);
+				{	/* mismatches and gaps of the new alignment (bwape.c:495-513) */
+					int n_mm = 0, n_gapo = 0, n_gape = 0;
+					const uint8_t *rs = rb.data() + ro[t], *qs = qb.data() + qo[t];
+					int64_t xx = pi ? pi - 1 : 0, yy = pj ? pj - 1 : 0;
+					for (int z = 0; z < m; ++z) {
+						const int op = COP(cg[z]), l = CLEN(cg[z]);
+						if (op == 0) {
+							for (int w = 0; w < l; ++w) if (rs[xx + w] < 4 && qs[yy + w] < 4 && rs[xx + w] != qs[yy + w]) ++n_mm;
+							xx += l; yy += l;
+						} else if (op == 2) { xx += l; ++n_gapo; n_gape += l - 1; }
+						else if (op == 1) { yy += l; ++n_gapo; n_gape += l - 1; }
+					}
+					cnt[k] = (uint32_t)n_mm << 16 | n_gapo << 8 | n_gape;
+				}
+				n_cig[k] = m; have[k] = true;
+				{	/* is the rescued placement more likely than the one the search found? (bwape.c:584-600) */
+					int clip = 0;
+					if (COP(cg[0]) == 3) clip += CLEN(cg[0]);
+					if (COP(cg[m - 1]) == 3) clip += CLEN(cg[m - 1]);
+					int s_old = (int)((mate.n_mm * 9 + mate.n_gapo * 13 + mate.n_gape * 2) / 3. * 8. + .499);
+					int s_new = (int)(((cnt[k] >> 16) * 9 + (cnt[k] >> 8 & 0xff) * 13 + (cnt[k] & 0xff) * 2 + (uint32_t)clip * 3) / 3. * 8. + .499);
+					const double so = (double)s_old + -4.343 * log(ii->ap_prior / R->l_pac);
+					s_old = (so > -2147483649.0 && so < 2147483648.0) ? (int)so : INT_MIN;   /* ap_prior 0 (no estimate): cvttsd2si gives INT_MIN */
+					s_new += sw_isize_term;
+					if (s_old < s_new) { mq_adjust[k] = (int)((uint32_t)s_new - (uint32_t)s_old); have[k] = false; n_cig[k] = 0; }
+					else mq_adjust[k] = s_old - s_new;
+				}
+			}
+			int k = -1, mapQ = 0;
+			nabwa_pe_t *p[2] = { &PE(out, pr, 0), &PE(out, pr, 1) };
+			if (have[0] && have[1]) { k = p[0]->se.mapQ < p[1]->se.mapQ ? 0 : 1; mapQ = abs(p[1]->se.mapQ - p[0]->se.mapQ); }
+			else if (have[0]) { k = 0; mapQ = p[1]->se.mapQ; }
+			else if (have[1]) { k = 1; mapQ = p[0]->se.mapQ; }
+			if (k >= 0 && (int64_t)p[k]->se.pos != beg[k]) {
+				++n_mapped[0];
+				nabwa_se_t &fix = p[k]->se, &ref = p[1 - k]->se;
+				int tmp = ref.mapQ - fix.mapQ / 2 - 8;
+				if (tmp <= 0) tmp = 1;
+				if (mapQ > tmp) mapQ = tmp;
+				fix.mapQ = ref.mapQ = mapQ & 0xff;
+				fix.seQ = ref.seQ = ref.seQ < mapQ ? ref.seQ : (mapQ & 0xff);
+				if (fix.mapQ > mq_adjust[k]) fix.mapQ = mq_adjust[k] & 0xff;
+				if (fix.seQ > mq_adjust[k]) fix.seQ = mq_adjust[k] & 0xff;
+				fix.n_cigar = n_cig[k]; memcpy(fix.cigar, cig[k], 2 * (size_t)n_cig[k]);
+				fix.type = 3;                                          /* BWA_TYPE_MATESW */
+				fix.pos = (uint32_t)beg[k];
+				fix.seQ = ref.seQ;
+				fix.strand = 1 - ref.strand;
+				fix.n_mm = cnt[k] >> 16 & 0xff; fix.n_gapo = cnt[k] >> 8 & 0xff; fix.n_gape = cnt[k] & 0xff;
+				p[0]->extra_flag |= F_PP; p[1]->extra_flag |= F_PP;
+			}
+		}
+	}
+	t3 = now();
+
+	/* ---- D. gap refinement of both ends and their multi hits, one GPU batch (bwa_refine_gapped, bwase.c:356-381) */
+	{
+		int r = refine_batch(ix, out, sizeof(nabwa_pe_t), n, off, seq, rseq, &n_refine);
+		if (r != NABWA_OK) return r;
+	}
+	t4 = now();
+
+	/* ---- E. MD / NM / trimmed tail per end, then the flag and mate fields (bwase.c:399-419, bam2bam.c:430-525) */
+	auto phaseE = [&](int lo, int hi) {
+		std::vector<uint8_t> fwd;
+		for (int pr = lo; pr < hi; ++pr) {
+			for (int j = 0; j < 2; ++j) {
+				nabwa_se_t &s = PE(out, pr, j).se;
+				if (s.type != 0) md_and_trim(R, s, seq + off[2 * pr + j], rseq + off[2 * pr + j], fwd);
+			}
+			for (int j = 0; j < 2; ++j) {                              /* end 0 first, as bam2bam.c:804-805 */
+				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &p = r.se;
+				const nabwa_se_t &mate = PE(out, pr, 1 - j).se;
+				if (p.type == 0 && mate.type == 0) {
+					p.flag = (r.extra_flag & ~(F_PP | F_MU)) | F_SU | F_MU;
+					p.seqid = -1; p.rpos = 0; p.nn = 0; p.xt = 0; r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0;
+					continue;
+				}
+				int jlen;
+				if (p.type == 0) { p.pos = mate.pos; p.strand = mate.strand; r.extra_flag |= F_SU; jlen = 1; }
+				else jlen = (int)(rec_pos_end(p) - p.pos);
+				int flag = r.extra_flag, nn, seqid, m_seqid = -1;
+				nn = pac2real(R, p.pos, jlen, &seqid);
+				if (p.type != 0 && (int64_t)p.pos + jlen - R->anns[seqid].offset > R->anns[seqid].len) { flag |= F_SU; flag &= ~F_PP; p.mapQ = 0; }
+				if (p.strand) flag |= F_SR;
+				p.seqid = seqid; p.rpos = (int64_t)p.pos - R->anns[seqid].offset + 1;
+				if (mate.type != 0) {
+					r.am = mate.seQ < p.seQ ? mate.seQ : p.seQ;
+					nn += pac2real(R, mate.pos, mate.len, &m_seqid);
+					const int m_j = (int)(rec_pos_end(mate) - mate.pos);
+					if ((int64_t)mate.pos + m_j - R->anns[m_seqid].offset > R->anns[m_seqid].len) { flag |= F_MU; flag &= ~F_PP; }
+					if (mate.strand) flag |= F_MR;
+					r.m_seqid = m_seqid; r.m_rpos = (int64_t)mate.pos - R->anns[m_seqid].offset + 1;
+					if (p.type == 0 || seqid != m_seqid) r.isize = 0;
+					else r.isize = (mate.strand ? rec_pos_end(mate) : (int64_t)mate.pos) - (p.strand ? rec_pos_end(p) : (int64_t)p.pos);
+				} else { flag |= F_MU; flag &= ~F_PP; r.am = 0; r.m_seqid = seqid; r.m_rpos = p.rpos; r.isize = 0; }
+				p.flag = flag; p.nn = nn;
+				p.xt = p.type == 0 ? 0 : (nn > 10 ? 'N' : "NURM"[p.type]);
+			}
+		}
+	};
+	{
+		int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+		if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
+		if (n_pairs < 4096) nt = 1;
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back(phaseE, (int)((int64_t)n_pairs * t / nt), (int)((int64_t)n_pairs * (t + 1) / nt));
+		for (auto &x : th) x.join();
+	}
+	if (timing) fprintf(stderr, "[nabwa] pe_finish %d pairs: pairing (%zu hit rows) %.3f s, multi %.3f s, mate rescue (%zu alignments) %.3f s, "
+						"refinement (%zu jobs) %.3f s, md/flags %.3f s\n", n_pairs, n_hit_rows, t1 - t0, t2 - t1, n_sw, t3 - t2, n_refine, t4 - t3, now() - t4);
+	return NABWA_OK;
+}

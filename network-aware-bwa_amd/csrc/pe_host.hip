@@ -76,6 +76,13 @@ extern "C" int nabwa_isize_bin(int kind, int mapq0, int mapq1, uint32_t pos0, in
 	return len;
 }
 
+extern "C" void nabwa_pe_opt_default(nabwa_pe_opt_t *po)            /* bwa_init_pe_opt, bwape.c:27-41 */
+{
+	if (!po) return;
+	memset(po, 0, sizeof(*po));
+	po->max_isize = 500; po->max_occ = 100000; po->max_occ_se = 3; po->n_multi = 3; po->N_multi = 10; po->type = 1; po->is_sw = 1; po->ap_prior = 1e-5;
+}
+
 static inline uint64_t mix_u64(uint64_t key)       /* the tie-breaking hash of pairing (bwape.c:43-54) */
 {
 	key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);

@@ -20,6 +20,7 @@
 #include <thread>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
+#include "finish_common.hpp"
 
 struct DpParams {
 	int n;
@@ -303,96 +304,6 @@ extern "C" int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefi
 	return NABWA_OK;
 }
 
-/* ------------------------------------------------------------------ small host pieces */
-
-static inline double rng48_next(uint64_t *x)          /* drand48: X' = 0x5DEECE66D X + 0xB mod 2^48, result X'/2^48 */
-{
-	*x = (*x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;
-	return (double)*x * (1.0 / 281474976710656.0);
-}
-
-static inline int pac_at(const nabwa_reference *R, int64_t k) { return R->pac[k >> 2] >> ((~k & 3) << 1) & 3; }
-
-/* base of the reference at pos with the ambiguity codes of the .amb holes restored (bwase.c:239-251) */
-static int ref_char(const nabwa_reference *R, int64_t pos)
-{
-	size_t lo = 0, hi = R->holes.size();
-	while (lo < hi) {
-		size_t mid = (lo + hi) / 2;
-		if (pos >= R->holes[mid].offset + R->holes[mid].len) lo = mid + 1;
-		else if (pos < R->holes[mid].offset) hi = mid;
-		else return R->holes[mid].amb;
-	}
-	return pac_at(R, pos);
-}
-
-/* bns_coor_pac2real (bntseq.c:272-306): contig of a position and the number of ambiguous bases under [pos, pos+len) */
-static int pac2real(const nabwa_reference *R, int64_t pos, int len, int *seqid)
-{
-	int left = 0, mid = 0, right = (int)R->anns.size(), nn = 0;
-	while (left < right) {
-		mid = (left + right) >> 1;
-		if (pos >= R->anns[mid].offset) {
-			if (mid == (int)R->anns.size() - 1) break;
-			if (pos < R->anns[mid + 1].offset) break;
-			left = mid + 1;
-		} else right = mid;
-	}
-	*seqid = mid;
-	left = 0; right = (int)R->holes.size();
-	while (left < right) {
-		const int m = (left + right) >> 1; const nabwa_hole &h = R->holes[m];
-		if (pos >= h.offset + h.len) left = m + 1;
-		else if (pos + len <= h.offset) right = m;
-		else {
-			if (pos >= h.offset) nn += h.offset + h.len < pos + len ? (int)(h.offset + h.len - pos) : len;
-			else nn += h.offset + h.len < pos + len ? h.len : len - (int)(h.offset - pos);
-			break;
-		}
-	}
-	return nn;
-}
-
-#define COP(c) ((c) >> 14)
-#define CLEN(c) ((c) & 0x3fff)
-#define CMAKE(op, len) ((uint16_t)((op) << 14 | (len)))
-
-/* one gap-refinement job: which record, main hit (-1) or multi index, query orientation, window */
-struct RefineJob { int rec, multi, strand, ext, len; int64_t pos; int64_t win_lo; int win_n; };
-
-/* MD string and NM of an alignment (bwa_cal_md1, bwase.c:253-315) */
-static void make_md(const nabwa_reference *R, int n_cigar, const uint16_t *cigar, int len, uint32_t pos0, const uint8_t *q,
-					char *md, int cap, int *nm_out)
-{
-	int64_t pos = pos0; int u = 0, nm = 0, y = 0; std::string s; char num[16];
-	auto flush_num = [&]() { snprintf(num, sizeof num, "%d", u); s += num; };
-	auto base_chr = [](int c) -> char { return c > 3 ? (char)c : "ACGT"[c]; };
-	if (n_cigar) {
-		for (int k = 0; k < n_cigar; ++k) {
-			const int l = CLEN(cigar[k]), op = COP(cigar[k]);
-			if (op == 0) {
-				for (int z = 0; z < l && pos < R->l_pac; ++z, ++y, ++pos) {
-					const int c = ref_char(R, pos);
-					if (c > 3 || q[y] > 3 || c != q[y]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
-				}
-			} else if (op == 1 || op == 3) { y += l; if (op == 1) nm += l; }
-			else {
-				flush_num(); s += '^';
-				for (int z = 0; z < l && pos < R->l_pac; ++z, ++pos) s += base_chr(ref_char(R, pos));
-				u = 0; nm += l;
-			}
-		}
-	} else {
-		for (int z = 0; z < len; ++z, ++pos) {
-			const int c = ref_char(R, pos);
-			if (c > 3 || q[z] > 3 || c != q[z]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
-		}
-	}
-	flush_num();
-	snprintf(md, cap, "%s", s.c_str());
-	*nm_out = nm;
-}
-
 /* ------------------------------------------------------------------ the chain */
 
 extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const uint8_t *seq,
@@ -422,37 +333,9 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		const nabwa_aln1_t *A = aln + a0; const int na = n_aln[i];
 		a0 += na;
 		if (na == 0) continue;
-		int cnt = 0, j;
-		const int best = A[0].score;
-		for (j = 0; j < na; ++j) {
-			if (A[j].score > best) break;
-			const uint32_t w = A[j].l - A[j].k + 1;
-			if (rng48_next(rng48) * (double)(w + cnt) > (double)cnt) {          /* reservoir choice over the best-score rows */
-				s.n_mm = A[j].info & 0xff; s.n_gapo = A[j].info >> 8 & 0xff; s.n_gape = A[j].info >> 16 & 0xff;
-				s.strand = A[j].info >> 24 & 1; s.score = A[j].score;
-				s.sa = A[j].k + (uint32_t)((double)w * rng48_next(rng48));
-			}
-			cnt += w;
-		}
-		s.c1 = cnt & 0xfffffff;
-		for (; j < na; ++j) cnt += A[j].l - A[j].k + 1;
-		s.c2 = (cnt - s.c1) & 0xfffffff;
-		s.type = s.c1 > 1 ? 2 : 1;                                             /* BWA_TYPE_REPEAT : BWA_TYPE_UNIQUE */
-		if (n_occ) {
-			uint64_t tot = 0;
-			for (j = 0; j < na; ++j) tot += A[j].l - A[j].k + 1;
-			if (tot <= (uint64_t)n_occ + 1) {                                    /* few enough: list every row but the chosen one */
-				int z = 0;
-				for (j = 0; j < na; ++j)
-					for (uint32_t r = A[j].k; r <= A[j].l; ++r) {
-						if (r == s.sa) continue;
-						if (z == n_occ) break;
-						s.multi[z].pos = r; s.multi[z].gap = (A[j].info >> 8 & 0xff) + (A[j].info >> 16 & 0xff);
-						s.multi[z].mm = A[j].info & 0xff; s.multi[z].strand = A[j].info >> 24 & 1; ++z;
-					}
-				s.n_multi = z;
-			}
-		}
+		choose_main(s, na, A, rng48);
+		list_multi(s, na, A, n_occ);
+		int j;
 		which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look_rec.push_back(i); look_multi.push_back(-1);
 		for (j = 0; j < s.n_multi; ++j) {
 			which.push_back(s.multi[j].strand ? 0 : 1); rows.push_back(s.multi[j].pos); look_rec.push_back(i); look_multi.push_back(j);
@@ -476,64 +359,16 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		nabwa_se_t &s = out[i];
 		if (s.type == 0) continue;
 		const int md = opt->fnr > 0.0f ? nabwa_cal_maxdiff(s.len, 0.02, opt->fnr) : opt->max_diff;
-		int q;
-		if (s.c1 == 0) q = 23; else if (s.c1 > 1) q = 0; else if (s.n_mm == md) q = 25; else if (s.c2 == 0) q = 37;
-		else { const int nn = s.c2 >= 255 ? 255 : (int)s.c2; const int g = (int)(4.343 * log((double)nn) + 0.5); q = 23 < g ? 0 : 23 - g; }
+		const int q = approx_mapq(s, md);
 		s.mapQ = s.seQ = q;
 	}
 
 	t2 = now();
 	/* ---- phase 3, GPU: gap refinement of every gapped hit as one batch of global alignments (bwase.c:189-237) */
-	std::vector<RefineJob> jobs;
-	for (int i = 0; i < n; ++i) {
-		const nabwa_se_t &s = out[i];
-		for (int j = 0; j < s.n_multi; ++j)
-			if (s.multi[j].gap) jobs.push_back({ i, j, s.multi[j].strand, (s.multi[j].strand ? 1 : -1) * s.multi[j].gap, s.len, s.multi[j].pos, 0, 0 });
-		if (s.type != 0 && s.n_gapo) jobs.push_back({ i, -1, s.strand, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape), s.len, s.pos, 0, 0 });
-	}
-	if (!jobs.empty()) {
-		static const int maq[25] = { 11,-19,-19,-19,-13, -19,11,-19,-19,-13, -19,-19,11,-19,-13, -19,-19,-19,11,-13, -13,-13,-13,-13,-13 };  /* aln_sm_maq */
-		std::vector<int64_t> ro(jobs.size() + 1, 0), qo(jobs.size() + 1, 0);
-		std::vector<uint8_t> rbuf, qbuf;
-		for (size_t t = 0; t < jobs.size(); ++t) {
-			RefineJob &J = jobs[t];
-			const int ref_len = J.len + abs(J.ext);
-			int64_t p = (uint32_t)J.pos > R->l_pac ? (int64_t)(int32_t)(uint32_t)J.pos : (int64_t)(uint32_t)J.pos;   /* bwase.c:197 */
-			J.pos = p;
-			int64_t lo, hi;
-			if (J.ext > 0) { lo = std::max<int64_t>(p, 0); hi = std::min<int64_t>(p + ref_len, R->l_pac); }
-			else { const int64_t x = p + J.len; lo = x - ref_len > 0 ? x - ref_len : 0; hi = std::min<int64_t>(x, R->l_pac); }
-			for (int64_t k = lo; k < hi; ++k) rbuf.push_back((uint8_t)pac_at(R, k));
-			/* query in alignment orientation: reverse strand = rseq, forward = the read itself (seq is stored reversed) */
-			const uint8_t *src = (J.strand ? rseq : seq) + off[J.rec];
-			if (J.strand) qbuf.insert(qbuf.end(), src, src + J.len);
-			else for (int k = J.len - 1; k >= 0; --k) qbuf.push_back(src[k]);
-			ro[t + 1] = (int64_t)rbuf.size(); qo[t + 1] = (int64_t)qbuf.size();
-		}
-		rbuf.push_back(0); qbuf.push_back(0);
-		const int MAXC = NABWA_MAX_CIGAR;
-		std::vector<int32_t> sc(jobs.size()), nc(jobs.size()); std::vector<uint32_t> c32(jobs.size() * (size_t)MAXC);
-		int r = nabwa_global_align(ix->device, (int)jobs.size(), ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
-								   sc.data(), nc.data(), c32.data(), MAXC);                       /* aln_param_bwa, stdaln.c:227 */
+	size_t n_jobs = 0;
+	{
+		int r = refine_batch(ix, out, sizeof(nabwa_se_t), n, off, seq, rseq, &n_jobs);
 		if (r != NABWA_OK) return r;
-		for (size_t t = 0; t < jobs.size(); ++t) {
-			const RefineJob &J = jobs[t];
-			if (nc[t] > MAXC || nc[t] < 1) return nabwa_fail(NABWA_ECAP, "refined CIGAR longer than NABWA_MAX_CIGAR");
-			uint16_t cg[NABWA_MAX_CIGAR]; int m = nc[t]; int64_t p = J.pos;
-			for (int k = 0; k < m; ++k) cg[k] = CMAKE(c32[t * MAXC + k] & 0xf, c32[t * MAXC + k] >> 4);
-			if (J.ext < 0) {                       /* forward strand: the end was anchored, shift the start by the net indel */
-				int d = 0;
-				for (int k = 0; k < m; ++k) { if (COP(cg[k]) == 2) d -= CLEN(cg[k]); else if (COP(cg[k]) == 1) d += CLEN(cg[k]); }
-				p += d;
-			}
-			if (COP(cg[0]) == 2) { p += CLEN(cg[0]); for (int k = 0; k + 1 < m; ++k) cg[k] = cg[k + 1]; --m; }
-			if (COP(cg[m - 1]) == 2) --m;
-			if (COP(cg[m - 1]) == 1) cg[m - 1] = CMAKE(3, CLEN(cg[m - 1]));
-			if (COP(cg[0]) == 1) cg[0] = CMAKE(3, CLEN(cg[0]));
-			nabwa_se_t &s = out[J.rec];
-			if (J.multi < 0) { s.pos = (uint32_t)p; s.n_cigar = m; memcpy(s.cigar, cg, 2 * m); }
-			else { s.multi[J.multi].pos = (uint32_t)p; s.multi[J.multi].n_cigar = m; memcpy(s.multi[J.multi].cigar, cg, 2 * m); }
-		}
 	}
 
 	t3 = now();
@@ -543,26 +378,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		for (int i = lo; i < hi; ++i) {
 			nabwa_se_t &s = out[i];
 			if (s.type == 0) { s.flag = 4; continue; }
-			const int len = s.len;
-			const uint8_t *q;
-			if (s.strand) q = rseq + off[i];
-			else { fwd.resize(len); for (int k = 0; k < len; ++k) fwd[k] = seq[off[i] + len - 1 - k]; q = fwd.data(); }
-			make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
-			if (len != s.full_len) {                                   /* bwa_correct_trimmed */
-				const int clip = s.full_len - len;
-				if (s.strand == 0) {
-					if (s.n_cigar && COP(s.cigar[s.n_cigar - 1]) == 3) s.cigar[s.n_cigar - 1] += clip;
-					else { if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[0] = CMAKE(0, len); } else ++s.n_cigar; s.cigar[s.n_cigar - 1] = CMAKE(3, clip); }
-				} else {
-					if (s.n_cigar && COP(s.cigar[0]) == 3) s.cigar[0] += clip;
-					else {
-						if (s.n_cigar == 0) { s.n_cigar = 2; s.cigar[1] = CMAKE(0, len); }
-						else { ++s.n_cigar; memmove(s.cigar + 1, s.cigar, (s.n_cigar - 1) * 2); }
-						s.cigar[0] = CMAKE(3, clip);
-					}
-				}
-				s.len = s.full_len;
-			}
+			md_and_trim(R, s, seq + off[i], rseq + off[i], fwd);
 			int64_t end = s.pos;
 			if (s.n_cigar) { for (int k = 0; k < s.n_cigar; ++k) { const int op = COP(s.cigar[k]); if (op == 0 || op == 2) end += CLEN(s.cigar[k]); } }
 			else end += s.len;
@@ -584,6 +400,6 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		for (auto &x : th) x.join();
 	}
 	if (timing) fprintf(stderr, "[nabwa] se_finish %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) %.3f s, refinement (%zu jobs) %.3f s, md/flags %.3f s\n",
-						n, t1 - t0, rows.size(), t2 - t1, jobs.size(), t3 - t2, now() - t3);
+						n, t1 - t0, rows.size(), t2 - t1, n_jobs, t3 - t2, now() - t3);
 	return NABWA_OK;
 }

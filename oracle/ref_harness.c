@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <math.h>
 #include "bwt.h"
 #include "bwtaln.h"
 #include "bwtgap.h"
@@ -325,4 +326,147 @@ int ref_pairing(const int *n_aln, const uint32_t *aln0, const uint32_t *aln1,
 	}
 	kv_destroy(d.arr); free(po);
 	return r;
+}
+
+/* ------------------------------------------------------------------ the per-pair chain of bam2bam
+ * bam2bam.c itself cannot be compiled here (needs <zmq.h>), so this is OUR restatement of the glue in
+ * posn_pair / finish_pair (bam2bam.c:683-811) -- a dozen calls in a fixed order -- with every call going to
+ * the REFERENCE's own function (bwa_aln2seq*, bwa_cal_pac_pos_core, bwt_sa, pairing, bwa_paired_sw1,
+ * bwa_refine_gapped).  The position cache (my_hash, bam2bam.c:741-757) only memoises bwt_sa and is left out. */
+typedef struct { int n; bwa_seq_t *s; } ref_pe_batch_t;      /* s[2*i + end] */
+
+ref_pe_batch_t *ref_pe_new(int n_pairs)
+{
+	ref_pe_batch_t *b = (ref_pe_batch_t*)calloc(1, sizeof(*b));
+	b->n = n_pairs; b->s = (bwa_seq_t*)calloc(2 * (size_t)n_pairs, sizeof(bwa_seq_t));
+	return b;
+}
+void ref_pe_set(ref_pe_batch_t *b, int pair, int end, int len, const uint8_t *seq, const uint8_t *rseq, int n_aln, const uint32_t *aln)
+{
+	bwa_seq_t *p = b->s + 2 * pair + end;
+	p->len = p->full_len = p->clip_len = len;
+	p->seq = (ubyte_t*)malloc(len + 1); memcpy(p->seq, seq, len);
+	p->rseq = (ubyte_t*)malloc(len + 1); memcpy(p->rseq, rseq, len);
+	p->n_aln = n_aln; p->aln = (bwt_aln1_t*)calloc(n_aln ? n_aln : 1, sizeof(bwt_aln1_t));
+	if (n_aln) memcpy(p->aln, aln, 16 * (size_t)n_aln);
+	p->extra_flag = SAM_FPD | (end ? SAM_FR2 : SAM_FR1);
+}
+/* pass 1 of every pair, in order (global drand48 stream): posn_pair, bam2bam.c:683-703 */
+void ref_pe_posn(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt)
+{
+	int i, j;
+	for (i = 0; i < b->n; ++i)
+		for (j = 0; j < 2; ++j) {
+			bwa_seq_t *p = b->s + 2 * i + j;
+			p->n_multi = 0;
+			bwa_aln2seq(p->n_aln, p->aln, p);
+			bwa_cal_pac_pos_core(ix->bwt[0], ix->bwt[1], p, opt->max_diff, opt->fnr);
+		}
+}
+/* pass 2 of every pair: finish_pair, bam2bam.c:705-811, up to (not including) bwa_update_bam1 */
+void ref_pe_finish(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv)
+{
+	pe_opt_t *po = bwa_init_pe_opt(); isize_info_t ii; uint64_t n_tot[2] = {0, 0}, n_mapped[2] = {0, 0}; int i, j, k;
+	memset(&ii, 0, sizeof(ii));
+	ii.avg = iiv[0]; ii.std = iiv[1]; ii.ap_prior = iiv[2]; ii.low = iiv[3]; ii.high = iiv[4]; ii.high_bayesian = iiv[5];
+	bwase_initialize();
+	for (i = 0; i < b->n; ++i) {
+		bwa_seq_t *p[2] = { b->s + 2 * i, b->s + 2 * i + 1 };
+		pe_data_t d; memset(&d, 0, sizeof(d));
+		for (j = 0; j < 2; ++j) { d.aln[j].a = p[j]->aln; d.aln[j].n = p[j]->n_aln; }
+		if ((p[0]->type == BWA_TYPE_UNIQUE || p[0]->type == BWA_TYPE_REPEAT) && (p[1]->type == BWA_TYPE_UNIQUE || p[1]->type == BWA_TYPE_REPEAT)) {
+			long long n_occ[2];
+			for (j = 0; j < 2; ++j) { n_occ[j] = 0; for (k = 0; k < d.aln[j].n; ++k) n_occ[j] += d.aln[j].a[k].l - d.aln[j].a[k].k + 1; }
+			if (n_occ[0] <= po->max_occ && n_occ[1] <= po->max_occ) {
+				for (j = 0; j < 2; ++j)
+					for (k = 0; k < d.aln[j].n; ++k) {
+						bwt_aln1_t *r = d.aln[j].a + k; bwtint_t l;
+						for (l = r->k; l <= r->l; ++l) {
+							uint64_t x = r->a ? bwt_sa(ix->bwt[0], l) : ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], l) + p[j]->len);
+							x = x << 32 | k << 1 | j;
+							kv_push(uint64_t, d.arr, x);
+						}
+					}
+				pairing(p, &d, po, opt->s_mm, &ii);
+			}
+		}
+		for (j = 0; j < 2; ++j)
+			if (p[j]->type != BWA_TYPE_NO_MATCH) {
+				if (!(p[j]->extra_flag & SAM_FPP) && p[1-j]->type != BWA_TYPE_NO_MATCH)
+					bwa_aln2seq_core(d.aln[j].n, d.aln[j].a, p[j], 0, p[j]->c1 + p[j]->c2 - 1 > po->N_multi ? po->n_multi : po->N_multi);
+				else bwa_aln2seq_core(d.aln[j].n, d.aln[j].a, p[j], 0, po->n_multi);
+				for (k = 0; k < p[j]->n_multi; ++k) {
+					bwt_multi1_t *q = p[j]->multi + k;
+					q->pos = q->strand ? bwt_sa(ix->bwt[0], q->pos) : ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], q->pos) + p[j]->len);
+				}
+			}
+		kv_destroy(d.arr);
+		bwa_paired_sw1(ix->bns, ix->pac, p, po, &ii, n_tot, n_mapped);
+		bwa_refine_gapped(ix->bns, 1, p[0], ix->pac, 0);
+		bwa_refine_gapped(ix->bns, 1, p[1], ix->pac, 0);
+	}
+	free(po);
+}
+/* fields of one end: type,strand,n_mm,n_gapo,n_gape,score,sa,c1,c2,pos,mapQ,seQ,extra_flag,n_cigar,nm,n_multi,len ;
+ * cigar (u16) ; md ; multi rows (pos,gap,mm,strand,n_cigar, then cigar padded to 16) */
+void ref_pe_get(ref_pe_batch_t *b, int pair, int end, int64_t *f, uint16_t *cigar, char *md, int md_cap, int64_t *multi)
+{
+	const bwa_seq_t *p = b->s + 2 * pair + end; int k, c;
+	f[0] = p->type; f[1] = p->strand; f[2] = p->n_mm; f[3] = p->n_gapo; f[4] = p->n_gape; f[5] = p->score; f[6] = p->sa;
+	f[7] = p->c1; f[8] = p->c2; f[9] = p->pos; f[10] = p->mapQ; f[11] = p->seQ; f[12] = p->extra_flag;
+	f[13] = p->cigar ? p->n_cigar : 0; f[14] = p->nm; f[15] = p->n_multi; f[16] = p->len;
+	if (p->cigar) memcpy(cigar, p->cigar, 2 * p->n_cigar);
+	md[0] = 0; if (p->md) { strncpy(md, p->md, md_cap - 1); md[md_cap - 1] = 0; }
+	for (k = 0; k < p->n_multi; ++k) {
+		const bwt_multi1_t *q = p->multi + k;
+		multi[21 * k] = q->pos; multi[21 * k + 1] = q->gap; multi[21 * k + 2] = q->mm; multi[21 * k + 3] = q->strand;
+		multi[21 * k + 4] = q->cigar ? q->n_cigar : 0;
+		for (c = 0; c < 16; ++c) multi[21 * k + 5 + c] = (q->cigar && c < (int)q->n_cigar) ? q->cigar[c] : 0;
+	}
+}
+void ref_pe_free(ref_pe_batch_t *b)
+{
+	int i;
+	for (i = 0; i < 2 * b->n; ++i) bwa_free_read_seq1(b->s + i);
+	free(b->s); free(b);
+}
+
+/* The insert-size estimate `sampe` makes from one batch of positioned pairs: bwape.c:74-175 is a static
+ * function, so this is a RESTATEMENT of it over the harness batch (same libm, same expression order); it is
+ * only used to reproduce the reference's `sampe` command end to end (make_golden.py checks the harness chain
+ * against the SAM that command printed, which pins both this function and the chain glue above). */
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+int ref_pe_isize_pairs(ref_pe_batch_t *b, double ap_prior, int64_t L, double *o)
+{
+	uint64_t x, *isz = (uint64_t*)calloc(b->n ? b->n : 1, 8), n_ap = 0; int n, i, tot = 0, p25, p75, max_len = 1, tmp;
+	double avg = -1.0, std = -1.0, y, ap; uint32_t low = 0, high = 0, hb = 0;
+	o[0] = o[1] = -1.0; o[2] = 0; o[3] = o[4] = o[5] = 0;
+	for (i = 0; i < b->n; ++i) {
+		const bwa_seq_t *p0 = b->s + 2 * i, *p1 = p0 + 1;
+		if (p0->mapQ >= 20 && p1->mapQ >= 20) {
+			x = (p0->pos < p1->pos) ? p1->pos + p1->len - p0->pos : p0->pos + p0->len - p1->pos;
+			if (x < 100000) isz[tot++] = x;
+		}
+		if ((int)p0->len > max_len) max_len = p0->len;
+		if ((int)p1->len > max_len) max_len = p1->len;
+	}
+	if (tot < 20) { free(isz); return -1; }
+	qsort(isz, tot, 8, cmp_u64);
+	p25 = isz[(int)(tot * 0.25 + 0.5)]; p75 = isz[(int)(tot * 0.75 + 0.5)];
+	tmp = (int)(p25 - 2.0 * (p75 - p25) + .499);
+	low = tmp > max_len ? tmp : max_len;
+	high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+	for (i = 0, x = n = 0; i < tot; ++i) if (isz[i] >= low && isz[i] <= high) ++n, x += isz[i];
+	avg = (double)x / n;
+	for (i = 0; i < tot; ++i) if (isz[i] >= low && isz[i] <= high) { double t = (isz[i] - avg) * (isz[i] - avg); std += t; }
+	std = sqrt(std / n);
+	for (y = 1.0; y < 10.0; y += 0.01) if (.5 * erfc(y / M_SQRT2) < ap_prior / L * (y * std + avg)) break;
+	hb = (uint32_t)(y * std + avg + .499);
+	for (i = 0; i < tot; ++i) if (isz[i] > hb) ++n_ap;
+	ap = .01 * (n_ap + .01) / tot; if (ap < ap_prior) ap = ap_prior;
+	free(isz);
+	o[2] = ap;
+	if (isnan(std) || p75 > 100000) return -1;
+	o[0] = avg; o[1] = std; o[3] = low; o[4] = high; o[5] = hb;
+	return 0;
 }

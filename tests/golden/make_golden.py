@@ -325,6 +325,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "vectors.npz"), **out)
     make_sw_vectors(lib, sm_maq, sm_blast)
     make_pe_vectors(lib)
+    make_pe_chain(lib)
     print("golden fixtures written to", HERE, "reads:", len(reads))
 
 
@@ -468,5 +469,244 @@ def make_pe_vectors(lib):
                pr_misc=np.array(misc, np.float64))
     np.savez_compressed(os.path.join(HERE, "vectors_pe.npz"), **out)
 
+
+def read_genome():
+    out, name, buf = [], None, []
+    for line in open(PREFIX + ".fa"):
+        if line.startswith(">"):
+            if name:
+                out.append((name, "".join(buf)))
+            name, buf = line[1:].split()[0], []
+        else:
+            buf.append(line.strip())
+    out.append((name, "".join(buf)))
+    return out
+
+
+def make_pe_reads(rng, contigs):
+    """Read pairs of the toy genome: proper FR pairs (insert ~N(300,25)), pairs whose second end is too diverged for
+    `aln` (singletons), far-apart and cross-contig pairs (discordant), ends inside the exact duplicate (pairing
+    has to choose), and pairs whose second end carries the chr1 version of the diverged chr2 copy (so `aln` places it
+    on chr1 and the mate rescue finds it next to read 1 on chr2)."""
+    g = dict(contigs)
+    pairs = []
+
+    def subs(s, n, lo=0, hi=None):
+        s = list(s)
+        hi = len(s) if hi is None else hi
+        for p in rng.choice(np.arange(lo, hi), n, replace=False):
+            s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(0, 3))) % 4] if s[p] in "ACGT" else "A"
+        return "".join(s)
+
+    def frag_pair(contig, start, isize, L1, L2):
+        f = g[contig][start:start + isize]
+        return f[:L1], revcomp(f[-L2:])
+
+    def add(tag, r1, r2):
+        if rng.integers(0, 2):                       # which end is read 1 is arbitrary
+            r1, r2 = r2, r1
+        pairs.append(("p%04d_%s" % (len(pairs), tag), r1, r2))
+
+    def clean(contig, start, isize):
+        return "N" not in g[contig][start:start + isize]
+
+    n_kind = {"proper": 230, "sub": 40, "diverged": 24, "far": 24, "cross": 16, "dup": 30, "rescue": 30, "short": 16, "gap": 20, "junk": 6}
+    for kind, n in n_kind.items():
+        made = 0
+        while made < n:
+            contig = "chr1" if rng.random() < 0.6 else "chr2"
+            isize = int(np.clip(rng.normal(300, 25), 210, 420))
+            L1 = L2 = 100
+            if kind == "short":
+                L1, L2 = int(rng.choice([76, 50, 100])), int(rng.choice([76, 50]))
+            start = int(rng.integers(0, len(g[contig]) - isize))
+            if kind == "dup":
+                contig, start = "chr1", int(rng.choice([5000, 30000])) + int(rng.integers(-250, 4900))
+            if kind == "rescue":
+                contig, start = "chr2", int(rng.integers(7700, 7990))
+                isize = int(rng.integers(330, 420))
+            if not clean(contig, start, isize):
+                continue
+            r1, r2 = frag_pair(contig, start, isize, L1, L2)
+            if kind == "proper":
+                r1, r2 = subs(r1, int(rng.integers(0, 3))), subs(r2, int(rng.integers(0, 3)))
+            elif kind == "sub":
+                r1, r2 = subs(r1, int(rng.integers(2, 5)), 34), subs(r2, int(rng.integers(2, 5)), 34)
+            elif kind == "diverged":                  # too many differences for aln: the end stays unmapped
+                r2 = subs(r2, int(rng.integers(9, 14)))
+            elif kind == "far":
+                start2 = int(rng.integers(0, len(g[contig]) - 100))
+                if not clean(contig, start2, 100) or abs(start2 - start) < 1500:
+                    continue
+                r2 = revcomp(g[contig][start2:start2 + 100]) if rng.random() < 0.7 else g[contig][start2:start2 + 100]
+            elif kind == "cross":
+                other = "chr2" if contig == "chr1" else ("chr3" if rng.random() < 0.3 else "chr1")
+                start2 = int(rng.integers(0, len(g[other]) - 100))
+                if not clean(other, start2, 100):
+                    continue
+                r2 = revcomp(g[other][start2:start2 + 100])
+            elif kind == "rescue":
+                # second end: chr1 version (chr1[5000+x]) of the chr2 copy window, with differences outside the seed
+                e2 = start + isize                    # fragment end on chr2, inside the copy 8000..10000
+                lo = e2 - 100
+                if lo < 8000 or e2 > 10000:
+                    continue
+                w1 = g["chr1"][5000 + lo - 8000: 5000 + e2 - 8000]
+                w2 = g["chr2"][lo:e2]
+                ndiv = sum(a != b for a, b in zip(w1, w2))
+                if ndiv < 1:
+                    continue
+                r2f = list(w1)
+                cand = [i for i in range(0, 66) if w1[i] == w2[i]]        # read 2 is the reverse complement: its seed is the window's tail
+                for p in rng.choice(cand, int(rng.integers(4, 6)), replace=False):
+                    r2f[p] = "ACGT"[("ACGT".index(r2f[p]) + 1 + int(rng.integers(0, 3))) % 4]
+                r2 = revcomp("".join(r2f))
+            elif kind == "gap":
+                p = int(rng.integers(36, 80)); d = int(rng.integers(1, 4))
+                if rng.random() < 0.5:
+                    r2 = r2[:p] + r2[p + d:] + "ACGTACGT"[:d]
+                else:
+                    r2 = (r2[:p] + "TGCA"[:d] + r2[p:])[:len(r2)]
+                r1 = subs(r1, int(rng.integers(0, 2)), 34)
+            elif kind == "junk":
+                r1 = "".join("ACGT"[i] for i in rng.integers(0, 4, 100))
+                r2 = "".join("ACGT"[i] for i in rng.integers(0, 4, 100))
+            if kind in ("proper", "sub") and rng.random() < 0.04:
+                r1 = r1[:50] + "N" + r1[51:]
+            add(kind, r1, r2)
+            made += 1
+    order = rng.permutation(len(pairs))
+    return [pairs[i] for i in order]
+
+
+PE_F = ("type", "strand", "n_mm", "n_gapo", "n_gape", "score", "sa", "c1", "c2", "pos", "mapQ", "seQ", "extra_flag", "n_cigar",
+        "nm", "n_multi", "len")
+
+
+def make_pe_chain(lib=None):
+    """The paired-end chain (bam2bam.c:683-811 / bwape.c:295-425,519-633 / bwase.c:356-423) on toy read pairs:
+    reads_pe_[12].fq, pe_[12].sai, pe_default.sam (the reference's `sampe`), vectors_pe_chain.npz (state of every end
+    after pass 1 and after pass 2 under three insert-size estimates: sampe's own, bam2bam's histogram one, none)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nabwa_testlib as T
+    if lib is None:
+        lib = C.CDLL(REFLIB)
+    rng = np.random.default_rng(4242)
+    pairs = make_pe_reads(rng, read_genome())
+    fq = [os.path.join(HERE, "reads_pe_%d.fq" % e) for e in (1, 2)]
+    sai = [os.path.join(HERE, "pe_%d.sai" % e) for e in (1, 2)]
+    for e in range(2):
+        with open(fq[e], "w") as f:
+            for n, r1, r2 in pairs:
+                s = (r1, r2)[e]
+                f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+        run([REFBIN, "aln", PREFIX, fq[e]], sai[e])
+    run([REFBIN, "sampe", PREFIX, sai[0], sai[1], fq[0], fq[1]], os.path.join(HERE, "pe_default.sam"))
+
+    P = C.c_void_p
+    lib.ref_index_load.restype = P
+    lib.ref_index_load.argtypes = [C.c_char_p, C.c_int]
+    lib.ref_pe_new.restype = P
+    lib.ref_pe_new.argtypes = [C.c_int]
+    lib.ref_pe_set.argtypes = [P, C.c_int, C.c_int, C.c_int, P, P, C.c_int, P]
+    lib.ref_pe_posn.argtypes = [P, P, P]
+    lib.ref_pe_finish.argtypes = [P, P, P, P]
+    lib.ref_pe_get.argtypes = [P, C.c_int, C.c_int, P, P, C.c_char_p, C.c_int, P]
+    lib.ref_pe_isize_pairs.argtypes = [P, C.c_double, C.c_int64, P]
+    lib.ref_pe_isize_pairs.restype = C.c_int
+    lib.ref_pe_free.argtypes = [P]
+    lib.ref_seed48.argtypes = [C.c_long]
+    ix = lib.ref_index_load(PREFIX.encode(), 1)
+    opt, alns = [], []
+    enc = []
+    for e in range(2):
+        o, a = T.read_sai(sai[e])
+        opt.append(o); alns.append(a)
+        enc.append(T.encode_reads(T.read_fastq(fq[e])))
+    n = len(pairs)
+    l_pac = sum(len(s) for _, s in read_genome())
+
+    def snapshot(b):
+        f = np.zeros((2 * n, 17), np.int64); cg = np.zeros((2 * n, 64), np.uint16); mu = np.zeros((2 * n, 16 * 21), np.int64)
+        md = []
+        buf = C.create_string_buffer(1024)
+        for i in range(n):
+            for e in range(2):
+                r = 2 * i + e
+                lib.ref_pe_get(b, i, e, f[r].ctypes.data_as(P), cg[r].ctypes.data_as(P), buf, 1024, mu[r].ctypes.data_as(P))
+                md.append(buf.value.decode())
+        return f, cg, mu, md
+
+    def chain(ii_mode):
+        b = lib.ref_pe_new(n)
+        for i in range(n):
+            for e in range(2):
+                seq, rseq, off, _ = enc[e]
+                a = alns[e][i]
+                s = np.ascontiguousarray(seq[off[i]:off[i + 1]]); rs = np.ascontiguousarray(rseq[off[i]:off[i + 1]])
+                av = np.ascontiguousarray(a).view(np.uint32) if len(a) else np.zeros(4, np.uint32)
+                lib.ref_pe_set(b, i, e, len(s), s.ctypes.data_as(P), rs.ctypes.data_as(P), len(a), av.ctypes.data_as(P))
+        lib.ref_seed48(11)
+        lib.ref_pe_posn(b, ix, C.byref(opt[1]))
+        posn = snapshot(b)
+        ii = np.zeros(6, np.float64)
+        if ii_mode == "sampe":
+            lib.ref_pe_isize_pairs(b, C.c_double(1e-5), C.c_int64(l_pac), ii.ctypes.data_as(P))
+        elif ii_mode == "hist":
+            h = np.zeros(100000, np.uint16)
+            f = posn[0]
+            for i in range(n):
+                a, c = f[2 * i], f[2 * i + 1]
+                if a[0] in (1, 2) and c[0] in (1, 2) and a[10] >= 20 and c[10] >= 20:      # insert_size.c:141-165
+                    d = c[9] + c[16] - a[9] if a[9] < c[9] else a[9] + a[16] - c[9]
+                    if 0 <= d < 100000:
+                        h[d] += 1
+            lib.ref_infer_isize(h.ctypes.data_as(P), C.c_double(1e-5), C.c_int64(l_pac), ii.ctypes.data_as(P))
+        lib.ref_pe_finish(b, ix, C.byref(opt[1]), ii.ctypes.data_as(P))
+        fin = snapshot(b)
+        lib.ref_pe_free(b)
+        return posn, ii, fin
+
+    out = {}
+    for mode in ("sampe", "hist", "null"):
+        posn, ii, fin = chain(mode)
+        if mode == "sampe":
+            out["posn_f"] = posn[0]
+        out["ii_" + mode] = ii
+        out["f_" + mode], out["cig_" + mode], out["multi_" + mode] = fin[0], fin[1], fin[2]
+        out["md_" + mode] = np.array(fin[3])
+        print("pe chain [%s] ii=%s  types=%s  FPP=%d  MATESW=%d" % (mode, ii, np.bincount(fin[0][:, 0], minlength=4),
+              int((fin[0][:, 12] & 2).astype(bool).sum()), int((fin[0][:, 0] == 3).sum())))
+    check_against_sampe(T, out, read_genome(), pairs)
+    np.savez_compressed(os.path.join(HERE, "vectors_pe_chain.npz"), **out)
+
+
+def check_against_sampe(T, out, contigs, pairs):
+    """The harness chain under sampe's own insert-size estimate must reproduce what the reference's `sampe` printed."""
+    sam = T.parse_sam(os.path.join(HERE, "pe_default.sam"))
+    f, cg, md = out["f_sampe"], out["cig_sampe"], out["md_sampe"]
+    offs = np.cumsum([0] + [len(s) for _, s in contigs])
+    assert len(sam) == len(f), (len(sam), len(f))
+    bad = 0
+    for r, rec in enumerate(sam):
+        if f[r][0] == 0:
+            continue
+        pos = int(f[r][9])
+        sid = int(np.searchsorted(offs, pos, side="right") - 1)
+        cig = "".join("%d%s" % (c & 0x3fff, "MIDS"[c >> 14]) for c in cg[r][:f[r][13]]) or "%dM" % f[r][16]
+        ok = (rec["rname"] == contigs[sid][0] and rec["pos"] == pos - offs[sid] + 1 and rec["cigar"] == cig
+              and rec["tags"].get("MD") == md[r] and rec["tags"].get("NM") == f[r][14] and bool(rec["flag"] & 2) == bool(f[r][12] & 2)
+              and rec["tags"].get("SM") == f[r][11])
+        if not (rec["flag"] & 4):
+            ok = ok and rec["mapq"] == f[r][10]
+        if not ok:
+            bad += 1
+            print("MISMATCH", r, rec, f[r], cig, md[r])
+    assert bad == 0, "%d records differ from the reference's sampe output" % bad
+    print("harness chain == reference sampe output on", len(sam), "records")
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pe_chain":
+        make_pe_chain()
+    else:
+        main()

@@ -140,7 +140,7 @@ def parse_sam(path):
             k, ty, v = t.split(":", 2)
             tags[k] = int(v) if ty == "i" else v
         recs.append(dict(name=f[0], flag=int(f[1]), rname=f[2], pos=int(f[3]), mapq=int(f[4]), cigar=f[5],
-                         seq=f[9], qual=f[10], tags=tags))
+                         rnext=f[6], pnext=int(f[7]), tlen=int(f[8]), seq=f[9], qual=f[10], tags=tags))
     return recs
 
 
