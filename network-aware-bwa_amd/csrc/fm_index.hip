@@ -107,3 +107,27 @@ extern "C" void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uin
 	if (n <= 0) return;
 	hipLaunchKernelGGL(occ4_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *B, n, k, out);
 }
+
+// Interval table, one level per launch: level t holds the SA interval of every string of t symbols (key = symbols
+// as base-4 digits, first consumed symbol most significant), computed from its parent at level t-1 by one backward
+// step with the search's own recurrences (bwt.c:237-252): k' = C(c) + Occ(c, k-1) + 1, l' = C(c) + Occ(c, l).
+__global__ __launch_bounds__(256) void kmer_level_kernel(DevBwt B, const uint2 *__restrict__ prev, uint2 *__restrict__ cur, uint32_t n_cur)
+{
+	const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+	if (idx >= n_cur) return;
+	uint2 par = prev ? prev[idx >> 2] : make_uint2(0u, B.seq_len);
+	uint2 out = make_uint2(1u, 0u);
+	if (par.x <= par.y) {
+		const uint32_t c = idx & 3u;
+		Occ4 ck, cl;
+		nabwa_occ4_pair(B, par.x - 1u, par.y, ck, cl);
+		out.x = B.L2[c] + ck.c[c] + 1u; out.y = B.L2[c] + cl.c[c];
+		if (out.x > out.y) out = make_uint2(1u, 0u);
+	}
+	cur[idx] = out;
+}
+
+extern "C" void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s)
+{
+	hipLaunchKernelGGL(kmer_level_kernel, dim3((n_cur + 255) / 256), dim3(256), 0, s, *B, prev, cur, n_cur);
+}

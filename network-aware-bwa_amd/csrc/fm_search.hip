@@ -45,6 +45,8 @@
 #define STATE_M 0
 #define STATE_I 1
 #define STATE_D 2
+#define STATE_GROUP 3   // arena only: the gap children of one expansion, see fm_search_kernel
+#define GRP_EXT 0x100u
 
 // bucket touches the REFERENCE algorithm performs for one (k-1, l) query: one per
 // bwt_occ / bwt_occ4 body execution, one for a same-128-row-block pair (bwt.c:92-216)
@@ -252,8 +254,14 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 
 	int st = LS_IDLE;
 	// per-read
-	uint32_t item = 0; int len = 0, md_read = 0, mg_read = 0; const uint8_t *sq0 = 0, *sq1 = 0;
-	uint8_t *rec = 0;                                       // this read's width record (kernel W)
+	uint32_t item = 0, rid_w = 0; int len = 0; uint32_t mdmg = 0;   // mdmg: this read's max_diff | max_gapo << 8
+	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
+	// the few reads of the second pass carry no LDS: they walk every tail step by step
+	const int KT = WIDE ? 0 : (int)P.bwt[0].kmer_T;         // 0 also in the touch-counting run
+#define RID (WIDE ? rid_w : item)                           /* the first pass takes reads in batch order (P.ids == 0) */
+#define REC (P.wdata + (size_t)RID * P.wstride)            /* this read's width record (kernel W) */
+#define MD_READ ((int)(mdmg & 0xffu))
+#define MG_READ ((int)(mdmg >> 8))
 	// current interval
 	uint32_t k = 0, l = 0;
 	// search globals
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;          // 16 bound bytes of strand bw_a from bw_base
 	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;          // same for the seed bounds
 	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
-	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0;
+	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0;
 	bool ovf = false;
 
 	auto head_get = [&](int score) -> uint32_t {
@@ -301,8 +309,34 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64);
 	};
 
+	// first pass only: the entry at the head of the lowest non-empty score list is fetched ahead of its pop while the
+	// lane walks an exact tail (a tail pushes nothing, so that head IS the next pop) and parked in LDS
+	uint4 *const s_pf = (uint4*)(s_head + (size_t)P.NS * NABWA_SEARCH_BLOCK);
+	uint2 *const s_key = (uint2*)(s_pf + NABWA_SEARCH_BLOCK);
+	uint32_t pf_slot = NIL;
+	bool finish = false;
+	// unpack a popped arena entry into the current-entry registers and unlink it (bwtgap.c:66-79)
+	auto take_entry = [&](const uint4 &r_ent, uint32_t r_lnk, uint32_t ent_slot) {
+		uint32_t nx;
+		k = r_ent.x; l = r_ent.y; e_i = (int)(r_ent.z & 0xffffu); e_ldp = (int)(r_ent.z >> 16);
+		if (WIDE) {
+			nx = r_lnk;
+			e_mm = (int)(r_ent.w & 0xffu); e_go = (int)(r_ent.w >> 8 & 0xffu); e_ge = (int)(r_ent.w >> 16 & 0xffu);
+			e_state = (int)(r_ent.w >> 24 & 3u); e_a = (int)(r_ent.w >> 26 & 1u);
+			freel[nfree++] = ent_slot;
+		} else {
+			nx = r_ent.w & 0xffffu;
+			e_mm = (int)(r_ent.w >> 16 & 15u); e_go = (int)(r_ent.w >> 20 & 15u); e_ge = (int)(r_ent.w >> 24 & 31u);
+			e_state = (int)(r_ent.w >> 29 & 3u); e_a = (int)(r_ent.w >> 31);
+		}
+		head_set(e_score, nx);
+		if (nx == NIL) { if (e_score < 64) mask_lo &= ~(1ull << e_score); else mask_hi &= ~(1ull << (e_score - 64)); }
+		--n_entries;
+		if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
+	};
+
 	for (;;) {
-		bool finish = false;
+		finish = false;
 		// ---------------------------------------------------------------- refill
 		unsigned long long need = __ballot(st == LS_IDLE);
 		if (P.sync_refill && __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull) need = 0ull;   // experiment: refill only when the whole wave is idle
@@ -317,16 +351,16 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					const uint32_t rid = P.ids ? (uint32_t)P.ids[idx] : idx;
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
-					sq0 = P.seq + o; sq1 = P.rseq + o;
-					rec = P.wdata + (size_t)rid * P.wstride;
-					md_read = P.rd_maxdiff[rid]; mg_read = P.rd_maxgapo[rid];
+					sq_off = (uint32_t)o; rid_w = rid;
+					mdmg = (uint32_t)P.rd_maxdiff[rid] | (uint32_t)P.rd_maxgapo[rid] << 8;
+					if (KT) s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 2 * (size_t)rid);   // interval-table keys of the two strands
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
-					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false;
-					if (len > 0 && (int)P.rd_nN[rid] <= md_read) {      // too many N: no search (bwtgap.c:118-123)
+					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false; pf_slot = NIL;
+					if (len > 0 && (int)P.rd_nN[rid] <= MD_READ) {      // too many N: no search (bwtgap.c:118-123)
 						// ---- start of bwt_match_gap (bwtgap.c:104-128)
 						seeded = len > P.seed_len;
-						max_diff = md_read;
-						best_score = (md_read + 1) * P.s_mm + (mg_read + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
+						max_diff = MD_READ;
+						best_score = (MD_READ + 1) * P.s_mm + (MG_READ + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
 						best_cnt = 0;
 						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
 						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
@@ -365,13 +399,36 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				} else {
 					if (p_valid) { push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a); p_valid = false; }
 					if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
-					else { ent_slot = head_get(best_mem); want_ent = true; e_score = best_mem; }
+					else {
+						ent_slot = head_get(best_mem); e_score = best_mem;
+						if (!WIDE && ent_slot == pf_slot) {                 // already here: pop it and go on in this trip
+							const uint4 r = s_pf[threadIdx.x];
+							take_entry(r, 0u, ent_slot);
+							pf_slot = NIL;
+							if (!finish) have = true;
+						} else want_ent = true;
+					}
 				}
 			}
 		}
 		// what this lane does with its current entry in this trip
-		int kind = 0;                 // 1 expand, 2 exact-tail step, 3 hit without query (i == 0)
+		int kind = 0;                 // 1 expand, 2 exact-tail step, 3 hit without query (i == 0), 4 tail jump, 5 group member
 		bool need_win = false, spec = false; int win_hi = 0;
+		int grp_c = 0;
+		if (have && !finish && e_state == STATE_GROUP) {
+			// pop ONE member of a gap group, newest first (deletion of T, G, C, A, then the insertion); the rest goes back
+			// on the stack it came from, where it is again the top
+			const uint32_t mk = (uint32_t)e_ldp & 0x1fu, ext = (uint32_t)e_ldp & GRP_EXT;
+			const int j = 31 - __clz((int)mk);
+			const uint32_t rest = mk & ~(1u << j);
+			if (rest) {
+				push_mem(e_score, k, l, e_i, (int)(rest | ext), e_mm, e_go, e_ge, STATE_GROUP, e_a);
+				if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
+			}
+			if (ext) ++e_ge; else ++e_go;
+			if (j == 0) { e_state = STATE_I; e_ldp = e_i; }                 // the insertion keeps the parent's interval
+			else { kind = 5; grp_c = j - 1; st = LS_POP; have = false; }    // a deletion: re-derive its interval
+		}
 		if (have && !finish) {
 			st = LS_POP;
 			m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
@@ -388,7 +445,13 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						if (m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) go = false;   // bwtgap.c:156
 					} else { need_win = true; spec = true; }
 					if (go) {
-						if (tail) { kind = 2; xt = e_i - 1; }       // nothing may differ any more: exact tail (bwt.c:237-252)
+						if (tail) {                                 // nothing may differ any more: exact tail (bwt.c:237-252)
+							kind = 2; xt = e_i - 1;
+							// tail jump: the path so far is the read's own last len-e_i symbols, at most one of them (the one
+							// just consumed) substituted, so the interval after KT symbols is one table entry away
+							if (KT && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i <= KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
+								&& (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu) kind = 4;
+						}
 						else { kind = 1; --e_i; }
 					}
 				}
@@ -399,7 +462,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		const int spos = kind == 2 ? xt : e_i;
 		const int stag = (e_a << 20) | (spos >> 4);
 		const bool need_seq = (kind == 1 || kind == 2) && stag != sq_tag;
-		bool query = kind == 1 || kind == 2;
+		bool query = kind == 1 || kind == 2 || kind == 5;
 		if (kind == 2 && !need_seq && byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u) > 3u) query = false;   // an N: no query
 		const int ii = e_i - (len - P.seed_len);
 		const bool use_seed = kind == 1 && e_i > 0 && seeded && ii > 0;
@@ -407,22 +470,33 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 
 		// ================================================================ phase 2: issue every load
 		uint4 r_ent = make_uint4(0, 0, 0, 0); uint32_t r_lnk = 0;
-		if (want_ent) { r_ent = ent[ent_slot]; if (WIDE) r_lnk = lnk[ent_slot]; }
+		if (WIDE && want_ent) { r_ent = ent[ent_slot]; r_lnk = lnk[ent_slot]; }
 		if (need_win) {
 			int base = (win_hi | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(rec + P.woff_bid + e_a * P.WLB + base);
+			const uint2 *p = (const uint2*)(REC + P.woff_bid + e_a * P.WLB + base);
 			const uint2 u = p[0], v = p[1];
 			WIN_SET(bw_lo, bw_hi, u.x, u.y, v.x, v.y); bw_base = base; bw_a = e_a;
 		}
 		if (need_seq) {
-			const uint4 q = *(const uint4*)((e_a ? sq1 : sq0) + (spos & ~15));
+			const uint4 q = *(const uint4*)((e_a ? P.rseq : P.seq) + sq_off + (spos & ~15));
 			WIN_SET(sqw_lo, sqw_hi, q.x, q.y, q.z, q.w); sq_tag = stag;
 		}
 		if (need_seed) {
 			int base = (ii | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(rec + P.woff_sbid + e_a * P.SLB + base);
+			const uint2 *p = (const uint2*)(REC + P.woff_sbid + e_a * P.SLB + base);
 			const uint2 u = p[0], v = p[1];
 			WIN_SET(sw_lo, sw_hi, u.x, u.y, v.x, v.y); sw_base = base; sw_a = e_a;
+		}
+		uint2 r_km = make_uint2(1u, 0u);
+		if (kind == 4) {
+			uint32_t key = e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x;
+			if (e_mm) {     // the substituted symbol is the one k was derived with: k lies in (C(c), C(c+1)]
+				const uint32_t c1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1], c2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], c3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
+				const uint32_t cs = (k > c1 ? 1u : 0u) + (k > c2 ? 1u : 0u) + (k > c3 ? 1u : 0u);
+				const uint32_t sh = 2u * (uint32_t)(KT - (len - e_i));
+				key = (key & ~(3u << sh)) | cs << sh;
+			}
+			r_km = (qb ? P.bwt[1].kmer : P.bwt[0].kmer)[key];
 		}
 		// the rank query: Occ of all four bases at rows k-1 and l of index qb (bwt.c:159-216 conventions)
 		uint4 a0, a1, a2, a3, b0, b1, b2, b3; uint32_t rk = 0, rl = 0; bool kvalid = false, two = false;
@@ -441,35 +515,32 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			if (two) { const uint4 *pk = bk + (size_t)bkk * 4; b0 = pk[0]; b1 = pk[1]; b2 = pk[2]; b3 = pk[3]; }
 		}
 
+		// look-ahead pop (see s_pf): only from inside a tail, with nothing pending in registers
+		bool pf_now = false; uint32_t pf_cand = NIL;
+		if (!WIDE) {
+			if (want_ent) { pf_cand = ent_slot; pf_now = true; }            // a pop that was not fetched ahead: fetch now, pop next trip
+			else if ((kind == 2 || kind == 4) && !p_valid && (mask_lo | mask_hi) != 0ull) {
+				const int bm = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1 : 64 + __ffsll((unsigned long long)mask_hi) - 1;
+				pf_cand = head_get(bm);
+				pf_now = pf_cand != pf_slot;
+			}
+			if (pf_now) r_ent = ent[pf_cand];
+		}
 		if (COUNT) {   // trip statistics (instrumented build only): [2] trips, [3..] lane-trips by activity
 			const unsigned long long bx = __ballot(kind == 1), be = __ballot(kind == 2), bm = __ballot(want_ent),
-				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT);
+				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT), bj = __ballot(kind == 4);
 			if (lane == 0) {
 				st_trips += 1; st_expand += __popcll(bx); st_exact += __popcll(be); st_ent += __popcll(bm); st_spec += __popcll(bs);
-				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi);
+				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi); st_jump += __popcll(bj);
 			}
 		}
 		asm volatile("" ::: "memory");   // keep every consumer below every load above (no block merging across)
 		// ================================================================ phase 3: consume
-		if (want_ent) {
-			uint32_t nx;
-			k = r_ent.x; l = r_ent.y; e_i = (int)(r_ent.z & 0xffffu); e_ldp = (int)(r_ent.z >> 16);
-			if (WIDE) {
-				nx = r_lnk;
-				e_mm = (int)(r_ent.w & 0xffu); e_go = (int)(r_ent.w >> 8 & 0xffu); e_ge = (int)(r_ent.w >> 16 & 0xffu);
-				e_state = (int)(r_ent.w >> 24 & 3u); e_a = (int)(r_ent.w >> 26 & 1u);
-				freel[nfree++] = ent_slot;
-			} else {
-				nx = r_ent.w & 0xffffu;
-				e_mm = (int)(r_ent.w >> 16 & 15u); e_go = (int)(r_ent.w >> 20 & 15u); e_ge = (int)(r_ent.w >> 24 & 31u);
-				e_state = (int)(r_ent.w >> 29 & 3u); e_a = (int)(r_ent.w >> 31);
-			}
-			head_set(e_score, nx);
-			if (nx == NIL) { if (e_score < 64) mask_lo &= ~(1ull << e_score); else mask_hi &= ~(1ull << (e_score - 64)); }
-			--n_entries;
-			if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
-			else st = LS_HAVE;                                                  // pre-checks + query in the next trip
+		if (WIDE && want_ent) {
+			take_entry(r_ent, r_lnk, ent_slot);
+			if (!finish) st = LS_HAVE;                                          // pre-checks + query in the next trip
 		}
+		if (pf_now) { s_pf[threadIdx.x] = r_ent; pf_slot = pf_cand; }
 		if (spec && m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) kind = 0;   // pruned after all (bwtgap.c:156)
 		int c = 4;
 		if (kind == 1 || kind == 2) c = (int)byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u);
@@ -479,7 +550,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (query && kind) {
 			cl = nabwa_count4(a0, a1, a2, a3, rl);
 			if (kvalid) ck = two ? nabwa_count4(b0, b1, b2, b3, rk) : nabwa_count4(a0, a1, a2, a3, rk);
-			if (COUNT) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);
+			if (COUNT && kind != 5) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);   // (the reference derived a group's members in the parent's query)
 		}
 		const uint32_t L2q0 = qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0], L2q1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1];
 		const uint32_t L2q2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], L2q3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
@@ -488,7 +559,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #define CK(cc) ((cc) == 0 ? ck.c[0] : ((cc) == 1 ? ck.c[1] : ((cc) == 2 ? ck.c[2] : ck.c[3])))
 #define CL(cc) ((cc) == 0 ? cl.c[0] : ((cc) == 1 ? cl.c[1] : ((cc) == 2 ? cl.c[2] : cl.c[3])))
 
-		if (kind == 2 || kind == 3) {
+		if (kind == 5) {                                        // the popped deletion: one more base of the reference, same read position
+			k = L2Q(grp_c) + CK(grp_c) + 1u; l = L2Q(grp_c) + CL(grp_c);
+			e_i += 1; e_state = STATE_D; e_ldp = e_i;
+			st = LS_HAVE;
+		} else if (kind == 4) {                                 // landed at depth KT (len > KT, so the tail goes on)
+			k = r_km.x; l = r_km.y;
+			if (k > l) st = LS_POP;
+			else { xt = len - KT - 1; st = LS_EXACT; }
+		} else if (kind == 2 || kind == 3) {
 			bool hit = false;
 			if (kind == 3) hit = true;
 			else if (c > 3) st = LS_POP;                          // an N in the tail: no match
@@ -506,7 +585,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				if (n_aln == 0) {
 					best_score = score;
 					const int best_diff = e_mm + e_go + (gape_mode ? e_ge : 0);
-					if (!nonstop) max_diff = best_diff + 1 > md_read ? md_read : best_diff + 1;
+					if (!nonstop) max_diff = best_diff + 1 > MD_READ ? MD_READ : best_diff + 1;
 				}
 				if (score == best_score) best_cnt += (int)(l - k + 1u);
 				else if (best_cnt > P.max_top2) { finish = true; do_add = false; }
@@ -520,6 +599,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						// gap_shadow (bwtgap.c:81-91) on this strand's bounds, positions < last_diff_pos;
 						// 8 positions per trip; the weq flags of positions 1..last_diff_pos are refreshed
 						const uint32_t x = l - k + 1u, mx = seqlen_q; uint32_t jj = 0, pw = 0;
+						uint8_t *const rec = REC;
 						uint32_t *const wp = (uint32_t*)rec + e_a * P.WL; uint8_t *const bp = rec + P.woff_bid + e_a * P.WLB;
 						for (int t0 = 0; t0 <= e_ldp && e_ldp > 0; t0 += 8) {
 							const uint4 w0 = *(const uint4*)(wp + t0), w1 = *(const uint4*)(wp + t0 + 4);
@@ -568,35 +648,32 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				}
 			}
 			// children go through a one-entry delay: the last one stays in registers as `pending`
-			auto emit = [&](int score, uint32_t nk, uint32_t nl, int ni, int nmm, int ngo, int nge, int nstate, bool is_diff) {
+			auto emit = [&](int score, uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int count) {
 				if (p_valid) push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a);
-				p_valid = true; p_k = nk; p_l = nl; p_i = ni; p_ldp = is_diff ? ni : 0;
+				p_valid = true; p_k = nk; p_l = nl; p_i = ni; p_ldp = nldp;
 				p_mm = nmm & 0xff; p_go = ngo & 0xff; p_ge = nge & 0xff; p_state = nstate; p_a = e_a; p_score = score;
-				++n_entries;
+				n_entries += count;
 			};
 			const int sc0 = e_mm * P.s_mm + e_go * P.s_gapo + e_ge * P.s_gape;
 			int tmp = e_go + e_ge;
 			if (loggap) { const uint32_t v = (uint32_t)(e_ge + e_go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
 			if (allow_diff && e_i >= P.indel_end_skip + tmp && len - e_i >= P.indel_end_skip + tmp) {
+				// The gap children of one expansion (an insertion and/or up to four deletions, bwtgap.c:216-240) share one
+				// score and are pushed back to back, i.e. they are ADJACENT in that score's stack.  They travel as one
+				// STATE_GROUP entry: the parent's interval and position plus a member mask (bit 0 the insertion, bit 1+j the
+				// deletion of base j, GRP_EXT: gap extension of a deletion rather than gap open); a member is materialised --
+				// the deletions by repeating the parent's rank query -- only if it is ever popped (see the pop side).  Most
+				// never are: once a hit exists, scores above best_score + s_mm end the search (bwtgap.c:144).
+				uint32_t dm = 0;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { const uint32_t nk = L2Q(j) + CK(j) + 1u, nl = L2Q(j) + CL(j); if (nk <= nl) dm |= 2u << j; }
 				if (e_state == STATE_M) {
-					if (e_go < mg_read) {
-						emit(sc0 + P.s_gapo, k, l, e_i, e_mm, e_go + 1, e_ge, STATE_I, true);
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const uint32_t nk = L2Q(j) + CK(j) + 1u, nl = L2Q(j) + CL(j);
-							if (nk <= nl) emit(sc0 + P.s_gapo, nk, nl, e_i + 1, e_mm, e_go + 1, e_ge, STATE_D, true);
-						}
-					}
+					if (e_go < MG_READ) emit(sc0 + P.s_gapo, k, l, e_i, (int)(dm | 1u), e_mm, e_go, e_ge, STATE_GROUP, __popc(dm) + 1);
 				} else if (e_state == STATE_I) {
-					if (e_ge < P.max_gape) emit(sc0 + P.s_gape, k, l, e_i, e_mm, e_go, e_ge + 1, STATE_I, true);
+					if (e_ge < P.max_gape) emit(sc0 + P.s_gape, k, l, e_i, e_i, e_mm, e_go, e_ge + 1, STATE_I, 1);
 				} else if (e_ge < P.max_gape) {
-					if (e_ge + e_go < max_diff || occ < (uint32_t)P.max_del_occ) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const uint32_t nk = L2Q(j) + CK(j) + 1u, nl = L2Q(j) + CL(j);
-							if (nk <= nl) emit(sc0 + P.s_gape, nk, nl, e_i + 1, e_mm, e_go, e_ge + 1, STATE_D, true);
-						}
-					}
+					if ((e_ge + e_go < max_diff || occ < (uint32_t)P.max_del_occ) && dm)
+						emit(sc0 + P.s_gape, k, l, e_i, (int)(dm | GRP_EXT), e_mm, e_go, e_ge, STATE_GROUP, __popc(dm));
 				}
 			}
 			if (allow_diff && allow_M) {
@@ -604,11 +681,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				for (int j = 1; j <= 4; ++j) {
 					const int cc = (c + j) & 3; const bool is_mm = (j != 4 || c > 3);
 					const uint32_t nk = L2Q(cc) + CK(cc) + 1u, nl = L2Q(cc) + CL(cc);
-					if (nk <= nl) emit(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, is_mm);
+					if (nk <= nl) emit(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, is_mm ? e_i : 0, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, 1);
 				}
 			} else if (c < 4) {
 				const uint32_t nk = L2Q(c) + CK(c) + 1u, nl = L2Q(c) + CL(c);
-				if (nk <= nl) emit(sc0, nk, nl, e_i, e_mm, e_go, e_ge, STATE_M, false);
+				if (nk <= nl) emit(sc0, nk, nl, e_i, 0, e_mm, e_go, e_ge, STATE_M, 1);
 			}
 			if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 		}
@@ -628,11 +705,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			atomicAdd(P.touch_counter, touches);
 			atomicAdd(P.touch_counter + 2, st_trips); atomicAdd(P.touch_counter + 3, st_expand); atomicAdd(P.touch_counter + 4, st_exact);
 			atomicAdd(P.touch_counter + 5, st_ent); atomicAdd(P.touch_counter + 6, st_spec); atomicAdd(P.touch_counter + 7, st_query);
-			atomicAdd(P.touch_counter + 8, st_two); atomicAdd(P.touch_counter + 9, st_exit);
+			atomicAdd(P.touch_counter + 8, st_two); atomicAdd(P.touch_counter + 9, st_exit); atomicAdd(P.touch_counter + 10, st_jump);
 		}
 	}
 }
 
+#undef RID
+#undef REC
+#undef MD_READ
+#undef MG_READ
 extern "C" void nabwa_launch_fm_width(const SearchParams *P, int n_blocks, hipStream_t s)
 {
 	if (P->touch_counter) hipLaunchKernelGGL((fm_width_kernel<true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), 0, s, *P);
@@ -647,7 +728,7 @@ extern "C" int nabwa_width_occupancy(void)
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
 {
-	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2;
+	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 24;
 	if (P->touch_counter) {
 		if (wide) hipLaunchKernelGGL((fm_search_kernel<true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
 		else hipLaunchKernelGGL((fm_search_kernel<false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
@@ -660,14 +741,16 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 	int nb = 0;
 	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<true, false>, NABWA_SEARCH_BLOCK, 0)
 						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false, false>, NABWA_SEARCH_BLOCK,
-																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2);
+																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 24);
 	return e == hipSuccess ? nb : 0;
 }
 
-// re-lay the reads out with every read starting on a 16-byte boundary (register windows load 16 bases)
+// re-lay the reads out with every read starting on a 16-byte boundary (register windows load 16 bases), and form
+// the interval-table keys: the first T symbols the search consumes (positions len-1 down to len-T) of each strand
 __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ rseq,
 													const int64_t *__restrict__ off, const int64_t *__restrict__ poff,
-													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len)
+													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len,
+													uint32_t *__restrict__ rd_key, int T)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
@@ -675,13 +758,25 @@ __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__
 	const int L = (int)(off[i + 1] - o), PL = (int)(poff[i + 1] - p);
 	rd_len[i] = L;
 	for (int j = 0; j < PL; ++j) { pseq[p + j] = j < L ? seq[o + j] : 4; prseq[p + j] = j < L ? rseq[o + j] : 4; }
+	uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+	if (T > 0 && L > T) {
+		uint32_t a = 0, b = 0; bool oka = true, okb = true;
+		for (int t = 1; t <= T; ++t) {
+			const uint32_t x = seq[o + L - t], y = rseq[o + L - t];
+			oka = oka && x < 4u; okb = okb && y < 4u;
+			a = a << 2 | (x & 3u); b = b << 2 | (y & 3u);
+		}
+		if (oka) k0 = a;
+		if (okb) k1 = b;
+	}
+	rd_key[2 * (size_t)i] = k0; rd_key[2 * (size_t)i + 1] = k1;
 }
 
 extern "C" void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, hipStream_t s)
+									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len);
+	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T);
 }
 
 // ids of the reads whose first pass was abandoned (arena or hit list outgrown)

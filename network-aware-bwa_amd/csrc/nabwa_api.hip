@@ -14,6 +14,7 @@
 
 extern "C" {
 void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets, uint4 *out, hipStream_t s);
+void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s);
 void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s);
@@ -31,7 +32,7 @@ void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, c
 						 uint4 *out, hipStream_t s);
 int nabwa_search_occupancy(int wide, int ns);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, hipStream_t s);
+							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -81,13 +82,13 @@ extern "C" int nabwa_cal_maxdiff(int l, double err, double thres)
 
 /* ------------------------------------------------------------------ index */
 
-static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_words, bool on_device,
+static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_words, bool on_device,
 					 const uint32_t *sa_words, uint64_t n_sa_words)
 {
 	uint32_t hdr[5];
 	if (n_words < 5) return fail(NABWA_EIO, "bwt array too short");
 	if (on_device) HIPCHK(hipMemcpy(hdr, words, 20, hipMemcpyDeviceToHost)); else memcpy(hdr, words, 20);
-	DevBwt &B = ix->bwt[t];
+	DevBwt &B = ix->bwt[t_];
 	memset(&B, 0, sizeof(B));
 	B.primary = hdr[0]; B.L2[0] = 0; B.L2[1] = hdr[1]; B.L2[2] = hdr[2]; B.L2[3] = hdr[3]; B.seq_len = hdr[4];
 	/* (seq_len+15)/16 BWT words plus (seq_len+127)/128+1 checkpoints of 4 words (bwtmisc.c:130-131) */
@@ -101,13 +102,35 @@ static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_w
 		HIPCHK(hipMemcpy(raw, words + 5, (n_words - 5) * 4, hipMemcpyHostToDevice));
 		src = raw;
 	}
-	HIPCHK(hipMalloc(&ix->bk[t], (size_t)B.n_buckets * 64));
-	nabwa_launch_repack(src, B.seq_len, B.n_buckets, ix->bk[t], 0);
+	HIPCHK(hipMalloc(&ix->bk[t_], (size_t)B.n_buckets * 64));
+	nabwa_launch_repack(src, B.seq_len, B.n_buckets, ix->bk[t_], 0);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipDeviceSynchronize());
 	if (raw) HIPCHK(hipFree(raw));
-	B.bk = ix->bk[t];
+	B.bk = ix->bk[t_];
 	ix->bytes += (uint64_t)B.n_buckets * 64;
+	{	/* interval table for the tail jump: T = floor(log4(seq_len)), at most 15, unless NABWA_KMER_T says otherwise (0 = off) */
+		int T = 0;
+		for (uint64_t x = B.seq_len; x >= 4; x >>= 2) ++T;          /* floor(log4 n): about one row per key at the last level */
+		const char *e = getenv("NABWA_KMER_T");
+		if (e) T = atoi(e);
+		if (T > 15) T = 15;
+		if (T >= 1) {
+			size_t total = 0;
+			for (int t = 1; t <= T; ++t) total += (size_t)1 << (2 * t);
+			HIPCHK(hipMalloc(&ix->kmer[t_], total * 8));
+			uint2 *prev = 0, *cur = ix->kmer[t_];
+			for (int t = 1; t <= T; ++t) {
+				const uint32_t n_cur = 1u << (2 * t);
+				nabwa_launch_kmer_level(&B, prev, cur, n_cur, 0);
+				prev = cur; cur += n_cur;
+			}
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipDeviceSynchronize());
+			B.kmer = prev; B.kmer_T = (uint32_t)T;
+			ix->bytes += total * 8;
+		}
+	}
 	if (sa_words) {
 		uint32_t sh[7];
 		if (n_sa_words < 7) return fail(NABWA_EIO, "sa array too short");
@@ -116,11 +139,11 @@ static int build_one(nabwa_index *ix, int t, const uint32_t *words, uint64_t n_w
 		B.sa_intv = sh[5];
 		B.n_sa = (uint32_t)(((uint64_t)B.seq_len + B.sa_intv) / B.sa_intv);
 		if (n_sa_words - 7 < (uint64_t)B.n_sa - 1) return fail(NABWA_EIO, "sa array shorter than n_sa");
-		HIPCHK(hipMalloc(&ix->sa[t], (size_t)B.n_sa * 4));
-		HIPCHK(hipMemset(ix->sa[t], 0xff, 4));
-		HIPCHK(hipMemcpy(ix->sa[t] + 1, sa_words + 7, (size_t)(B.n_sa - 1) * 4,
+		HIPCHK(hipMalloc(&ix->sa[t_], (size_t)B.n_sa * 4));
+		HIPCHK(hipMemset(ix->sa[t_], 0xff, 4));
+		HIPCHK(hipMemcpy(ix->sa[t_] + 1, sa_words + 7, (size_t)(B.n_sa - 1) * 4,
 						 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-		B.sa = ix->sa[t];
+		B.sa = ix->sa[t_];
 		ix->bytes += (uint64_t)B.n_sa * 4;
 	}
 	return NABWA_OK;
@@ -134,7 +157,7 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
-	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->bytes = 0; ix->ref = 0;
+	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
 	if (r == NABWA_OK) r = build_one(ix, 1, bwt1, nw1, is_device != 0, sa1, ns1);
@@ -178,7 +201,7 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 {
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
-	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); }
+	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]); }
 	delete ix->ref;
 	delete ix;
 }
@@ -196,7 +219,7 @@ struct nabwa_batch {
 	hipEvent_t ev0, ev1, evw;
 	float last_ms;
 	// device inputs
-	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; int max_len;
+	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; uint32_t *d_key; int max_len;
 	// first pass
 	SearchParams P; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
@@ -237,7 +260,7 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->ix->device);
-	void *ptrs[] = { b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+	void *ptrs[] = { b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -295,10 +318,11 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	poff[0] = 0;
 	for (int i = 0; i < n; ++i) poff[i + 1] = poff[i] + ((off[i + 1] - off[i] + 15) / 16) * 16;
 	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1, pnb = (size_t)poff[n] + 64;
+	if ((uint64_t)pnb >= (1ull << 32)) { nabwa_batch_destroy(b); return fail(NABWA_EINVAL, "batch holds 4 Gi padded bases or more: split it (lane state keeps a 32-bit read offset)"); }
 	b->max_len = max_len;
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
-	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1));
+	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 8));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
@@ -306,7 +330,8 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		BCHK(hipMemcpy(raw_s, seq, (size_t)off[n], hipMemcpyHostToDevice));
 		BCHK(hipMemcpy(raw_r, rseq, (size_t)off[n], hipMemcpyHostToDevice));
 		BCHK(hipMemcpy(raw_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
-		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->stream);
+		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->d_key,
+							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, b->stream);
 		BCHK(hipStreamSynchronize(b->stream));
 		BCHK(hipFree(raw_s)); BCHK(hipFree(raw_r)); BCHK(hipFree(raw_off));
 		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));
@@ -316,7 +341,8 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	SearchParams &P = b->P;
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
-	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg;
+	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key;
+	if (ix->bwt[0].kmer_T != ix->bwt[1].kmer_T) P.bwt[0].kmer_T = P.bwt[1].kmer_T = 0;
 	P.ids = 0; P.n = n;
 	P.s_mm = opt->s_mm; P.s_gapo = opt->s_gapo; P.s_gape = opt->s_gape; P.mode = opt->mode;
 	P.indel_end_skip = opt->indel_end_skip; P.max_del_occ = opt->max_del_occ; P.max_entries = opt->max_entries;
@@ -445,9 +471,15 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	HIPCHK(hipSetDevice(b->ix->device));
 	HIPCHK(hipMemsetAsync(b->d_sum, 0, 128, b->stream));
 	b->P.touch_counter = b->d_sum;
+	/* the reference walks every exact tail row by row: count with the tail jump off (NABWA_TRIP_STATS=jump keeps it
+	 * on to profile the production trips; the touch totals are then not the reference's) */
+	const uint32_t kt0 = b->P.bwt[0].kmer_T, kt1 = b->P.bwt[1].kmer_T;
+	const char *ts = getenv("NABWA_TRIP_STATS");
+	if (!(ts && strcmp(ts, "jump") == 0)) b->P.bwt[0].kmer_T = b->P.bwt[1].kmer_T = 0;
 	int r = nabwa_batch_run(b);
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
 	b->P.touch_counter = 0;
+	b->P.bwt[0].kmer_T = kt0; b->P.bwt[1].kmer_T = kt1;
 	if (r != NABWA_OK) return r;
 	unsigned long long v[2] = { 0, 0 };
 	HIPCHK(hipMemcpy(v, b->d_sum, 16, hipMemcpyDeviceToHost));
@@ -456,8 +488,8 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	if (getenv("NABWA_TRIP_STATS")) {
 		unsigned long long t[16];
 		HIPCHK(hipMemcpy(t, b->d_sum, 128, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu\n",
-				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu\n",
+				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10]);
 	}
 	return NABWA_OK;
 }

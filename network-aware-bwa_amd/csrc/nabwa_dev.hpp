@@ -1,5 +1,9 @@
 // nabwa_dev.hpp -- device-side FM-index layout and rank primitives (gfx950).
 //
+// Beside the buckets each index carries an interval table for all 4^T strings of T symbols (T ~ log4(n) - 2),
+// which lets an exact tail that starts within T symbols of the read end jump to depth T with ONE 8-byte load
+// instead of up to T dependent rank queries (fm_search.hip, "tail jump").
+//
 // HBM layout of one FM-index ("bucket array"): 64-byte buckets, 64-byte aligned, each
 // covering NABWA_INTV = 192 consecutive rows of the $-removed BWT string B0:
 //
@@ -21,8 +25,10 @@ struct DevBwt {
 	const uint32_t *sa;     // SA samples, sa[j] = SA[j*sa_intv]; sa[0] is never read (bwt.c:80)
 	uint32_t primary, seq_len, n_sa, sa_intv;
 	uint32_t L2[4];         // cumulative base counts C(c)
-	uint32_t n_buckets, pad;
-};
+	uint32_t n_buckets;
+	uint32_t kmer_T;        // 0: no table.  Otherwise kmer[key] = SA interval {k, l} (k > l: empty) of the string whose
+	const uint2 *kmer;      // T symbols, in the order the backward search consumes them, are the base-4 digits of key
+};                          // (first consumed symbol = most significant digit); built at load time (fm_index.hip)
 
 struct Occ4 { uint32_t c[4]; };
 
