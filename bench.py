@@ -72,9 +72,10 @@ def main():
     t0 = time.time()
     n = args.genome_len
     d_text = synth.synth_text(n, 20261004, n_dup=2000, dup_len=5000, device=dev)
-    parts = [synth.build_index(d_text, n, rev, 32, False, device=dev, verbose=(rank == 0)) for rev in (0, 1)]
-    ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]), device=dev,
-                                 device_ptrs=True)
+    # with the SA samples (.sa/.rsa content): the index derives its full SA / inverse / text from them (text mode)
+    parts = [synth.build_index(d_text, n, rev, 32, True, device=dev, verbose=(rank == 0)) for rev in (0, 1)]
+    ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]),
+                                 (parts[0][2].ptr, parts[0][3]), (parts[1][2].ptr, parts[1][3]), device=dev, device_ptrs=True)
     if rank == 0:
         log("index: %d bp x2 FM-indexes built on GPU + re-packed in %.1f s (%.2f GB in HBM)"
             % (n, time.time() - t0, ix.device_bytes() / 1e9))
@@ -84,6 +85,7 @@ def main():
         host_bwt = [p[0].to_host(np.uint32, p[1]) for p in parts]
     for p in parts:
         p[0].free()
+        p[2].free()
 
     # reads: this rank's shard (seeded by rank)
     seq, rseq, off = synth.synth_reads(d_text, n, args.reads, args.read_len, args.sub_ppm, 0, 2 + 1000 * rank, device=dev)

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void sa_lookup_kernel(DevBwt B0, DevBwt B1, in
 	const uint32_t L0 = w1 ? B1.L2[0] : B0.L2[0], L1 = w1 ? B1.L2[1] : B0.L2[1];
 	const uint32_t L2_ = w1 ? B1.L2[2] : B0.L2[2], L3 = w1 ? B1.L2[3] : B0.L2[3];
 	uint32_t k = kin[idx], steps = 0;
+	const uint32_t *full = w1 ? B1.sa_full : B0.sa_full;
+	if (full) { out[idx] = full[k]; return; }
 	while (k % intv != 0) {
 		++steps;
 		if (k == primary) { k = 0; continue; }
@@ -130,4 +132,51 @@ __global__ __launch_bounds__(256) void kmer_level_kernel(DevBwt B, const uint2 *
 extern "C" void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s)
 {
 	hipLaunchKernelGGL(kmer_level_kernel, dim3((n_cur + 255) / 256), dim3(256), 0, s, *B, prev, cur, n_cur);
+}
+
+// Full suffix array, its inverse and the text from the BWT and the row-sampled SA (bwt.c:72-81 is the per-row
+// walk this replaces).  One thread per SAMPLED row r (SA value v): LF(r) is the row of the suffix one position
+// to the left, so walking LF hands out v-1, v-2, ... until the next sampled row, and the BWT character met at each
+// row is the text base at that position.  LF is one cycle over all rows, so every row and every text position is
+// written exactly once (row 0 stands for the empty suffix, position seq_len; LF(primary) = 0, bwt.h:71-75).
+__global__ __launch_bounds__(256) void sa_fill_kernel(DevBwt B, uint32_t *__restrict__ sa_full, uint32_t *__restrict__ isa,
+												  uint8_t *__restrict__ text_bytes)
+{
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= B.n_sa) return;
+	uint32_t row = j * B.sa_intv, v = j ? B.sa[j] : B.seq_len;
+	sa_full[row] = j ? v : 0xffffffffu;
+	isa[v] = row;
+	for (;;) {
+		if (row == B.primary) break;                          // the whole text: nothing to its left (LF = row 0, sampled)
+		const uint32_t kp = row - (row > B.primary ? 1u : 0u);
+		const uint32_t b = kp / NABWA_INTV, r = kp - b * NABWA_INTV;
+		const uint4 *p = B.bk + (size_t)b * 4;
+		const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+		const uint32_t c = nabwa_base_at(q1, q2, q3, r);
+		const Occ4 o = nabwa_count4(q0, q1, q2, q3, r);
+		v -= 1u;
+		text_bytes[v] = (uint8_t)c;
+		row = B.L2[c] + o.c[c];
+		if (row % B.sa_intv == 0u) break;                     // that row's own thread takes over
+		sa_full[row] = v; isa[v] = row;
+	}
+}
+
+__global__ __launch_bounds__(256) void text_pack_kernel(const uint8_t *__restrict__ bytes, uint32_t n, uint32_t n_words, uint32_t *__restrict__ out)
+{
+	const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+	if (w >= n_words) return;
+	uint32_t x = 0;
+	for (uint32_t t = 0; t < 16u; ++t) { const uint64_t j = (uint64_t)w * 16u + t; if (j < n) x |= (uint32_t)(bytes[j] & 3u) << (2u * t); }
+	out[w] = x;
+}
+
+extern "C" void nabwa_launch_sa_fill(const DevBwt *B, uint32_t *sa_full, uint32_t *isa, uint8_t *text_bytes, hipStream_t s)
+{
+	hipLaunchKernelGGL(sa_fill_kernel, dim3((B->n_sa + 255) / 256), dim3(256), 0, s, *B, sa_full, isa, text_bytes);
+}
+extern "C" void nabwa_launch_text_pack(const uint8_t *bytes, uint32_t n, uint32_t n_words, uint32_t *out, hipStream_t s)
+{
+	hipLaunchKernelGGL(text_pack_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, bytes, n, n_words, out);
 }

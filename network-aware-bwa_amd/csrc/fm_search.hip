@@ -93,13 +93,21 @@ extern __shared__ uint16_t s_head[];   // search kernel, first pass only: [score
 //   SBd[2][SLB] the same for the seed passes
 // =====================================================================================
 template <bool COUNT>
-__global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const SearchParams P)
+__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const SearchParams P)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	bool run = false, done = false;
 	uint32_t rid = 0; int len = 0, phase = 0, wi = 0, n = 0, sbase = 0, nN = 0;
-	const uint8_t *sq[2] = { 0, 0 }; uint8_t *rec = 0;
+	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
+#define WREC (P.wdata + (size_t)rid * P.wstride)
+	// text mode (nabwa_dev.hpp): pass x has narrowed to ONE row, the suffix at text position tp[x]; the next symbol
+	// matches iff it equals the text base in front of it, and the width stays 1 (kk == ll is kept as it is)
+	uint32_t tmode = 0, tp[2] = { 0, 0 }, twtag[2] = { 0xffffffffu, 0xffffffffu }; uint2 twin[2];
+	twin[0] = twin[1] = make_uint2(0u, 0u);
+	const bool text_ok = !COUNT && P.bwt[0].sa_full && P.bwt[1].sa_full;
 	uint32_t kk[2] = { 0, 0 }, ll[2] = { 0, 0 }, pw[2] = { 0, 0 }; int bid[2] = { 0, 0 };
+	uint32_t wkey[2] = { 0xffffffffu, 0xffffffffu }; bool tok = false;   // interval-table keys of this phase's first KT symbols
+	const int KT = (int)P.bwt[0].kmer_T;
 	uint4 wacc[2]; uint64_t blo[2] = { 0, 0 }, bhi[2] = { 0, 0 }, slo[2] = { 0, 0 }, shi[2] = { 0, 0 }; int stag[2] = { -1, -1 };
 	unsigned long long touches = 0;
 	wacc[0] = wacc[1] = make_uint4(0, 0, 0, 0);
@@ -116,11 +124,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 					rid = P.ids ? (uint32_t)P.ids[idx] : idx;
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
-					sq[0] = P.seq + o; sq[1] = P.rseq + o;
-					rec = P.wdata + (size_t)rid * P.wstride;
+					sq_off = (uint32_t)o;
 					nN = 0; stag[0] = stag[1] = -1;
 					if (len > 0) {
-						run = true; phase = 0; wi = 0; n = len; sbase = 0;
+						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = 0;
+						if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 2); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
 #pragma unroll
 						for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; blo[x] = bhi[x] = 0; }
 					} else P.rd_nN[rid] = 0;
@@ -128,17 +136,66 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 			}
 		}
 		if (__ballot(!done) == 0ull) break;
-		if (run) {
+		// output of position p of both passes: width, bound byte, 16-byte chunk flushes; `last` = the terminator
+		// {w = 0, bid = ++bid} after the final position (bwtaln.c:73-74)
+		auto out_pos = [&](int p, bool last) {
+			uint8_t *const rec = WREC;
+			uint32_t *const wbase = (uint32_t*)rec;
+			uint8_t *const bbase = rec + (phase ? P.woff_sbid : P.woff_bid);
+			const uint32_t bstride = phase ? P.SLB : P.WLB;
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+				if (last) ++bid[x];
+				const uint32_t wv = last ? 0u : ll[x] - kk[x] + 1u;
+				const uint32_t bv = (uint32_t)(bid[x] > 127 ? 127 : bid[x]) | ((p > 0 && wv == pw[x]) ? 128u : 0u);
+				set_word(wacc[x], (uint32_t)p & 3u, wv);
+				{ const uint64_t sh = (uint64_t)bv << (((uint32_t)p & 7u) << 3); if (p & 8) bhi[x] |= sh; else blo[x] |= sh; }
+				pw[x] = wv;
+				if (phase == 0 && ((p & 3) == 3 || last)) *(uint4*)(wbase + x * P.WL + (p & ~3)) = wacc[x];
+				if ((p & 15) == 15 || last) {
+					*(uint4*)(bbase + x * bstride + (p & ~15)) = make_uint4((uint32_t)blo[x], (uint32_t)(blo[x] >> 32), (uint32_t)bhi[x], (uint32_t)(bhi[x] >> 32));
+					blo[x] = bhi[x] = 0;
+				}
+			}
+		};
+		if (run && tok && wi + 4 <= KT && wi + 4 < n) {
+			// table trip: the intervals after wi+1 .. wi+4 symbols of this phase are entries of levels wi+1 .. wi+4 of the
+			// interval table (fm_index.hip) -- eight independent 8-byte loads, the low levels cache-resident -- instead
+			// of four dependent rank queries per pass.  An empty entry is the reference's restart (bwtaln.c:66-70): from
+			// there on the prefix is no longer the read's, so the rest of the phase steps normally.
+			uint2 tv[2][4];
+#pragma unroll
+			for (int x = 0; x < 2; ++x) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int t = wi + u + 1;
+					const uint2 *lvl = P.bwt[x].kmer - (((1u << (2 * KT)) - (1u << (2 * t))) / 3u);
+					tv[x][u] = lvl[wkey[x] >> (2 * (KT - t))];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				bool dead = false;
+#pragma unroll
+				for (int x = 0; x < 2; ++x) {
+					kk[x] = tv[x][u].x; ll[x] = tv[x][u].y;
+					if (kk[x] > ll[x]) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; dead = true; }
+				}
+				out_pos(wi, false);
+				++wi;
+				if (dead) { tok = false; break; }
+			}
+		} else if (run) {
 			const int pos = sbase + wi;
 			int c[2]; Occ4 ck[2], cl[2];
 #pragma unroll
 			for (int x = 0; x < 2; ++x) {
 				const int tag = pos >> 4;
-				if (tag != stag[x]) { const uint4 q = *(const uint4*)(sq[x] + (pos & ~15)); WIN_SET(slo[x], shi[x], q.x, q.y, q.z, q.w); stag[x] = tag; }
+				if (tag != stag[x]) { const uint4 q = *(const uint4*)((x ? P.rseq : P.seq) + sq_off + (pos & ~15)); WIN_SET(slo[x], shi[x], q.x, q.y, q.z, q.w); stag[x] = tag; }
 				c[x] = (int)byte_of(slo[x], shi[x], (uint32_t)pos & 15u);
 			}
 			// issue the bucket loads of BOTH passes before consuming any (one memory latency per trip)
-			uint4 qa[2][4], qb[2][4]; uint32_t rk[2], rl[2]; bool kval[2], two[2];
+			uint4 qa[2][4], qb[2][4]; uint32_t rk[2], rl[2], sav[2]; bool kval[2], two[2];
 #pragma unroll
 			for (int x = 0; x < 2; ++x) {
 				const uint32_t primary = P.bwt[x].primary, kq = kk[x] - 1u, lq = ll[x];
@@ -147,7 +204,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 				kval[x] = kq != 0xffffffffu;
 				const uint32_t bkk = kval[x] ? kp / NABWA_INTV : bl; rk[x] = kp - bkk * NABWA_INTV;
 				two[x] = bkk != bl;
-				const bool q = c[x] < 4;
+				const bool q = c[x] < 4 && !(tmode >> x & 1u);
 				const uint4 *pl = P.bwt[x].bk + (size_t)bl * 4, *pk = P.bwt[x].bk + (size_t)bkk * 4;
 #pragma unroll
 				for (int u = 0; u < 4; ++u) { qa[x][u] = make_uint4(0, 0, 0, 0); qb[x][u] = make_uint4(0, 0, 0, 0); }
@@ -160,11 +217,18 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 					}
 					if (COUNT) touches += ref_touches(P.bwt[x], kq, lq, false);
 				}
+				// one row left: fetch its text position alongside this step's query (the step moves it one to the left)
+				sav[x] = 0u;
+				if (text_ok && q && kk[x] == ll[x]) sav[x] = P.bwt[x].sa_full[kk[x]];
+				if ((tmode >> x & 1u) && tp[x] > 0u && ((tp[x] - 1u) >> 5) != twtag[x]) {
+					twtag[x] = (tp[x] - 1u) >> 5;
+					twin[x] = *(const uint2*)(P.bwt[x].text + 2 * (size_t)twtag[x]);
+				}
 			}
 #pragma unroll
 			for (int x = 0; x < 2; ++x) {
 				ck[x].c[0] = ck[x].c[1] = ck[x].c[2] = ck[x].c[3] = 0; cl[x] = ck[x];
-				if (c[x] < 4) {
+				if (c[x] < 4 && !(tmode >> x & 1u)) {
 					cl[x] = nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rl[x]);
 					if (kval[x]) ck[x] = two[x] ? nabwa_count4(qb[x][0], qb[x][1], qb[x][2], qb[x][3], rk[x])
 											   : nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rk[x]);
@@ -173,6 +237,18 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 #pragma unroll
 			for (int x = 0; x < 2; ++x) {
 				const int cc = c[x];
+				if (tmode >> x & 1u) {
+					bool ok = cc < 4 && tp[x] > 0u;
+					if (ok) {
+						const uint32_t q = tp[x] - 1u, wd = (q & 16u) ? twin[x].y : twin[x].x;
+						ok = (wd >> ((q & 15u) << 1) & 3u) == (uint32_t)cc;
+						if (ok) tp[x] = q;
+					}
+					if (cc > 3 && x == 0 && phase == 0) ++nN;
+					if (!ok) { tmode &= ~(1u << x); kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; }   // the restart of bwtaln.c:66-70
+					continue;
+				}
+				const bool was_one = text_ok && cc < 4 && kk[x] == ll[x];
 				if (cc < 4) {
 					const uint32_t L2c = cc == 0 ? P.bwt[x].L2[0] : (cc == 1 ? P.bwt[x].L2[1] : (cc == 2 ? P.bwt[x].L2[2] : P.bwt[x].L2[3]));
 					const uint32_t ok = cc == 0 ? ck[x].c[0] : (cc == 1 ? ck[x].c[1] : (cc == 2 ? ck[x].c[2] : ck[x].c[3]));
@@ -180,35 +256,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 					kk[x] = L2c + ok + 1u; ll[x] = L2c + ol;
 				} else if (x == 0 && phase == 0) ++nN;
 				if (kk[x] > ll[x] || cc > 3) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; }
+				else if (was_one) { tmode |= 1u << x; tp[x] = sav[x] - 1u; twtag[x] = 0xffffffffu; }
 			}
-			uint32_t *const wbase = (uint32_t*)rec;
-			uint8_t *const bbase = rec + (phase ? P.woff_sbid : P.woff_bid);
-			const uint32_t bstride = phase ? P.SLB : P.WLB;
-			// position wi, and after the last one the terminator {w = 0, bid = ++bid} (bwtaln.c:73-74)
-			const bool at_end = wi + 1 == n;
-#pragma unroll
-			for (int rep = 0; rep < 2; ++rep) {
-				if (rep == 1 && !at_end) break;
-				const int p = wi + rep; const bool last = rep == 1;
-#pragma unroll
-				for (int x = 0; x < 2; ++x) {
-					if (last) ++bid[x];
-					const uint32_t wv = last ? 0u : ll[x] - kk[x] + 1u;
-					const uint32_t bv = (uint32_t)(bid[x] > 127 ? 127 : bid[x]) | ((p > 0 && wv == pw[x]) ? 128u : 0u);
-					set_word(wacc[x], (uint32_t)p & 3u, wv);
-					{ const uint64_t sh = (uint64_t)bv << (((uint32_t)p & 7u) << 3); if (p & 8) bhi[x] |= sh; else blo[x] |= sh; }
-					pw[x] = wv;
-					if (phase == 0 && ((p & 3) == 3 || last)) *(uint4*)(wbase + x * P.WL + (p & ~3)) = wacc[x];
-					if ((p & 15) == 15 || last) {
-						*(uint4*)(bbase + x * bstride + (p & ~15)) = make_uint4((uint32_t)blo[x], (uint32_t)(blo[x] >> 32), (uint32_t)bhi[x], (uint32_t)(bhi[x] >> 32));
-						blo[x] = bhi[x] = 0;
-					}
-				}
-			}
+			out_pos(wi, false);
+			if (wi + 1 == n) out_pos(wi + 1, true);
 			++wi;
 			if (wi == n) {
 				if (phase == 0 && len > P.seed_len) {
-					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len;
+					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = 0;
+					if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 4); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
 #pragma unroll
 					for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; }
 				} else { P.rd_nN[rid] = (uint8_t)(nN > 255 ? 255 : nN); run = false; }
@@ -219,6 +275,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK) void fm_width_kernel(const Sear
 		for (int o = 32; o > 0; o >>= 1) touches += __shfl_down(touches, o);
 		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter + 1, touches);
 	}
+#undef WREC
 }
 
 // =====================================================================================
@@ -353,7 +410,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o; rid_w = rid;
 					mdmg = (uint32_t)P.rd_maxdiff[rid] | (uint32_t)P.rd_maxgapo[rid] << 8;
-					if (KT) s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 2 * (size_t)rid);   // interval-table keys of the two strands
+					if (KT) s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 6 * (size_t)rid);   // interval-table keys of the two strands
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false; pf_slot = NIL;
 					if (len > 0 && (int)P.rd_nN[rid] <= MD_READ) {      // too many N: no search (bwtgap.c:118-123)
@@ -750,7 +807,7 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ rseq,
 													const int64_t *__restrict__ off, const int64_t *__restrict__ poff,
 													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len,
-													uint32_t *__restrict__ rd_key, int T)
+													uint32_t *__restrict__ rd_key, int T, int seed_len)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
@@ -758,25 +815,31 @@ __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__
 	const int L = (int)(off[i + 1] - o), PL = (int)(poff[i + 1] - p);
 	rd_len[i] = L;
 	for (int j = 0; j < PL; ++j) { pseq[p + j] = j < L ? seq[o + j] : 4; prseq[p + j] = j < L ? rseq[o + j] : 4; }
-	uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+	// keys (first consumed symbol = most significant digit): [0,1] kernel S, from position L-1 downwards, seq / rseq;
+	// [2,3] kernel W full passes, from position 0 upwards; [4,5] kernel W seed passes, from position L-seed_len upwards
+	uint32_t key[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
 	if (T > 0 && L > T) {
-		uint32_t a = 0, b = 0; bool oka = true, okb = true;
-		for (int t = 1; t <= T; ++t) {
-			const uint32_t x = seq[o + L - t], y = rseq[o + L - t];
-			oka = oka && x < 4u; okb = okb && y < 4u;
-			a = a << 2 | (x & 3u); b = b << 2 | (y & 3u);
+		for (int v = 0; v < 3; ++v) {
+			if (v == 2 && !(L > seed_len && seed_len > T)) break;
+			uint32_t a = 0, b = 0; bool oka = true, okb = true;
+			for (int t = 1; t <= T; ++t) {
+				const int pos = v == 0 ? L - t : (v == 1 ? t - 1 : L - seed_len + t - 1);
+				const uint32_t x = seq[o + pos], y = rseq[o + pos];
+				oka = oka && x < 4u; okb = okb && y < 4u;
+				a = a << 2 | (x & 3u); b = b << 2 | (y & 3u);
+			}
+			if (oka) key[2 * v] = a;
+			if (okb) key[2 * v + 1] = b;
 		}
-		if (oka) k0 = a;
-		if (okb) k1 = b;
 	}
-	rd_key[2 * (size_t)i] = k0; rd_key[2 * (size_t)i + 1] = k1;
+	for (int v = 0; v < 6; ++v) rd_key[6 * (size_t)i + v] = key[v];
 }
 
 extern "C" void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, hipStream_t s)
+									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T);
+	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T, seed_len);
 }
 
 // ids of the reads whose first pass was abandoned (arena or hit list outgrown)

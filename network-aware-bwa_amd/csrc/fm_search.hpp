@@ -23,7 +23,7 @@ struct SearchParams {
 	size_t wstride;
 	uint32_t woff_bid, woff_sbid;
 	uint32_t WL, WLB, SLB;
-	const uint32_t *rd_key;                   // per read and strand [2*rid + a]: the first kmer_T consumed symbols of seq[a] as a table key, ~0u = none
+	const uint32_t *rd_key;                   // per read six interval-table keys [6*rid + ..] (see pad_reads_kernel), ~0u = none
 	uint8_t *rd_nN;                           // per read: number of N in the read, saturated at 255
 	// per-lane scratch of kernel S: the arena (and, wide pass only, links / free list / heads)
 	uint8_t *scratch;

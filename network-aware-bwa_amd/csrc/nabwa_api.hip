@@ -15,6 +15,8 @@
 extern "C" {
 void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets, uint4 *out, hipStream_t s);
 void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s);
+void nabwa_launch_sa_fill(const DevBwt *B, uint32_t *sa_full, uint32_t *isa, uint8_t *text_bytes, hipStream_t s);
+void nabwa_launch_text_pack(const uint8_t *bytes, uint32_t n, uint32_t n_words, uint32_t *out, hipStream_t s);
 void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s);
@@ -32,7 +34,7 @@ void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, c
 						 uint4 *out, hipStream_t s);
 int nabwa_search_occupancy(int wide, int ns);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, hipStream_t s);
+							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -145,6 +147,20 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 						 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 		B.sa = ix->sa[t_];
 		ix->bytes += (uint64_t)B.n_sa * 4;
+		const char *tm = getenv("NABWA_TEXT_MODE");
+		if (!(tm && atoi(tm) == 0)) {      /* full SA + inverse + text, ~8.3 B per base (NABWA_TEXT_MODE=0: keep the samples only) */
+			const size_t rows = (size_t)B.seq_len + 1, words = ((size_t)B.seq_len + 15) / 16 + 4;
+			uint8_t *tb = 0;
+			HIPCHK(hipMalloc(&ix->sa_full[t_], rows * 4)); HIPCHK(hipMalloc(&ix->isa[t_], rows * 4));
+			HIPCHK(hipMalloc(&ix->text[t_], words * 4)); HIPCHK(hipMalloc(&tb, rows));
+			nabwa_launch_sa_fill(&B, ix->sa_full[t_], ix->isa[t_], tb, 0);
+			nabwa_launch_text_pack(tb, B.seq_len, (uint32_t)words, ix->text[t_], 0);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipFree(tb));
+			B.sa_full = ix->sa_full[t_]; B.isa = ix->isa[t_]; B.text = ix->text[t_];
+			ix->bytes += rows * 8 + words * 4;
+		}
 	}
 	return NABWA_OK;
 }
@@ -157,7 +173,7 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
-	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; ix->bytes = 0; ix->ref = 0;
+	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; for (int t = 0; t < 2; ++t) ix->sa_full[t] = ix->isa[t] = ix->text[t] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
 	if (r == NABWA_OK) r = build_one(ix, 1, bwt1, nw1, is_device != 0, sa1, ns1);
@@ -201,7 +217,8 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 {
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
-	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]); }
+	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]);
+		if (ix->sa_full[t]) (void)hipFree(ix->sa_full[t]); if (ix->isa[t]) (void)hipFree(ix->isa[t]); if (ix->text[t]) (void)hipFree(ix->text[t]); }
 	delete ix->ref;
 	delete ix;
 }
@@ -322,7 +339,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	b->max_len = max_len;
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
-	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 8));
+	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
@@ -331,7 +348,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		BCHK(hipMemcpy(raw_r, rseq, (size_t)off[n], hipMemcpyHostToDevice));
 		BCHK(hipMemcpy(raw_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->d_key,
-							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, b->stream);
+							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, opt->seed_len, b->stream);
 		BCHK(hipStreamSynchronize(b->stream));
 		BCHK(hipFree(raw_s)); BCHK(hipFree(raw_r)); BCHK(hipFree(raw_off));
 		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));

@@ -4,6 +4,10 @@
 // which lets an exact tail that starts within T symbols of the read end jump to depth T with ONE 8-byte load
 // instead of up to T dependent rank queries (fm_search.hip, "tail jump").
 //
+// With 288 GB of HBM the index also carries the full suffix array, its inverse and the text (sa_full / isa / text,
+// ~8.3 bytes per base and index): once an interval has shrunk to ONE row, "extend by the next read symbol" is a
+// comparison with the text base in front of that suffix -- no rank query -- and rows <-> positions are single loads.
+//
 // HBM layout of one FM-index ("bucket array"): 64-byte buckets, 64-byte aligned, each
 // covering NABWA_INTV = 192 consecutive rows of the $-removed BWT string B0:
 //
@@ -28,7 +32,12 @@ struct DevBwt {
 	uint32_t n_buckets;
 	uint32_t kmer_T;        // 0: no table.  Otherwise kmer[key] = SA interval {k, l} (k > l: empty) of the string whose
 	const uint2 *kmer;      // T symbols, in the order the backward search consumes them, are the base-4 digits of key
-};                          // (first consumed symbol = most significant digit); built at load time (fm_index.hip)
+	                        // (first consumed symbol = most significant digit); built at load time (fm_index.hip)
+	// "text mode" companions, all derived from the BWT + the SA samples at load time (fm_index.hip), or null:
+	const uint32_t *sa_full;   // SA value of EVERY row (row 0: ~0u), so bwt_sa is one load
+	const uint32_t *isa;       // row of every text position 0..seq_len (inverse of sa_full; isa[seq_len] = 0)
+	const uint32_t *text;      // the indexed text itself, 2 bits per base, base j in word j>>4 at bits 2*(j&15)
+};
 
 struct Occ4 { uint32_t c[4]; };
 
