@@ -47,6 +47,13 @@
 #define STATE_D 2
 #define STATE_GROUP 3   // arena only: the gap children of one expansion, see fm_search_kernel
 #define GRP_EXT 0x100u
+#define TXM 0xffffffffu   // l of an interval carried in text form (k = text position)
+#ifndef NABWA_WORK_CHUNK
+#define NABWA_WORK_CHUNK 256u
+#endif
+#ifndef NABWA_RUN_MAX
+#define NABWA_RUN_MAX 4   // levels one text-form trip may walk (every lane of the wave waits for the longest walk)
+#endif
 
 // bucket touches the REFERENCE algorithm performs for one (k-1, l) query: one per
 // bwt_occ / bwt_occ4 body execution, one for a same-128-row-block pair (bwt.c:92-216)
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	bool run = false, done = false;
+	unsigned int w_next = 0, w_end = 0;                     // this wave's block of read numbers
 	uint32_t rid = 0; int len = 0, phase = 0, wi = 0, n = 0, sbase = 0, nN = 0;
 	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
 #define WREC (P.wdata + (size_t)rid * P.wstride)
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 	// matches iff it equals the text base in front of it, and the width stays 1 (kk == ll is kept as it is)
 	uint32_t tmode = 0, tp[2] = { 0, 0 }, twtag[2] = { 0xffffffffu, 0xffffffffu }; uint2 twin[2];
 	twin[0] = twin[1] = make_uint2(0u, 0u);
-	const bool text_ok = !COUNT && P.bwt[0].sa_full && P.bwt[1].sa_full;
+	const bool text_ok = (P.text_mode & 1) && P.bwt[0].sa_full && P.bwt[1].sa_full;
 	uint32_t kk[2] = { 0, 0 }, ll[2] = { 0, 0 }, pw[2] = { 0, 0 }; int bid[2] = { 0, 0 };
 	uint32_t wkey[2] = { 0xffffffffu, 0xffffffffu }; bool tok = false;   // interval-table keys of this phase's first KT symbols
 	const int KT = (int)P.bwt[0].kmer_T;
@@ -115,11 +123,18 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 	for (;;) {
 		const unsigned long long need = __ballot(!run && !done);
 		if (need) {
-			unsigned int base = 0;
-			if (lane == 0) base = atomicAdd(P.work_counter + 1, (unsigned int)__popcll(need));
-			base = __shfl(base, 0);
-			if (!run && !done) {
-				const unsigned int idx = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+			// read numbers come in blocks of NABWA_WORK_CHUNK per wave: one atomic on the shared counter per block, not per
+			// refill (a few hundred million single-address atomics per second is all the L2 gives)
+			if (w_next == w_end) {
+				unsigned int base = 0;
+				if (lane == 0) base = atomicAdd(P.work_counter + 1, (unsigned int)NABWA_WORK_CHUNK);
+				w_next = __builtin_amdgcn_readfirstlane(base); w_end = w_next + NABWA_WORK_CHUNK;
+			}
+			const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull)), avail = w_end - w_next;
+			const unsigned int base = w_next;
+			w_next += min((unsigned int)__popcll(need), avail);
+			if (!run && !done && rank < avail) {
+				const unsigned int idx = base + rank;
 				if (idx < (unsigned int)P.n) {
 					rid = P.ids ? (uint32_t)P.ids[idx] : idx;
 					const int64_t o = P.poff[rid];
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 						if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 2); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
 #pragma unroll
 						for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; blo[x] = bhi[x] = 0; }
-					} else P.rd_nN[rid] = 0;
+					} else { P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[rid] = 0; }
 				} else done = true;
 			}
 		}
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 			if (wi + 1 == n) out_pos(wi + 1, true);
 			++wi;
 			if (wi == n) {
+				if (phase == 0 && P.rd_cls) P.rd_cls[rid] = (bid[0] == 1 || bid[1] == 1) ? 1 : 0;   // only the terminator's ++: no restart (bwtaln.c:66-74)
 				if (phase == 0 && len > P.seed_len) {
 					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = 0;
 					if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 4); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 #define LS_IDLE  0
 #define LS_POP   1   // needs to pop
 #define LS_HAVE  2   // the entry popped from the arena in the previous trip is in e_*
-#define LS_EXACT 3   // inside an exact tail (bwt.c:237-252), next position xt
+#define LS_EXACT 3   // inside an exact tail (bwt.c:237-252), next position e_i - 1
 #define LS_EXIT  4
 
 template <bool WIDE, bool COUNT>
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	const bool gape_mode = P.mode & 0x01, nonstop = P.mode & 0x10, loggap = P.mode & 0x04;
 
 	int st = LS_IDLE;
+	unsigned int w_next = 0, w_end = 0; bool w_sync = false;   // this wave's block of read numbers; lockstep mode
 	// per-read
 	uint32_t item = 0, rid_w = 0; int len = 0; uint32_t mdmg = 0;   // mdmg: this read's max_diff | max_gapo << 8
 	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
@@ -325,16 +342,20 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	int max_diff = 0, best_score = 0, best_cnt = 0, n_aln = 0, max_ent = 0, n_entries = 0;
 	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;
 	// current entry
-	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, e_score = 0, m = 0, m_seed = 0, xt = 0;
+	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, e_score = 0, m = 0;
 	// pending entry: the last child pushed by the previous expansion, still in registers
-	bool p_valid = false; uint32_t p_k = 0, p_l = 0;
-	int p_i = 0, p_ldp = 0, p_mm = 0, p_go = 0, p_ge = 0, p_state = 0, p_a = 0, p_score = 0;
+	// (kept in the 16-byte arena format, so spilling it is one store and popping it is the arena unpack; p_score < 0: none)
+	uint4 pe = make_uint4(0, 0, 0, 0); int p_score = -1;
+#define p_valid (p_score >= 0)
 	// register windows over read data / the width record
-	uint64_t sqw_lo = 0, sqw_hi = 0; int sq_tag = -1;                    // 16 read bases
-	uint64_t bw_lo = 0, bw_hi = 0; int bw_base = -1, bw_a = -1;          // 16 bound bytes of strand bw_a from bw_base
-	uint64_t sw_lo = 0, sw_hi = 0; int sw_base = -1, sw_a = -1;          // same for the seed bounds
+	// 16-byte windows over read data / the width record live in LDS (first pass), [lane][16 bytes], filled by
+	// global_load_lds_dwordx4 (no registers in between; layout checked by profiles/probes/lds_dma_probe.hip) and read a byte at a time
+	int sq_tag = -1;                     // 16 read bases
+	int bw_base = -1, bw_a = -1;         // 16 bound bytes of strand bw_a from bw_base
+	int sw_base = -1, sw_a = -1;         // same for the seed bounds
+	uint4 wq_sq = make_uint4(0, 0, 0, 0), wq_bw = wq_sq, wq_sw = wq_sq;   // WIDE only (no LDS): the same windows in registers
 	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
-	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0;
+	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0, st_txe = 0, st_txt = 0;
 	bool ovf = false;
 
 	auto head_get = [&](int score) -> uint32_t {
@@ -349,19 +370,21 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// (n_entries feeds max_entries and the bwtgap.c:140 cut-off) but never written to the arena.
 	auto never_popped = [&](int score) -> bool { return !nonstop && n_aln > 0 && score > best_score + P.s_mm; };
 	// append an entry to the in-memory list of its score (n_entries is maintained by the callers)
-	auto push_mem = [&](int score, uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int na) {
+	// the arena word of an entry: {k, l, i | last_diff_pos << 16, counters / state / strand (+ the list link, first pass)}
+	auto mk_entry = [&](uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int na) -> uint4 {
+		const uint32_t z = (uint32_t)ni | (uint32_t)nldp << 16;
+		if (WIDE) return make_uint4(nk, nl, z, (uint32_t)nmm | (uint32_t)ngo << 8 | (uint32_t)nge << 16 | (uint32_t)nstate << 24 | (uint32_t)na << 26);
+		return make_uint4(nk, nl, z, (uint32_t)nmm << 16 | (uint32_t)ngo << 20 | (uint32_t)nge << 24 | (uint32_t)nstate << 29 | (uint32_t)na << 31);
+	};
+	auto push_mem = [&](int score, uint4 e) {
 		if (ovf || never_popped(score)) return;
+		if (score >= (int)P.NS) { ovf = true; return; }            // cannot happen (nabwa_api.hip sizes NS); the second pass would take over
 		uint32_t s;
 		if (WIDE && nfree) s = freel[--nfree];
 		else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
 		const uint32_t prev = mask_has(score) ? head_get(score) : NIL;
-		const uint32_t z = (uint32_t)ni | (uint32_t)nldp << 16;
-		if (WIDE) {
-			ent[s] = make_uint4(nk, nl, z, (uint32_t)nmm | (uint32_t)ngo << 8 | (uint32_t)nge << 16 | (uint32_t)nstate << 24 | (uint32_t)na << 26);
-			lnk[s] = prev;
-		} else {
-			ent[s] = make_uint4(nk, nl, z, prev | (uint32_t)nmm << 16 | (uint32_t)ngo << 20 | (uint32_t)nge << 24 | (uint32_t)nstate << 29 | (uint32_t)na << 31);
-		}
+		if (WIDE) lnk[s] = prev; else e.w |= prev;
+		ent[s] = e;
 		head_set(score, s);
 		if (score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64);
 	};
@@ -370,22 +393,43 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// lane walks an exact tail (a tail pushes nothing, so that head IS the next pop) and parked in LDS
 	uint4 *const s_pf = (uint4*)(s_head + (size_t)P.NS * NABWA_SEARCH_BLOCK);
 	uint2 *const s_key = (uint2*)(s_pf + NABWA_SEARCH_BLOCK);
+	// Text mode (nabwa_dev.hpp).  An interval of ONE row is carried as {k = text position of that row's suffix, l = TXM}:
+	// extending it by a symbol is a comparison with the text base to the left of the suffix, its only non-empty child
+	// is the suffix one position further left, and rows are recovered (isa) only where one is reported.  Entries of
+	// either form live side by side in the stacks.  s_tw: this lane's 16-base text word and its tag.
+	uint2 *const s_tw = s_key + NABWA_SEARCH_BLOCK;
+	uint32_t *const s_bw = (uint32_t*)(s_tw + NABWA_SEARCH_BLOCK), *const s_sw = s_bw + 4 * NABWA_SEARCH_BLOCK, *const s_sq = s_sw + 4 * NABWA_SEARCH_BLOCK;
+	auto win_byte = [&](const uint32_t *W, const uint4 &q, uint32_t idx) -> uint32_t {
+		if (WIDE) { const uint32_t w = idx < 8u ? (idx < 4u ? q.x : q.y) : (idx < 12u ? q.z : q.w); return w >> ((idx & 3u) << 3) & 0xffu; }
+		return (uint32_t)((const uint8_t*)W)[(threadIdx.x << 4) + idx];
+	};
+	// 16 bytes from global memory into this lane's window slot (first pass) or into the register copy (second pass)
+	auto win_load = [&](const void *src, uint32_t *W, uint4 &q) {
+		if (WIDE) { const uint2 *p2 = (const uint2*)src; const uint2 u = p2[0], v = p2[1]; q = make_uint4(u.x, u.y, v.x, v.y); return; }
+		__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+										 (void __attribute__((address_space(3)))*)(W + ((threadIdx.x & ~63u) << 2)), 16, 0, 0);
+	};
+#define BW_BYTE(i_) win_byte(s_bw, wq_bw, (uint32_t)(i_))
+#define SW_BYTE(i_) win_byte(s_sw, wq_sw, (uint32_t)(i_))
+#define SQ_BYTE(i_) win_byte(s_sq, wq_sq, (uint32_t)(i_))
+	const bool text_ok = !WIDE && (P.text_mode & 2) && P.bwt[0].sa_full && P.bwt[1].sa_full && P.bwt[0].seq_len < 0xfffffff0u;
 	uint32_t pf_slot = NIL;
 	bool finish = false;
 	// unpack a popped arena entry into the current-entry registers and unlink it (bwtgap.c:66-79)
-	auto take_entry = [&](const uint4 &r_ent, uint32_t r_lnk, uint32_t ent_slot) {
-		uint32_t nx;
-		k = r_ent.x; l = r_ent.y; e_i = (int)(r_ent.z & 0xffffu); e_ldp = (int)(r_ent.z >> 16);
+	auto unpack = [&](const uint4 &r) {
+		k = r.x; l = r.y; e_i = (int)(r.z & 0xffffu); e_ldp = (int)(r.z >> 16);
 		if (WIDE) {
-			nx = r_lnk;
-			e_mm = (int)(r_ent.w & 0xffu); e_go = (int)(r_ent.w >> 8 & 0xffu); e_ge = (int)(r_ent.w >> 16 & 0xffu);
-			e_state = (int)(r_ent.w >> 24 & 3u); e_a = (int)(r_ent.w >> 26 & 1u);
-			freel[nfree++] = ent_slot;
+			e_mm = (int)(r.w & 0xffu); e_go = (int)(r.w >> 8 & 0xffu); e_ge = (int)(r.w >> 16 & 0xffu);
+			e_state = (int)(r.w >> 24 & 3u); e_a = (int)(r.w >> 26 & 1u);
 		} else {
-			nx = r_ent.w & 0xffffu;
-			e_mm = (int)(r_ent.w >> 16 & 15u); e_go = (int)(r_ent.w >> 20 & 15u); e_ge = (int)(r_ent.w >> 24 & 31u);
-			e_state = (int)(r_ent.w >> 29 & 3u); e_a = (int)(r_ent.w >> 31);
+			e_mm = (int)(r.w >> 16 & 15u); e_go = (int)(r.w >> 20 & 15u); e_ge = (int)(r.w >> 24 & 31u);
+			e_state = (int)(r.w >> 29 & 3u); e_a = (int)(r.w >> 31);
 		}
+	};
+	auto take_entry = [&](const uint4 &r_ent, uint32_t r_lnk, uint32_t ent_slot) {
+		unpack(r_ent);
+		const uint32_t nx = WIDE ? r_lnk : (r_ent.w & 0xffffu);
+		if (WIDE) freel[nfree++] = ent_slot;
 		head_set(e_score, nx);
 		if (nx == NIL) { if (e_score < 64) mask_lo &= ~(1ull << e_score); else mask_hi &= ~(1ull << (e_score - 64)); }
 		--n_entries;
@@ -396,23 +440,32 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		finish = false;
 		// ---------------------------------------------------------------- refill
 		unsigned long long need = __ballot(st == LS_IDLE);
-		if (P.sync_refill && __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull) need = 0ull;   // experiment: refill only when the whole wave is idle
+		// reads whose search is known to run alike (an exact occurrence exists: kernel W's class, sorted to the front) are
+		// taken 64 at a time by a wave with all lanes idle, so its lanes stay in step and its trips stay converged
+		if ((P.sync_refill || w_sync) && __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull) need = 0ull;
 		if (need) {
-			unsigned int base = 0;
-			if (lane == 0) base = atomicAdd(P.work_counter, (unsigned int)__popcll(need));
-			base = __shfl(base, 0);
-			if (st == LS_IDLE) {
-				const unsigned int idx = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+			if (w_next == w_end) {          // blocks of read numbers per wave, as in kernel W
+				unsigned int base = 0;
+				if (lane == 0) base = atomicAdd(P.work_counter, (unsigned int)NABWA_WORK_CHUNK);
+				w_next = __builtin_amdgcn_readfirstlane(base); w_end = w_next + NABWA_WORK_CHUNK;
+				w_sync = P.n_sync && w_end <= *P.n_sync;
+			}
+			const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull)), avail = w_end - w_next;
+			const unsigned int base = w_next;
+			w_next += min((unsigned int)__popcll(need), avail);
+			if (st == LS_IDLE && rank < avail) {
+				const unsigned int idx = base + rank;
 				if (idx < (unsigned int)P.n) {
-					item = idx;
 					const uint32_t rid = P.ids ? (uint32_t)P.ids[idx] : idx;
+					item = WIDE ? idx : rid;                             // results: by list position (second pass) / by read (first pass)
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o; rid_w = rid;
 					mdmg = (uint32_t)P.rd_maxdiff[rid] | (uint32_t)P.rd_maxgapo[rid] << 8;
 					if (KT) s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 6 * (size_t)rid);   // interval-table keys of the two strands
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
-					sq_tag = -1; bw_a = -1; sw_a = -1; p_valid = false; pf_slot = NIL;
+					sq_tag = -1; bw_a = -1; sw_a = -1; p_score = -1; pf_slot = NIL;
+					if (text_ok) s_tw[threadIdx.x] = make_uint2(0u, 0x7fffffffu);
 					if (len > 0 && (int)P.rd_nN[rid] <= MD_READ) {      // too many N: no search (bwtgap.c:118-123)
 						// ---- start of bwt_match_gap (bwtgap.c:104-128)
 						seeded = len > P.seed_len;
@@ -421,9 +474,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						best_cnt = 0;
 						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
 						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
-						push_mem(0, 0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0);
-						p_valid = true; p_k = 0u; p_l = P.bwt[0].seq_len; p_i = len; p_ldp = 0; p_mm = p_go = p_ge = 0;
-						p_state = STATE_M; p_a = 1; p_score = 0;
+						push_mem(0, mk_entry(0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0));
+						pe = mk_entry(0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 1); p_score = 0;
 						n_entries = 2;
 						st = LS_POP;
 					} else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
@@ -446,15 +498,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 											 : (mask_hi ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff);
 				if (p_valid && p_score <= best_mem) {
 					// the pending child is the newest entry of the lowest score: it is the pop
-					k = p_k; l = p_l; e_i = p_i; e_ldp = p_ldp; e_mm = p_mm; e_go = p_go; e_ge = p_ge; e_state = p_state; e_a = p_a;
-					e_score = p_score; p_valid = false;
+					unpack(pe);
+					e_score = p_score; p_score = -1;
 					--n_entries;
 					if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
 					else have = true;
 				} else if (best_mem == 0x7fffffff) {
 					finish = true;      // only never-stored children are left: the reference pops one of them and stops (bwtgap.c:144)
 				} else {
-					if (p_valid) { push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a); p_valid = false; }
+					if (p_valid) { push_mem(p_score, pe); p_score = -1; }
 					if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 					else {
 						ent_slot = head_get(best_mem); e_score = best_mem;
@@ -475,21 +527,20 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (have && !finish && e_state == STATE_GROUP) {
 			// pop ONE member of a gap group, newest first (deletion of T, G, C, A, then the insertion); the rest goes back
 			// on the stack it came from, where it is again the top
-			const uint32_t mk = (uint32_t)e_ldp & 0x1fu, ext = (uint32_t)e_ldp & GRP_EXT;
+			const uint32_t mk = (uint32_t)e_ldp & 0x1fu, ext = (uint32_t)e_ldp & GRP_EXT, more = (uint32_t)e_ldp >> 9;
 			const int j = 31 - __clz((int)mk);
 			const uint32_t rest = mk & ~(1u << j);
-			if (rest) {
-				push_mem(e_score, k, l, e_i, (int)(rest | ext), e_mm, e_go, e_ge, STATE_GROUP, e_a);
-				if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
-			}
+			if (rest) push_mem(e_score, mk_entry(k, l, e_i, (int)(rest | ext | more << 9), e_mm, e_go, e_ge, STATE_GROUP, e_a));
+			else if (more) push_mem(e_score, mk_entry(k + 1u, l, e_i + 1, (int)(3u | (more - 1u) << 9), e_mm, e_go, e_ge, STATE_GROUP, e_a));   // (text form) the next older level
+			if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 			if (ext) ++e_ge; else ++e_go;
 			if (j == 0) { e_state = STATE_I; e_ldp = e_i; }                 // the insertion keeps the parent's interval
+			else if (l == TXM) { k -= 1u; e_i += 1; e_state = STATE_D; e_ldp = e_i; }   // text form: the deleted base is the one to the left
 			else { kind = 5; grp_c = j - 1; st = LS_POP; have = false; }    // a deletion: re-derive its interval
 		}
 		if (have && !finish) {
 			st = LS_POP;
 			m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
-			m_seed = P.max_seed_diff - (e_mm + e_go); if (gape_mode) m_seed -= e_ge;
 			if (m >= 0) {
 				if (e_i == 0) kind = 3;
 				else {
@@ -499,28 +550,39 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					const int win_lo = (tail || e_i < 2) ? e_i - 1 : e_i - 2;
 					bool go = true;
 					if (bw_a == e_a && win_lo >= bw_base && win_hi < bw_base + 16) {
-						if (m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) go = false;   // bwtgap.c:156
+						if (m < (int)(BW_BYTE(win_hi - bw_base) & 127u)) go = false;   // bwtgap.c:156
 					} else { need_win = true; spec = true; }
 					if (go) {
 						if (tail) {                                 // nothing may differ any more: exact tail (bwt.c:237-252)
-							kind = 2; xt = e_i - 1;
+							kind = 2;                                   // its cursor is e_i: position e_i - 1 is consumed next
 							// tail jump: the path so far is the read's own last len-e_i symbols, at most one of them (the one
 							// just consumed) substituted, so the interval after KT symbols is one table entry away
-							if (KT && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i <= KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
+							if (l == TXM) kind = 7;                  // text form: compare the rest of the read with the text
+							else if (KT && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i <= KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
 								&& (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu) kind = 4;
 						}
 						else { kind = 1; --e_i; }
 					}
 				}
 			}
-		} else if (st == LS_EXACT) kind = 2;
+		} else if (st == LS_EXACT) kind = l == TXM ? 7 : 2;
 
 		const int qb = 1 - e_a;
-		const int spos = kind == 2 ? xt : e_i;
+		const bool tx = l == TXM && (kind == 1 || kind == 3 || kind == 7);
+		const int spos = (kind == 2 || kind == 7) ? e_i - 1 : e_i;
 		const int stag = (e_a << 20) | (spos >> 4);
-		const bool need_seq = (kind == 1 || kind == 2) && stag != sq_tag;
-		bool query = kind == 1 || kind == 2 || kind == 5;
-		if (kind == 2 && !need_seq && byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u) > 3u) query = false;   // an N: no query
+		const bool need_seq = (kind == 1 || kind == 2 || kind == 7) && stag != sq_tag;
+		bool query = (kind == 1 && !tx) || kind == 2 || kind == 5;
+		// text word in front of the suffix (kinds 1 and 7 in text form)
+		uint2 tw = make_uint2(0u, 0u); bool need_tw = false;
+		if (tx && kind != 3 && k > 0u) {
+			const uint32_t tag = ((k - 1u) >> 4) | (uint32_t)qb << 31;
+			tw = s_tw[threadIdx.x];
+			need_tw = tw.y != tag;
+			tw.y = tag;
+		}
+		const bool to_text = kind == 1 && !tx && text_ok && k == l;   // one row left: its children go on in text form
+		if (kind == 2 && !need_seq && SQ_BYTE((uint32_t)spos & 15u) > 3u) query = false;   // an N: no query
 		const int ii = e_i - (len - P.seed_len);
 		const bool use_seed = kind == 1 && e_i > 0 && seeded && ii > 0;
 		const bool need_seed = use_seed && !(sw_a == e_a && ii - 1 >= sw_base && ii < sw_base + 16);
@@ -530,20 +592,19 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (WIDE && want_ent) { r_ent = ent[ent_slot]; r_lnk = lnk[ent_slot]; }
 		if (need_win) {
 			int base = (win_hi | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(REC + P.woff_bid + e_a * P.WLB + base);
-			const uint2 u = p[0], v = p[1];
-			WIN_SET(bw_lo, bw_hi, u.x, u.y, v.x, v.y); bw_base = base; bw_a = e_a;
+			win_load(REC + P.woff_bid + e_a * P.WLB + base, s_bw, wq_bw); bw_base = base; bw_a = e_a;
 		}
 		if (need_seq) {
-			const uint4 q = *(const uint4*)((e_a ? P.rseq : P.seq) + sq_off + (spos & ~15));
-			WIN_SET(sqw_lo, sqw_hi, q.x, q.y, q.z, q.w); sq_tag = stag;
+			win_load((e_a ? P.rseq : P.seq) + sq_off + (spos & ~15), s_sq, wq_sq); sq_tag = stag;
 		}
 		if (need_seed) {
 			int base = (ii | 7) - 15; if (base < 0) base = 0;
-			const uint2 *p = (const uint2*)(REC + P.woff_sbid + e_a * P.SLB + base);
-			const uint2 u = p[0], v = p[1];
-			WIN_SET(sw_lo, sw_hi, u.x, u.y, v.x, v.y); sw_base = base; sw_a = e_a;
+			win_load(REC + P.woff_sbid + e_a * P.SLB + base, s_sw, wq_sw); sw_base = base; sw_a = e_a;
 		}
+		uint32_t r_x = 0u;       // text word, or the row of a reported suffix, or the position of the last row
+		if (need_tw) r_x = (qb ? P.bwt[1].text : P.bwt[0].text)[(k - 1u) >> 4];
+		else if (tx && kind == 3) r_x = (qb ? P.bwt[1].isa : P.bwt[0].isa)[k];
+		else if (to_text) r_x = (qb ? P.bwt[1].sa_full : P.bwt[0].sa_full)[k];
 		uint2 r_km = make_uint2(1u, 0u);
 		if (kind == 4) {
 			uint32_t key = e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x;
@@ -576,7 +637,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		bool pf_now = false; uint32_t pf_cand = NIL;
 		if (!WIDE) {
 			if (want_ent) { pf_cand = ent_slot; pf_now = true; }            // a pop that was not fetched ahead: fetch now, pop next trip
-			else if ((kind == 2 || kind == 4) && !p_valid && (mask_lo | mask_hi) != 0ull) {
+			else if ((kind == 2 || kind == 4 || kind == 7) && !p_valid && (mask_lo | mask_hi) != 0ull) {
 				const int bm = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1 : 64 + __ffsll((unsigned long long)mask_hi) - 1;
 				pf_cand = head_get(bm);
 				pf_now = pf_cand != pf_slot;
@@ -585,22 +646,24 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		}
 		if (COUNT) {   // trip statistics (instrumented build only): [2] trips, [3..] lane-trips by activity
 			const unsigned long long bx = __ballot(kind == 1), be = __ballot(kind == 2), bm = __ballot(want_ent),
-				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT), bj = __ballot(kind == 4);
+				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT), bj = __ballot(kind == 4), bt = __ballot(tx && kind == 1), b7 = __ballot(kind == 7);
 			if (lane == 0) {
 				st_trips += 1; st_expand += __popcll(bx); st_exact += __popcll(be); st_ent += __popcll(bm); st_spec += __popcll(bs);
-				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi); st_jump += __popcll(bj);
+				st_query += __popcll(bq); st_two += __popcll(b2); st_exit += __popcll(bi); st_jump += __popcll(bj); st_txe += __popcll(bt); st_txt += __popcll(b7);
 			}
 		}
 		asm volatile("" ::: "memory");   // keep every consumer below every load above (no block merging across)
+		if (!WIDE) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window loads above wrote LDS behind the compiler's back
 		// ================================================================ phase 3: consume
 		if (WIDE && want_ent) {
 			take_entry(r_ent, r_lnk, ent_slot);
 			if (!finish) st = LS_HAVE;                                          // pre-checks + query in the next trip
 		}
 		if (pf_now) { s_pf[threadIdx.x] = r_ent; pf_slot = pf_cand; }
-		if (spec && m < (int)(byte_of(bw_lo, bw_hi, (uint32_t)(win_hi - bw_base)) & 127u)) kind = 0;   // pruned after all (bwtgap.c:156)
+		if (spec && m < (int)(BW_BYTE(win_hi - bw_base) & 127u)) kind = 0;   // pruned after all (bwtgap.c:156)
+		if (need_tw) { tw.x = r_x; s_tw[threadIdx.x] = tw; }
 		int c = 4;
-		if (kind == 1 || kind == 2) c = (int)byte_of(sqw_lo, sqw_hi, (uint32_t)spos & 15u);
+		if (kind == 1 || kind == 2) c = (int)SQ_BYTE((uint32_t)spos & 15u);
 		if (kind == 2 && c > 3) query = false;
 		Occ4 ck, cl;
 		ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0; cl = ck;
@@ -609,8 +672,16 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			if (kvalid) ck = two ? nabwa_count4(b0, b1, b2, b3, rk) : nabwa_count4(a0, a1, a2, a3, rk);
 			if (COUNT && kind != 5) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);   // (the reference derived a group's members in the parent's query)
 		}
-		const uint32_t L2q0 = qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0], L2q1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1];
-		const uint32_t L2q2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], L2q3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
+		const bool tx1 = tx && kind == 1;
+		if (tx1) {
+			// the one row's only non-empty child is for the text base b to the left of the suffix, and it is the suffix
+			// starting there: present it to the generic expansion below as "counts" (with C(.) = 0) that yield {k-1, TXM}
+			const uint32_t b = k > 0u ? (tw.x >> (((k - 1u) & 15u) << 1) & 3u) : 4u;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { ck.c[j] = b == (uint32_t)j ? k - 2u : 0u; cl.c[j] = b == (uint32_t)j ? TXM : 0u; }
+		}
+		const uint32_t L2q0 = tx1 ? 0u : (qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0]), L2q1 = tx1 ? 0u : (qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1]);
+		const uint32_t L2q2 = tx1 ? 0u : (qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2]), L2q3 = tx1 ? 0u : (qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3]);
 		const uint32_t seqlen_q = qb ? P.bwt[1].seq_len : P.bwt[0].seq_len;
 #define L2Q(cc) ((cc) == 0 ? L2q0 : ((cc) == 1 ? L2q1 : ((cc) == 2 ? L2q2 : L2q3)))
 #define CK(cc) ((cc) == 0 ? ck.c[0] : ((cc) == 1 ? ck.c[1] : ((cc) == 2 ? ck.c[2] : ck.c[3])))
@@ -623,15 +694,31 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		} else if (kind == 4) {                                 // landed at depth KT (len > KT, so the tail goes on)
 			k = r_km.x; l = r_km.y;
 			if (k > l) st = LS_POP;
-			else { xt = len - KT - 1; st = LS_EXACT; }
+			else { e_i = len - KT; st = LS_EXACT; }
+		} else if (kind == 7) {
+			// exact tail in text form: read symbols e_i-1, e_i-2, ... against the text to the left, as far as both 16-base words reach
+			uint32_t pp = k; bool fail = false;
+			for (;;) {
+				const uint32_t cc = SQ_BYTE((uint32_t)(e_i - 1) & 15u);
+				if (cc > 3u || pp == 0u) { fail = true; break; }
+				const uint32_t q = pp - 1u;
+				if ((tw.x >> ((q & 15u) << 1) & 3u) != cc) { fail = true; break; }
+				pp = q; --e_i;
+				if (e_i == 0 || (e_i & 15) == 0 || (pp & 15u) == 0u) break;
+			}
+			k = pp;
+			if (fail) st = LS_POP;
+			else if (e_i == 0) st = LS_HAVE;                          // matched to the end: reported (as a row) in the next trip
+			else st = LS_EXACT;
 		} else if (kind == 2 || kind == 3) {
 			bool hit = false;
+			if (kind == 3 && tx) { k = r_x; l = r_x; }                // the row of the suffix (isa)
 			if (kind == 3) hit = true;
 			else if (c > 3) st = LS_POP;                          // an N in the tail: no match
 			else {
 				k = L2Q(c) + CK(c) + 1u; l = L2Q(c) + CL(c);
 				if (k > l) st = LS_POP;
-				else if (--xt < 0) hit = true;
+				else if (--e_i == 0) hit = true;
 				else st = LS_EXACT;
 			}
 			if (hit) {
@@ -690,35 +777,76 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 		} else if (kind == 1) {
 			// ---- node expansion (bwtgap.c:201-260); e_i is already decremented
-			const uint32_t occ = l - k + 1u;
+			const uint32_t occ = tx1 ? 1u : l - k + 1u;
+			bool match_child = false;
 			bool allow_diff = true, allow_M = true;
 			if (e_i > 0) {
-				const uint32_t B1 = byte_of(bw_lo, bw_hi, (uint32_t)(e_i - 1 - bw_base)), B0 = byte_of(bw_lo, bw_hi, (uint32_t)(e_i - bw_base));
+				const uint32_t B1 = BW_BYTE(e_i - 1 - bw_base), B0 = BW_BYTE(e_i - bw_base);
 				const int b1 = (int)(B1 & 127u), b0v = (int)(B0 & 127u);
 				if (b1 > m - 1) allow_diff = false;
 				else if (b1 == m - 1 && b0v == m - 1 && (B0 & 128u)) allow_M = false;
 				if (use_seed) {
-					const uint32_t S1 = byte_of(sw_lo, sw_hi, (uint32_t)(ii - 1 - sw_base)), S0 = byte_of(sw_lo, sw_hi, (uint32_t)(ii - sw_base));
+					const uint32_t S1 = SW_BYTE(ii - 1 - sw_base), S0 = SW_BYTE(ii - sw_base);
 					const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
+					const int m_seed = m - max_diff + P.max_seed_diff;      // max_seed_diff - (the same differences), bwtgap.c:153
 					if (s1 > m_seed - 1) allow_diff = false;
 					else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
 				}
 			}
 			// children go through a one-entry delay: the last one stays in registers as `pending`
 			auto emit = [&](int score, uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int count) {
-				if (p_valid) push_mem(p_score, p_k, p_l, p_i, p_ldp, p_mm, p_go, p_ge, p_state, p_a);
-				p_valid = true; p_k = nk; p_l = nl; p_i = ni; p_ldp = nldp;
-				p_mm = nmm & 0xff; p_go = ngo & 0xff; p_ge = nge & 0xff; p_state = nstate; p_a = e_a; p_score = score;
+				if (p_valid) push_mem(p_score, pe);
+				pe = mk_entry(nk, nl, ni, nldp, nmm & 0xff, ngo & 0xff, nge & 0xff, nstate, e_a); p_score = score;
 				n_entries += count;
 			};
 			const int sc0 = e_mm * P.s_mm + e_go * P.s_gapo + e_ge * P.s_gape;
 			int tmp = e_go + e_ge;
 			if (loggap) { const uint32_t v = (uint32_t)(e_ge + e_go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
-			if (allow_diff && e_i >= P.indel_end_skip + tmp && len - e_i >= P.indel_end_skip + tmp) {
+			// Text-form fast path.  While the next read symbols equal the text in front of the suffix, a level of the search
+			// tree is fully determined without memory: the only non-empty child is the matching one, which is the next pop
+			// (same score, newest), and the gap children -- if the bounds allow differences there -- are one insertion and
+			// one deletion.  So several levels are walked in this trip, as far as the 16-byte windows reach, and their gap
+			// groups leave as ONE stack entry (`more` older levels behind the newest, see the pop side).
+			bool ran = false;
+			if (tx1 && e_state == STATE_M && n_entries + 64 <= P.max_entries) {
+				const int ies = P.indel_end_skip + tmp, seed_lo = len - P.seed_len;
+				const int m_seed = m - max_diff + P.max_seed_diff;
+				int n = 0, icur = e_i, ilast = e_i; uint32_t pcur = k; bool grp_run = false;
+				for (;;) {
+					const uint32_t cc = SQ_BYTE((uint32_t)icur & 15u);
+					if (cc > 3u || pcur == 0u) break;
+					const uint32_t q = pcur - 1u;
+					if ((tw.x >> ((q & 15u) << 1) & 3u) != cc) break;
+					bool ad = true;
+					const bool us = seeded && icur > 0 && icur - seed_lo > 0;
+					if (icur > 0) {
+						if ((int)(BW_BYTE(icur - 1 - bw_base) & 127u) > m - 1) ad = false;
+						if (us && (int)(SW_BYTE(icur - seed_lo - 1 - sw_base) & 127u) > m_seed - 1) ad = false;
+					}
+					const bool g = ad && icur >= ies && len - icur >= ies && e_go < MG_READ;
+					if (n == 0) grp_run = g; else if (g != grp_run) break;
+					++n; pcur = q; ilast = icur;
+					// may the child (position icur, suffix q) be popped and expanded in this same trip?
+					if (n == NABWA_RUN_MAX || icur == 0) break;
+					if (m < (int)(BW_BYTE(icur - 1 - bw_base) & 127u)) break;       // its pop prunes it (bwtgap.c:156)
+					if ((icur & 15) == 0 || (q & 15u) == 0u) break;                  // read / text window ends
+					if (icur - 1 > 0 && icur - 2 < bw_base) break;                   // bound window ends
+					if (seeded && icur - 1 > 0 && icur - 1 - seed_lo > 0 && icur - 1 - seed_lo - 1 < sw_base) break;
+					--icur;
+				}
+				if (n) {
+					ran = true;
+					if (grp_run) emit(sc0 + P.s_gapo, k - (uint32_t)(n - 1), TXM, ilast, (int)(3u | (uint32_t)(n - 1) << 9), e_mm, e_go, e_ge, STATE_GROUP, 2 * n);
+					emit(sc0, pcur, TXM, ilast, 0, e_mm, e_go, e_ge, STATE_M, 1);
+				}
+			}
+			if (ran) { /* children done */ }
+			else if (allow_diff && e_i >= P.indel_end_skip + tmp && len - e_i >= P.indel_end_skip + tmp) {
 				// The gap children of one expansion (an insertion and/or up to four deletions, bwtgap.c:216-240) share one
 				// score and are pushed back to back, i.e. they are ADJACENT in that score's stack.  They travel as one
 				// STATE_GROUP entry: the parent's interval and position plus a member mask (bit 0 the insertion, bit 1+j the
-				// deletion of base j, GRP_EXT: gap extension of a deletion rather than gap open); a member is materialised --
+				// deletion of base j, GRP_EXT: gap extension of a deletion rather than gap open, bits 9..15: `more` older levels of a
+				// text-form run, each {insertion, deletion}); a member is materialised --
 				// the deletions by repeating the parent's rank query -- only if it is ever popped (see the pop side).  Most
 				// never are: once a hit exists, scores above best_score + s_mm end the search (bwtgap.c:144).
 				uint32_t dm = 0;
@@ -733,17 +861,20 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						emit(sc0 + P.s_gape, k, l, e_i, (int)(dm | GRP_EXT), e_mm, e_go, e_ge, STATE_GROUP, __popc(dm));
 				}
 			}
-			if (allow_diff && allow_M) {
+			if (ran) { /* children done */ }
+			else if (allow_diff && allow_M) {
 #pragma unroll
 				for (int j = 1; j <= 4; ++j) {
 					const int cc = (c + j) & 3; const bool is_mm = (j != 4 || c > 3);
 					const uint32_t nk = L2Q(cc) + CK(cc) + 1u, nl = L2Q(cc) + CL(cc);
-					if (nk <= nl) emit(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, is_mm ? e_i : 0, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, 1);
+					if (nk <= nl) { emit(sc0 + (is_mm ? P.s_mm : 0), nk, nl, e_i, is_mm ? e_i : 0, e_mm + (is_mm ? 1 : 0), e_go, e_ge, STATE_M, 1); if (!is_mm) match_child = true; }
 				}
 			} else if (c < 4) {
 				const uint32_t nk = L2Q(c) + CK(c) + 1u, nl = L2Q(c) + CL(c);
-				if (nk <= nl) emit(sc0, nk, nl, e_i, 0, e_mm, e_go, e_ge, STATE_M, 1);
+				if (nk <= nl) { emit(sc0, nk, nl, e_i, 0, e_mm, e_go, e_ge, STATE_M, 1); match_child = true; }
 			}
+			// the matching child of a one-row interval (always the last emit, still in the pending registers) goes on in text form
+			if (to_text && match_child) { pe.x = r_x - 1u; pe.y = TXM; }
 			if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 		}
 #undef L2Q
@@ -762,11 +893,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			atomicAdd(P.touch_counter, touches);
 			atomicAdd(P.touch_counter + 2, st_trips); atomicAdd(P.touch_counter + 3, st_expand); atomicAdd(P.touch_counter + 4, st_exact);
 			atomicAdd(P.touch_counter + 5, st_ent); atomicAdd(P.touch_counter + 6, st_spec); atomicAdd(P.touch_counter + 7, st_query);
-			atomicAdd(P.touch_counter + 8, st_two); atomicAdd(P.touch_counter + 9, st_exit); atomicAdd(P.touch_counter + 10, st_jump);
+			atomicAdd(P.touch_counter + 8, st_two); atomicAdd(P.touch_counter + 9, st_exit); atomicAdd(P.touch_counter + 10, st_jump); atomicAdd(P.touch_counter + 11, st_txe); atomicAdd(P.touch_counter + 12, st_txt);
 		}
 	}
 }
 
+#undef p_valid
+#undef BW_BYTE
+#undef SW_BYTE
+#undef SQ_BYTE
 #undef RID
 #undef REC
 #undef MD_READ
@@ -785,7 +920,7 @@ extern "C" int nabwa_width_occupancy(void)
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
 {
-	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 24;
+	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80;
 	if (P->touch_counter) {
 		if (wide) hipLaunchKernelGGL((fm_search_kernel<true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
 		else hipLaunchKernelGGL((fm_search_kernel<false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
@@ -798,7 +933,7 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 	int nb = 0;
 	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<true, false>, NABWA_SEARCH_BLOCK, 0)
 						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false, false>, NABWA_SEARCH_BLOCK,
-																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 24);
+																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80);
 	return e == hipSuccess ? nb : 0;
 }
 
@@ -943,4 +1078,24 @@ extern "C" void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *
 	if (n <= 0) return;
 	hipLaunchKernelGGL(checksum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, n_aln, aln, aln_cap, status, wide_idx,
 					   aln2, aln_cap2, sum, rows);
+}
+
+// work order of the search kernel: reads of class 1 (kernel W) from the front, the others from the back
+__global__ __launch_bounds__(256) void partition_kernel(int n, const uint8_t *__restrict__ cls, int32_t *__restrict__ ids, unsigned int *__restrict__ cnt)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const bool a = i < n && cls[i] != 0, b = i < n && cls[i] == 0;
+	const unsigned long long ma = __ballot(a), mb = __ballot(b);
+	const unsigned int lane = threadIdx.x & 63u;
+	unsigned int ba = 0, bb = 0;
+	if (lane == 0) { if (ma) ba = atomicAdd(cnt, (unsigned int)__popcll(ma)); if (mb) bb = atomicAdd(cnt + 1, (unsigned int)__popcll(mb)); }
+	ba = __shfl(ba, 0); bb = __shfl(bb, 0);
+	if (a) ids[ba + (unsigned int)__popcll(ma & ((1ull << lane) - 1ull))] = i;
+	if (b) ids[(unsigned int)n - 1u - (bb + (unsigned int)__popcll(mb & ((1ull << lane) - 1ull)))] = i;
+}
+
+extern "C" void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s)
+{
+	if (n <= 0) return;
+	hipLaunchKernelGGL(partition_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cls, ids, cnt);
 }

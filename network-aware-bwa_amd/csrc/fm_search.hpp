@@ -23,6 +23,7 @@ struct SearchParams {
 	size_t wstride;
 	uint32_t woff_bid, woff_sbid;
 	uint32_t WL, WLB, SLB;
+	int text_mode;                            // 0: never leave the FM-index (the touch-counting run); 1: text mode where the index has it
 	const uint32_t *rd_key;                   // per read six interval-table keys [6*rid + ..] (see pad_reads_kernel), ~0u = none
 	uint8_t *rd_nN;                           // per read: number of N in the read, saturated at 255
 	// per-lane scratch of kernel S: the arena (and, wide pass only, links / free list / heads)
@@ -36,6 +37,8 @@ struct SearchParams {
 	uint4 *aln;
 	int aln_cap;
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
-	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL)
+	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
+	uint8_t *rd_cls;                          // kernel W -> partition: 1 = one strand of the read occurs exactly (no restart in its width pass)
+	const unsigned int *n_sync;               // first *n_sync work items are such reads: their waves run in lockstep (see fm_search_kernel)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
 };

@@ -33,6 +33,7 @@ void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, c
 						 const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						 uint4 *out, hipStream_t s);
 int nabwa_search_occupancy(int wide, int ns);
+void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
 							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, hipStream_t s);
 }
@@ -236,9 +237,9 @@ struct nabwa_batch {
 	hipEvent_t ev0, ev1, evw;
 	float last_ms;
 	// device inputs
-	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; uint32_t *d_key; int max_len;
+	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; uint32_t *d_key; uint8_t *d_cls; int32_t *d_perm; unsigned int *d_ncls; int max_len;
 	// first pass
-	SearchParams P; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
+	SearchParams P; int class_sort; uint32_t NS_wide; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
 	unsigned int *d_counter, *d_novf; int32_t *d_ovf_ids;
 	// wide pass (allocated on demand)
@@ -277,7 +278,7 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->ix->device);
-	void *ptrs[] = { b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+	void *ptrs[] = { b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -319,6 +320,24 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		const long ns = (long)(md_sizing + 1) * opt->s_mm + (long)(g + 1) * opt->s_gapo + (long)(opt->max_gape + 1) * opt->s_gape;
 		if (ns > (long)NS) NS = (uint32_t)ns;
 	}
+	/* First pass: score levels that can actually hold an entry.  A child is only made of a parent that passed the
+	 * m >= 0 test (bwtgap.c:152-154), so it has at most max_diff + 1 counted differences, at most max_gapo opens and
+	 * max_gape extensions; its score is the largest index the per-score lists are addressed with.  (The formula above
+	 * is the reference's initial best_score, a value that is compared, never an index; the second pass still sizes by it.) */
+	uint32_t NS1 = 1;
+	{
+		int mdx = 0, mgx = 0;
+		for (int i = 0; i < n; ++i) { if (md[i] > mdx) mdx = md[i]; if (mg[i] > mgx) mgx = mg[i]; }
+		const bool gape_counts = opt->mode & NABWA_MODE_GAPE;
+		for (int a = 0; a <= mdx + 1; ++a)
+			for (int g = 0; g <= mgx; ++g)
+				for (int e = 0; e <= (g ? opt->max_gape : 0); ++e) {
+					if (a + g + (gape_counts ? e : 0) > mdx + 1) continue;
+					const long sc = (long)a * opt->s_mm + (long)g * opt->s_gapo + (long)e * opt->s_gape;
+					if (sc + 1 > (long)NS1) NS1 = (uint32_t)(sc + 1);
+				}
+		if (NS1 > NS) NS1 = NS;
+	}
 	if (NS > 128 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 31)
 		return fail(NABWA_EINVAL, "option block needs more than 128 score levels (unsupported)");
 	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
@@ -340,6 +359,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
 	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
+	BCHK(hipMalloc(&b->d_cls, n ? n : 1)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 8));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
@@ -359,6 +379,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
 	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key;
+	P.text_mode = env_int("NABWA_TEXT_KERNELS", 3);      /* bit 0: width kernel, bit 1: search kernel */
 	if (ix->bwt[0].kmer_T != ix->bwt[1].kmer_T) P.bwt[0].kmer_T = P.bwt[1].kmer_T = 0;
 	P.ids = 0; P.n = n;
 	P.s_mm = opt->s_mm; P.s_gapo = opt->s_gapo; P.s_gape = opt->s_gape; P.mode = opt->mode;
@@ -367,14 +388,16 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	int cap1 = env_int("NABWA_CAP1", 4096);
 	if (cap1 < 16) cap1 = 16;
 	if (cap1 > 65534) cap1 = 65534;
-	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, NS);
+	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, NS1);
+	b->NS_wide = NS;
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
+	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
 	if (P.aln_cap < 1) P.aln_cap = 1;
 
 	hipDeviceProp_t prop;
 	BCHK(hipGetDeviceProperties(&prop, ix->device));
-	int occ = nabwa_search_occupancy(0, (int)NS);
+	int occ = nabwa_search_occupancy(0, (int)NS1);
 	if (occ < 1) occ = 1;
 	const int occ_env = env_int("NABWA_BLOCKS_PER_CU", 0);
 	if (occ_env > 0) occ = occ_env;
@@ -412,9 +435,15 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
 	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
 	HIPCHK(hipEventRecord(b->evw, b->stream));
-	nabwa_launch_fm_width(&b->P, b->n_blocks_w, b->stream);
+	SearchParams PW = b->P; PW.ids = 0; PW.rd_cls = b->class_sort ? b->d_cls : 0;
+	nabwa_launch_fm_width(&PW, b->n_blocks_w, b->stream);
+	if (b->class_sort) {      /* work order of the search: reads with an exact occurrence first, in lockstep waves */
+		HIPCHK(hipMemsetAsync(b->d_ncls, 0, 8, b->stream));
+		nabwa_launch_partition(b->n, b->d_cls, b->d_perm, b->d_ncls, b->stream);
+	}
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
-	nabwa_launch_fm_search(&b->P, b->n_blocks, 0, b->stream);
+	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls : 0;
+	nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
 	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
 	HIPCHK(hipGetLastError());
@@ -447,7 +476,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	}
 	SearchParams Q = b->P;
 	uint64_t cap2 = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
-	layout(Q, (uint32_t)cap2, true, b->max_len, b->opt.seed_len, Q.NS);
+	layout(Q, (uint32_t)cap2, true, b->max_len, b->opt.seed_len, b->NS_wide);
 	long blocks2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
 	const long max_blocks2 = env_int("NABWA_WIDE_BLOCKS", 2);
 	if (blocks2 > max_blocks2) blocks2 = max_blocks2;
@@ -490,13 +519,13 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	b->P.touch_counter = b->d_sum;
 	/* the reference walks every exact tail row by row: count with the tail jump off (NABWA_TRIP_STATS=jump keeps it
 	 * on to profile the production trips; the touch totals are then not the reference's) */
-	const uint32_t kt0 = b->P.bwt[0].kmer_T, kt1 = b->P.bwt[1].kmer_T;
+	const uint32_t kt0 = b->P.bwt[0].kmer_T, kt1 = b->P.bwt[1].kmer_T; const int tm0 = b->P.text_mode;
 	const char *ts = getenv("NABWA_TRIP_STATS");
-	if (!(ts && strcmp(ts, "jump") == 0)) b->P.bwt[0].kmer_T = b->P.bwt[1].kmer_T = 0;
+	if (!(ts && strcmp(ts, "jump") == 0)) { b->P.bwt[0].kmer_T = b->P.bwt[1].kmer_T = 0; b->P.text_mode = 0; }
 	int r = nabwa_batch_run(b);
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
 	b->P.touch_counter = 0;
-	b->P.bwt[0].kmer_T = kt0; b->P.bwt[1].kmer_T = kt1;
+	b->P.bwt[0].kmer_T = kt0; b->P.bwt[1].kmer_T = kt1; b->P.text_mode = tm0;
 	if (r != NABWA_OK) return r;
 	unsigned long long v[2] = { 0, 0 };
 	HIPCHK(hipMemcpy(v, b->d_sum, 16, hipMemcpyDeviceToHost));
@@ -505,8 +534,8 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	if (getenv("NABWA_TRIP_STATS")) {
 		unsigned long long t[16];
 		HIPCHK(hipMemcpy(t, b->d_sum, 128, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu\n",
-				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10]);
+		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu text-expand %llu text-tail %llu\n",
+				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12]);
 	}
 	return NABWA_OK;
 }
