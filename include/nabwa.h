@@ -247,6 +247,10 @@ int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_p
 					int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
 					const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2]);
 
+/* Read-back of the index parts derived at load time (tests): what 0 = full SA, 1 = inverse SA, 2 = text bases (one per
+ * word), 3 = interval-table entries {k, l} of the last level (two words per key), 4 = the table's depth T (one word). */
+int nabwa_index_export(const nabwa_index_t *ix, int which, int what, uint64_t first, uint64_t n, uint32_t *out);
+
 /* Rank primitives for tests: Occ of all four bases at rows k[i] (bwt_occ4, bwt.c:159-176). */
 int nabwa_occ4(nabwa_index_t *ix, int which, int n, const uint32_t *k, uint32_t *cnt_out /* n x 4 */);
 

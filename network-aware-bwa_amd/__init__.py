@@ -244,6 +244,7 @@ def lib():
     L.nabwa_encode_read.restype = C.c_int
     L.nabwa_encode_read.argtypes = [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]
     L.nabwa_se_finish.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
+    L.nabwa_index_export.argtypes = [_P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P]
     L.nabwa_pe_opt_default.argtypes = [_P]
     L.nabwa_pe_opt_default.restype = None
     L.nabwa_pe_posn.argtypes = [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]
@@ -354,6 +355,12 @@ class Index:
                                    _ptr(np.ascontiguousarray(seq, np.uint8)), _ptr(np.ascontiguousarray(rseq, np.uint8)),
                                    _ptr(n_aln), _ptr(rows), recs, tot, mp))
         return list(tot), list(mp)
+
+    def export(self, which, what, first, n):
+        """derived index parts for tests (nabwa_index_export): 0 full SA, 1 inverse SA, 2 text bases, 3 interval table, 4 its depth"""
+        out = np.zeros(int(n) * (2 if what == 3 else 1), np.uint32)
+        _chk(lib().nabwa_index_export(self._h, int(which), int(what), int(first), int(n), _ptr(out)))
+        return out.reshape(-1, 2) if what == 3 else out
 
     def seq_len(self, which=0):
         return lib().nabwa_index_seq_len(self._h, which)

@@ -224,6 +224,36 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 	delete ix;
 }
 
+/* Read-back of the derived index parts (tests): what 0 = sa_full[first..), 1 = isa[first..), 2 = text bases first.. (one per
+ * word), 3 = interval table, level kmer_T: entry pairs {k, l} of keys first.. (2 words each), 4 = kmer_T (one word). */
+extern "C" int nabwa_index_export(const nabwa_index_t *ix, int which, int what, uint64_t first, uint64_t n, uint32_t *out)
+{
+	if (!ix || !out || which < 0 || which > 1) return fail(NABWA_EINVAL, "bad argument");
+	HIPCHK(hipSetDevice(ix->device));
+	const DevBwt &B = ix->bwt[which];
+	if (what == 4) { out[0] = B.kmer_T; return NABWA_OK; }
+	if (what == 3) {
+		if (!B.kmer || first + n > (1ull << (2 * B.kmer_T))) return fail(NABWA_EINVAL, "no interval table / out of range");
+		HIPCHK(hipMemcpy(out, B.kmer + first, n * 8, hipMemcpyDeviceToHost));
+		return NABWA_OK;
+	}
+	if (!B.sa_full) return fail(NABWA_EINVAL, "index has no text-mode companions (no SA given, or NABWA_TEXT_MODE=0)");
+	if (what == 0 || what == 1) {
+		if (first + n > (uint64_t)B.seq_len + 1) return fail(NABWA_EINVAL, "out of range");
+		HIPCHK(hipMemcpy(out, (what ? B.isa : B.sa_full) + first, n * 4, hipMemcpyDeviceToHost));
+		return NABWA_OK;
+	}
+	if (what == 2) {
+		if (first + n > (uint64_t)B.seq_len) return fail(NABWA_EINVAL, "out of range");
+		const uint64_t w0 = first / 16, w1 = (first + n + 15) / 16;
+		std::vector<uint32_t> w(w1 - w0);
+		HIPCHK(hipMemcpy(w.data(), B.text + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost));
+		for (uint64_t j = 0; j < n; ++j) { const uint64_t p = first + j; out[j] = w[p / 16 - w0] >> (2 * (p & 15)) & 3u; }
+		return NABWA_OK;
+	}
+	return fail(NABWA_EINVAL, "unknown part");
+}
+
 extern "C" uint32_t nabwa_index_seq_len(const nabwa_index_t *ix, int which) { return ix->bwt[which & 1].seq_len; }
 extern "C" uint64_t nabwa_index_device_bytes(const nabwa_index_t *ix) { return ix->bytes; }
 

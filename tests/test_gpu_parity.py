@@ -266,3 +266,45 @@ def test_drop_in_on_reference_records(gix):
             assert ours[i].bits0 == theirs[i].bits0 and ours[i].sa == theirs[i].sa and ours[i].c1c2seq == theirs[i].c1c2seq
             if ours[i].n_aln:
                 assert C.string_at(ours[i].aln, 16 * ours[i].n_aln) == C.string_at(theirs[i].aln, 16 * theirs[i].n_aln)
+
+
+def test_text_mode_companions(gix):
+    """what the index derives at load time (fm_index.hip): the text of both indexes equals the toy genome's .pac
+    (forward / reversed), the inverse SA inverts the full SA, the full SA equals the reference's bwt_sa known answers,
+    and the interval table holds the oracle's backward-search intervals"""
+    n = gix.seq_len(0)
+    pac = np.fromfile(T.TOY + ".pac", np.uint8)
+    bases = ((pac[:, None] >> np.array([6, 4, 2, 0])) & 3).reshape(-1)[:n]        # first base in the top bits (bwtaln.h:33)
+    assert (gix.export(0, 2, 0, n) == bases).all()
+    assert (gix.export(1, 2, 0, n) == bases[::-1]).all()                          # .rbwt indexes the reversed text (bwtindex.c:116-143)
+    v = np.load(os.path.join(T.GOLDEN, "vectors.npz"))
+    for which in (0, 1):
+        sa = gix.export(which, 0, 0, n + 1)
+        isa = gix.export(which, 1, 0, n + 1)
+        assert sa[0] == 0xffffffff and isa[n] == 0
+        assert (isa[sa[1:]] == np.arange(1, n + 1)).all()
+        assert (sa[v["sa_k%d" % which]] == v["sa_v%d" % which]).all()
+    # interval table against a plain backward search with the reference's own rank answers (oracle)
+    lib = T.load_oracle()
+    oix = T.OracleIndex(lib)
+    Tdepth = int(gix.export(0, 4, 0, 1)[0])
+    assert Tdepth >= 1
+    rng = np.random.default_rng(5)
+    keys = np.unique(np.concatenate([rng.integers(0, 4 ** Tdepth, 300), [0, 4 ** Tdepth - 1]]))
+    for which in (0, 1):
+        bw = oix.bwt(which)
+        hdr = np.fromfile(T.TOY + (".rbwt" if which else ".bwt"), np.uint32, 5)   # primary, C(C), C(G), C(T), seq_len (bwtio.c)
+        L2 = [0, int(hdr[1]), int(hdr[2]), int(hdr[3])]
+        for key in keys:
+            k, l = 0, n
+            for t in range(Tdepth):
+                c = int(key) >> (2 * (Tdepth - 1 - t)) & 3
+                ok, ol = lib.orc_occ(bw, (k - 1) & 0xffffffff, c), lib.orc_occ(bw, l, c)
+                k, l = L2[c] + ok + 1, L2[c] + ol
+                if k > l:
+                    break
+            got = gix.export(which, 3, int(key), 1)[0]
+            if k > l:
+                assert got[0] > got[1], (which, key)
+            else:
+                assert (int(got[0]), int(got[1])) == (k, l), (which, key)
