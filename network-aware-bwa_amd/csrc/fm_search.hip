@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint32_t k = 0, l = 0;
 	// search globals
 	int max_diff = 0, best_score = 0, best_cnt = 0, n_aln = 0, max_ent = 0, n_entries = 0;
-	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;
+	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;   // masks: non-empty scores; the first pass has at most 64 levels (host) and uses mask_lo only
 	// current entry
 	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, e_score = 0, m = 0;
 	// pending entry: the last child pushed by the previous expansion, still in registers
@@ -364,7 +364,14 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	auto head_set = [&](int score, uint32_t v) {
 		if (WIDE) ghead[score] = v; else s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x] = (uint16_t)v;
 	};
-	auto mask_has = [&](int score) -> bool { return score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull); };
+	auto mask_has = [&](int score) -> bool { if (!WIDE) return mask_lo >> score & 1ull; return score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull); };
+	auto mask_set = [&](int score) { if (!WIDE || score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64); };
+	auto mask_clr = [&](int score) { if (!WIDE || score < 64) mask_lo &= ~(1ull << score); else mask_hi &= ~(1ull << (score - 64)); };
+	auto mask_any = [&]() -> bool { return WIDE ? (mask_lo | mask_hi) != 0ull : mask_lo != 0ull; };
+	auto mask_first = [&]() -> int {          // lowest non-empty score, 0x7fffffff when none
+		if (mask_lo) return __ffsll((unsigned long long)mask_lo) - 1;
+		return (WIDE && mask_hi) ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff;
+	};
 	// After the first hit best_score is final (bwtgap.c:170), and the loop ends at the first pop whose score
 	// exceeds best_score + s_mm (bwtgap.c:144): such a child can never be expanded.  It is still COUNTED
 	// (n_entries feeds max_entries and the bwtgap.c:140 cut-off) but never written to the arena.
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	};
 	auto push_mem = [&](int score, uint4 e) {
 		if (ovf || never_popped(score)) return;
-		if (score >= (int)P.NS) { ovf = true; return; }            // cannot happen (nabwa_api.hip sizes NS); the second pass would take over
+		if ((uint32_t)score >= P.NS) { ovf = true; return; }       // cannot happen (nabwa_api.hip sizes NS); the second pass would take over
 		uint32_t s;
 		if (WIDE && nfree) s = freel[--nfree];
 		else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (WIDE) lnk[s] = prev; else e.w |= prev;
 		ent[s] = e;
 		head_set(score, s);
-		if (score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64);
+		mask_set(score);
 	};
 
 	// first pass only: the entry at the head of the lowest non-empty score list is fetched ahead of its pop while the
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		const uint32_t nx = WIDE ? r_lnk : (r_ent.w & 0xffffu);
 		if (WIDE) freel[nfree++] = ent_slot;
 		head_set(e_score, nx);
-		if (nx == NIL) { if (e_score < 64) mask_lo &= ~(1ull << e_score); else mask_hi &= ~(1ull << (e_score - 64)); }
+		if (nx == NIL) mask_clr(e_score);
 		--n_entries;
 		if (!nonstop && e_score > best_score + P.s_mm) finish = true;    // bwtgap.c:144
 	};
@@ -494,8 +501,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				if (n_entries > P.max_entries) finish = true;                 // bwtgap.c:140
 			}
 			if (!finish) {
-				const int best_mem = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1
-											 : (mask_hi ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff);
+				const int best_mem = mask_first();
 				if (p_valid && p_score <= best_mem) {
 					// the pending child is the newest entry of the lowest score: it is the pop
 					unpack(pe);
@@ -637,8 +643,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		bool pf_now = false; uint32_t pf_cand = NIL;
 		if (!WIDE) {
 			if (want_ent) { pf_cand = ent_slot; pf_now = true; }            // a pop that was not fetched ahead: fetch now, pop next trip
-			else if ((kind == 2 || kind == 4 || kind == 7) && !p_valid && (mask_lo | mask_hi) != 0ull) {
-				const int bm = mask_lo ? __ffsll((unsigned long long)mask_lo) - 1 : 64 + __ffsll((unsigned long long)mask_hi) - 1;
+			else if ((kind == 2 || kind == 4 || kind == 7) && !p_valid && mask_any()) {
+				const int bm = mask_first();
 				pf_cand = head_get(bm);
 				pf_now = pf_cand != pf_slot;
 			}
@@ -669,7 +675,10 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0; cl = ck;
 		if (query && kind) {
 			cl = nabwa_count4(a0, a1, a2, a3, rl);
-			if (kvalid) ck = two ? nabwa_count4(b0, b1, b2, b3, rk) : nabwa_count4(a0, a1, a2, a3, rk);
+			if (kvalid) {       // one counting sequence for row k-1 too: pick its bucket first (16 selects < a third copy of the count)
+				const uint4 s0 = two ? b0 : a0, s1 = two ? b1 : a1, s2 = two ? b2 : a2, s3 = two ? b3 : a3;
+				ck = nabwa_count4(s0, s1, s2, s3, rk);
+			}
 			if (COUNT && kind != 5) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);   // (the reference derived a group's members in the parent's query)
 		}
 		const bool tx1 = tx && kind == 1;
@@ -1080,22 +1089,37 @@ extern "C" void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *
 					   aln2, aln_cap2, sum, rows);
 }
 
-// work order of the search kernel: reads of class 1 (kernel W) from the front, the others from the back
+// work order of the search kernel: reads of class 1 (kernel W) from the front, the others from the back.
+// One wave handles 16 consecutive groups of 64 reads with ONE atomic per class (single-address atomics cost ~11 ns each).
 __global__ __launch_bounds__(256) void partition_kernel(int n, const uint8_t *__restrict__ cls, int32_t *__restrict__ ids, unsigned int *__restrict__ cnt)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	const bool a = i < n && cls[i] != 0, b = i < n && cls[i] == 0;
-	const unsigned long long ma = __ballot(a), mb = __ballot(b);
 	const unsigned int lane = threadIdx.x & 63u;
+	const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+	const long first = wave * 1024;
+	if (first >= n) return;
+	unsigned long long ma[16], mb[16]; unsigned int na = 0, nb = 0;
+#pragma unroll
+	for (int g = 0; g < 16; ++g) {
+		const long i = first + g * 64 + lane;
+		const bool in = i < n; const uint8_t c = in ? cls[i] : 0;
+		ma[g] = __ballot(in && c != 0); mb[g] = __ballot(in && c == 0);
+		na += (unsigned int)__popcll(ma[g]); nb += (unsigned int)__popcll(mb[g]);
+	}
 	unsigned int ba = 0, bb = 0;
-	if (lane == 0) { if (ma) ba = atomicAdd(cnt, (unsigned int)__popcll(ma)); if (mb) bb = atomicAdd(cnt + 1, (unsigned int)__popcll(mb)); }
+	if (lane == 0) { if (na) ba = atomicAdd(cnt, na); if (nb) bb = atomicAdd(cnt + 1, nb); }
 	ba = __shfl(ba, 0); bb = __shfl(bb, 0);
-	if (a) ids[ba + (unsigned int)__popcll(ma & ((1ull << lane) - 1ull))] = i;
-	if (b) ids[(unsigned int)n - 1u - (bb + (unsigned int)__popcll(mb & ((1ull << lane) - 1ull)))] = i;
+#pragma unroll
+	for (int g = 0; g < 16; ++g) {
+		const long i = first + g * 64 + lane;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		if (ma[g] >> lane & 1ull) ids[ba + (unsigned int)__popcll(ma[g] & below)] = (int32_t)i;
+		if (mb[g] >> lane & 1ull) ids[(unsigned int)n - 1u - (bb + (unsigned int)__popcll(mb[g] & below))] = (int32_t)i;
+		ba += (unsigned int)__popcll(ma[g]); bb += (unsigned int)__popcll(mb[g]);
+	}
 }
 
 extern "C" void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(partition_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cls, ids, cnt);
+	hipLaunchKernelGGL(partition_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, n, cls, ids, cnt);
 }

@@ -473,7 +473,11 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	}
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
 	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls : 0;
-	nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
+	if (b->P.NS <= 64) nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
+	else {      /* the first-pass kernel tracks at most 64 score levels: such option blocks go through the second pass whole */
+		HIPCHK(hipMemsetAsync(b->d_status, NABWA_ST_OVERFLOW, b->n, b->stream));
+		HIPCHK(hipMemsetAsync(b->d_naln, 0, (size_t)b->n * 4, b->stream));
+	}
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
 	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
 	HIPCHK(hipGetLastError());

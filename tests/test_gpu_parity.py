@@ -308,3 +308,24 @@ def test_text_mode_companions(gix):
                 assert got[0] > got[1], (which, key)
             else:
                 assert (int(got[0]), int(got[1])) == (k, l), (which, key)
+
+
+def test_more_than_64_score_levels_go_through_the_second_pass(gix, olib, oix):
+    """an option block whose entries can score above 63 (gap extensions not counted as differences, `aln -e 15`) is beyond
+    the first-pass kernel's 64-bit score mask: the whole batch takes the second pass, and the answers are the oracle's"""
+    rng = np.random.default_rng(99)
+    reads = random_reads(rng, 300, toy_genome(), lens=(50, 76, 100), err=0.02)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = T.default_opt()
+    opt.max_gape = 15
+    opt.mode &= ~1                                  # BWA_MODE_GAPE off, as `aln -e` does
+    want, wmax = T.oracle_cal_sa_reg_gap(olib, oix.h, opt, seq, rseq, off, per_read=0, n_threads=8)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    n2 = b.sync()
+    got, gmax = b.fetch()
+    b.close()
+    assert n2 == len(reads)                         # every read went through the wide instantiation
+    bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
+    assert not bad, "GPU differs from the oracle for %d reads" % len(bad)
+    assert np.array_equal(gmax, wmax)
