@@ -48,6 +48,9 @@
 #define STATE_GROUP 3   // arena only: the gap children of one expansion, see fm_search_kernel
 #define GRP_EXT 0x100u
 #define TXM 0xffffffffu   // l of an interval carried in text form (k = text position)
+#ifndef NABWA_W_WAVES
+#define NABWA_W_WAVES 5   // kernel W: waves per SIMD the register budget is bounded for (102 VGPRs)
+#endif
 #ifndef NABWA_WORK_CHUNK
 #define NABWA_WORK_CHUNK 256u
 #endif
@@ -92,39 +95,40 @@ extern __shared__ uint16_t s_head[];   // search kernel, first pass only: [score
 
 // =====================================================================================
 // Kernel W: the four bwt_cal_width passes (bwtaln.c:52-76,123-130) of every read.
-// All lanes run the same code on every trip (one width step of TWO passes: the forward-index
-// pass on seq and the reverse-index pass on rseq, then the same for the seed suffix), so the
-// wave stays converged; results go to the read's own record in HBM in 16-byte chunks:
+// One lane = one strand of one read (work item 2 * read + strand): its full pass, then its seed pass; all lanes run
+// the same code on every trip, so the wave stays converged; results go to the read's own record in HBM in 16-byte chunks:
 //   Wd [2][WL]  u32 interval widths (only gap_shadow reads them later)
 //   Bd [2][WLB] bound bytes: min(bid,127) | (w[i-1]==w[i]) << 7
 //   SBd[2][SLB] the same for the seed passes
 // =====================================================================================
 template <bool COUNT>
-__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const SearchParams P)
+__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_kernel(const SearchParams P)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	bool run = false, done = false;
-	unsigned int w_next = 0, w_end = 0;                     // this wave's block of read numbers
-	uint32_t rid = 0; int len = 0, phase = 0, wi = 0, n = 0, sbase = 0, nN = 0;
+	unsigned int w_next = 0, w_end = 0;                     // this wave's block of work items (item = 2 * read + strand)
+	uint32_t rid = 0, x = 0; int len = 0, phase = 0, wi = 0, n = 0, sbase = 0, nN = 0;
 	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
 #define WREC (P.wdata + (size_t)rid * P.wstride)
-	// text mode (nabwa_dev.hpp): pass x has narrowed to ONE row, the suffix at text position tp[x]; the next symbol
+#define BX(f_) (x ? P.bwt[1].f_ : P.bwt[0].f_)              /* this lane's index: strand x is matched against bwt[x] (bwtaln.c:123-130) */
+	// text mode (nabwa_dev.hpp): the pass has narrowed to ONE row, the suffix at text position tp; the next symbol
 	// matches iff it equals the text base in front of it, and the width stays 1 (kk == ll is kept as it is)
-	uint32_t tmode = 0, tp[2] = { 0, 0 }, twtag[2] = { 0xffffffffu, 0xffffffffu }; uint2 twin[2];
-	twin[0] = twin[1] = make_uint2(0u, 0u);
+	bool tmode = false; uint32_t tp = 0, twtag = 0xffffffffu; uint2 twin = make_uint2(0u, 0u);
 	const bool text_ok = (P.text_mode & 1) && P.bwt[0].sa_full && P.bwt[1].sa_full;
-	uint32_t kk[2] = { 0, 0 }, ll[2] = { 0, 0 }, pw[2] = { 0, 0 }; int bid[2] = { 0, 0 };
-	uint32_t wkey[2] = { 0xffffffffu, 0xffffffffu }; bool tok = false;   // interval-table keys of this phase's first KT symbols
+	uint32_t kk = 0, ll = 0, pw = 0; int bid = 0;
+	uint32_t wkey = 0xffffffffu; bool tok = false;          // interval-table key of this phase's first KT symbols
 	const int KT = (int)P.bwt[0].kmer_T;
-	uint4 wacc[2]; uint64_t blo[2] = { 0, 0 }, bhi[2] = { 0, 0 }, slo[2] = { 0, 0 }, shi[2] = { 0, 0 }; int stag[2] = { -1, -1 };
+	uint4 wacc = make_uint4(0, 0, 0, 0); uint64_t blo = 0, bhi = 0, slo = 0, shi = 0; int stag = -1;
 	unsigned long long touches = 0;
-	wacc[0] = wacc[1] = make_uint4(0, 0, 0, 0);
 
 	for (;;) {
-		const unsigned long long need = __ballot(!run && !done);
+		unsigned long long need = __ballot(!run && !done);
+		// equal-length reads (P.w_sync): a wave takes 64 new items only when all its lanes are done, so every lane is at the
+		// same position of the same phase and the wave executes ONE of the paths below per trip, not all of them
+		if (P.w_sync && __ballot(run) != 0ull) need = 0ull;
 		if (need) {
-			// read numbers come in blocks of NABWA_WORK_CHUNK per wave: one atomic on the shared counter per block, not per
-			// refill (a few hundred million single-address atomics per second is all the L2 gives)
+			// work items come in blocks of NABWA_WORK_CHUNK per wave: one atomic on the shared counter per block, not per
+			// refill (a single address takes ~10^8 atomics per second)
 			if (w_next == w_end) {
 				unsigned int base = 0;
 				if (lane == 0) base = atomicAdd(P.work_counter + 1, (unsigned int)NABWA_WORK_CHUNK);
@@ -135,155 +139,160 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 			w_next += min((unsigned int)__popcll(need), avail);
 			if (!run && !done && rank < avail) {
 				const unsigned int idx = base + rank;
-				if (idx < (unsigned int)P.n) {
-					rid = P.ids ? (uint32_t)P.ids[idx] : idx;
+				if (idx < 2u * (unsigned int)P.n) {
+					rid = P.ids ? (uint32_t)P.ids[idx >> 1] : idx >> 1; x = idx & 1u;
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o;
-					nN = 0; stag[0] = stag[1] = -1;
+					nN = 0; stag = -1;
 					if (len > 0) {
-						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = 0;
-						if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 2); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
-#pragma unroll
-						for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; blo[x] = bhi[x] = 0; }
-					} else { P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[rid] = 0; }
+						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = false;
+						if (KT) { wkey = P.rd_key[6 * (size_t)rid + 2 + x]; tok = wkey != 0xffffffffu; }
+						kk = 0; ll = BX(seq_len); bid = 0; pw = 0; blo = bhi = 0;
+					} else { if (x == 0u) P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = 0; }
 				} else done = true;
 			}
 		}
 		if (__ballot(!done) == 0ull) break;
-		// output of position p of both passes: width, bound byte, 16-byte chunk flushes; `last` = the terminator
-		// {w = 0, bid = ++bid} after the final position (bwtaln.c:73-74)
+		// output of position p: width, bound byte, 16-byte chunk flushes; `last` = the terminator {w = 0, bid = ++bid}
+		// after the final position (bwtaln.c:73-74)
 		auto out_pos = [&](int p, bool last) {
 			uint8_t *const rec = WREC;
-			uint32_t *const wbase = (uint32_t*)rec;
-			uint8_t *const bbase = rec + (phase ? P.woff_sbid : P.woff_bid);
-			const uint32_t bstride = phase ? P.SLB : P.WLB;
-#pragma unroll
-			for (int x = 0; x < 2; ++x) {
-				if (last) ++bid[x];
-				const uint32_t wv = last ? 0u : ll[x] - kk[x] + 1u;
-				const uint32_t bv = (uint32_t)(bid[x] > 127 ? 127 : bid[x]) | ((p > 0 && wv == pw[x]) ? 128u : 0u);
-				set_word(wacc[x], (uint32_t)p & 3u, wv);
-				{ const uint64_t sh = (uint64_t)bv << (((uint32_t)p & 7u) << 3); if (p & 8) bhi[x] |= sh; else blo[x] |= sh; }
-				pw[x] = wv;
-				if (phase == 0 && ((p & 3) == 3 || last)) *(uint4*)(wbase + x * P.WL + (p & ~3)) = wacc[x];
-				if ((p & 15) == 15 || last) {
-					*(uint4*)(bbase + x * bstride + (p & ~15)) = make_uint4((uint32_t)blo[x], (uint32_t)(blo[x] >> 32), (uint32_t)bhi[x], (uint32_t)(bhi[x] >> 32));
-					blo[x] = bhi[x] = 0;
-				}
+			if (last) ++bid;
+			const uint32_t wv = last ? 0u : ll - kk + 1u;
+			const uint32_t bv = (uint32_t)(bid > 127 ? 127 : bid) | ((p > 0 && wv == pw) ? 128u : 0u);
+			set_word(wacc, (uint32_t)p & 3u, wv);
+			{ const uint64_t sh = (uint64_t)bv << (((uint32_t)p & 7u) << 3); if (p & 8) bhi |= sh; else blo |= sh; }
+			pw = wv;
+			if (phase == 0 && ((p & 3) == 3 || last)) *(uint4*)((uint32_t*)rec + x * P.WL + (p & ~3)) = wacc;
+			if ((p & 15) == 15 || last) {
+				*(uint4*)(rec + (phase ? P.woff_sbid + x * P.SLB : P.woff_bid + x * P.WLB) + (p & ~15)) =
+					make_uint4((uint32_t)blo, (uint32_t)(blo >> 32), (uint32_t)bhi, (uint32_t)(bhi >> 32));
+				blo = bhi = 0;
 			}
 		};
-		if (run && tok && wi + 4 <= KT && wi + 4 < n) {
+		// bulk text trip: a full pass in text mode at a 16-position chunk boundary -- compare the chunk's 16 read symbols
+		// with the 16 text bases to the left of the suffix as packed words; if all match, every width is 1, every bound
+		// byte repeats (no restart, w[i-1] == w[i]) and the chunk's output is five 16-byte stores
+		bool bulk = run && phase == 0 && tmode && (wi & 15) == 0 && wi + 16 < n && tp >= 16u && pw == 1u;
+		if (bulk) {
+			if ((wi >> 4) != stag) { const uint4 q = *(const uint4*)((x ? P.rseq : P.seq) + sq_off + wi); WIN_SET(slo, shi, q.x, q.y, q.z, q.w); stag = wi >> 4; }
+			const uint32_t w0 = (tp - 16u) >> 4;
+			const uint32_t *const txt = BX(text);
+			const uint32_t t0 = txt[w0], t1 = txt[w0 + 1u];
+			// 2 low bits of each of the 16 read bytes, byte j -> bits 2j
+			auto squeeze = [](uint64_t v) -> uint32_t {
+				uint64_t y = v & 0x0303030303030303ull;
+				y = (y | y >> 6) & 0x000F000F000F000Full; y = (y | y >> 12) & 0x000000FF000000FFull; y = (y | y >> 24) & 0xFFFFull;
+				return (uint32_t)y;
+			};
+			const bool clean = ((slo | shi) & 0xFCFCFCFCFCFCFCFCull) == 0ull;           // no N among them
+			const uint32_t rd = squeeze(slo) | squeeze(shi) << 16;
+			// text bases tp-16 .. tp-1, base tp-16+m at bits 2m; the read meets them from the top down
+			const uint32_t tx = (uint32_t)(((uint64_t)t1 << 32 | t0) >> (((tp - 16u) & 15u) << 1));
+			uint32_t rv = __brev(tx); rv = (rv >> 1 & 0x55555555u) | (rv & 0x55555555u) << 1;   // 2-bit groups reversed
+			bulk = clean && rv == rd;
+			if (bulk) {
+				uint8_t *const rec = WREC;
+				uint32_t *const wp = (uint32_t*)rec + x * P.WL + wi;
+#pragma unroll
+				for (int u = 0; u < 4; ++u) *(uint4*)(wp + 4 * u) = make_uint4(1u, 1u, 1u, 1u);
+				const uint32_t b4 = ((uint32_t)(bid > 127 ? 127 : bid) | 128u) * 0x01010101u;
+				*(uint4*)(rec + P.woff_bid + x * P.WLB + wi) = make_uint4(b4, b4, b4, b4);
+				tp -= 16u; wi += 16;
+			}
+		}
+		if (bulk) { /* chunk done */ }
+		else if (run && tok && wi + 4 <= KT && wi + 4 < n) {
 			// table trip: the intervals after wi+1 .. wi+4 symbols of this phase are entries of levels wi+1 .. wi+4 of the
-			// interval table (fm_index.hip) -- eight independent 8-byte loads, the low levels cache-resident -- instead
-			// of four dependent rank queries per pass.  An empty entry is the reference's restart (bwtaln.c:66-70): from
-			// there on the prefix is no longer the read's, so the rest of the phase steps normally.
-			uint2 tv[2][4];
+			// interval table (fm_index.hip) -- four independent 8-byte loads, the low levels cache-resident -- instead
+			// of four dependent rank queries.  An empty entry is the reference's restart (bwtaln.c:66-70): from there on
+			// the prefix is no longer the read's, so the rest of the phase steps normally.
+			uint2 tv[4];
+			const uint2 *const top = BX(kmer);
 #pragma unroll
-			for (int x = 0; x < 2; ++x) {
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int t = wi + u + 1;
-					const uint2 *lvl = P.bwt[x].kmer - (((1u << (2 * KT)) - (1u << (2 * t))) / 3u);
-					tv[x][u] = lvl[wkey[x] >> (2 * (KT - t))];
-				}
+			for (int u = 0; u < 4; ++u) {
+				const int t = wi + u + 1;
+				tv[u] = (top - (((1u << (2 * KT)) - (1u << (2 * t))) / 3u))[wkey >> (2 * (KT - t))];
 			}
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				bool dead = false;
-#pragma unroll
-				for (int x = 0; x < 2; ++x) {
-					kk[x] = tv[x][u].x; ll[x] = tv[x][u].y;
-					if (kk[x] > ll[x]) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; dead = true; }
-				}
+				kk = tv[u].x; ll = tv[u].y;
+				const bool dead = kk > ll;
+				if (dead) { kk = 0; ll = BX(seq_len); ++bid; }
 				out_pos(wi, false);
 				++wi;
 				if (dead) { tok = false; break; }
 			}
 		} else if (run) {
 			const int pos = sbase + wi;
-			int c[2]; Occ4 ck[2], cl[2];
+			if ((pos >> 4) != stag) { const uint4 q = *(const uint4*)((x ? P.rseq : P.seq) + sq_off + (pos & ~15)); WIN_SET(slo, shi, q.x, q.y, q.z, q.w); stag = pos >> 4; }
+			const int cc = (int)byte_of(slo, shi, (uint32_t)pos & 15u);
+			// issue the loads of this step before consuming any (one memory latency per trip)
+			uint4 qa[4], qb[4]; uint32_t rk = 0, rl = 0, sav = 0; bool kval = false, two = false;
 #pragma unroll
-			for (int x = 0; x < 2; ++x) {
-				const int tag = pos >> 4;
-				if (tag != stag[x]) { const uint4 q = *(const uint4*)((x ? P.rseq : P.seq) + sq_off + (pos & ~15)); WIN_SET(slo[x], shi[x], q.x, q.y, q.z, q.w); stag[x] = tag; }
-				c[x] = (int)byte_of(slo[x], shi[x], (uint32_t)pos & 15u);
-			}
-			// issue the bucket loads of BOTH passes before consuming any (one memory latency per trip)
-			uint4 qa[2][4], qb[2][4]; uint32_t rk[2], rl[2], sav[2]; bool kval[2], two[2];
-#pragma unroll
-			for (int x = 0; x < 2; ++x) {
-				const uint32_t primary = P.bwt[x].primary, kq = kk[x] - 1u, lq = ll[x];
+			for (int u = 0; u < 4; ++u) { qa[u] = make_uint4(0, 0, 0, 0); qb[u] = make_uint4(0, 0, 0, 0); }
+			const bool q = cc < 4 && !tmode;
+			if (q) {
+				const uint32_t primary = BX(primary), kq = kk - 1u, lq = ll;
 				const uint32_t kp = kq - (kq >= primary ? 1u : 0u), lp = lq - (lq >= primary ? 1u : 0u);
-				const uint32_t bl = lp / NABWA_INTV; rl[x] = lp - bl * NABWA_INTV;
-				kval[x] = kq != 0xffffffffu;
-				const uint32_t bkk = kval[x] ? kp / NABWA_INTV : bl; rk[x] = kp - bkk * NABWA_INTV;
-				two[x] = bkk != bl;
-				const bool q = c[x] < 4 && !(tmode >> x & 1u);
-				const uint4 *pl = P.bwt[x].bk + (size_t)bl * 4, *pk = P.bwt[x].bk + (size_t)bkk * 4;
+				const uint32_t bl = lp / NABWA_INTV; rl = lp - bl * NABWA_INTV;
+				kval = kq != 0xffffffffu;
+				const uint32_t bkk = kval ? kp / NABWA_INTV : bl; rk = kp - bkk * NABWA_INTV;
+				two = bkk != bl;
+				const uint4 *const bkt = BX(bk);
+				const uint4 *pl = bkt + (size_t)bl * 4, *pk = bkt + (size_t)bkk * 4;
 #pragma unroll
-				for (int u = 0; u < 4; ++u) { qa[x][u] = make_uint4(0, 0, 0, 0); qb[x][u] = make_uint4(0, 0, 0, 0); }
-				if (q) {
+				for (int u = 0; u < 4; ++u) qa[u] = pl[u];
+				if (two) {
 #pragma unroll
-					for (int u = 0; u < 4; ++u) qa[x][u] = pl[u];
-					if (two[x]) {
-#pragma unroll
-						for (int u = 0; u < 4; ++u) qb[x][u] = pk[u];
-					}
-					if (COUNT) touches += ref_touches(P.bwt[x], kq, lq, false);
+					for (int u = 0; u < 4; ++u) qb[u] = pk[u];
 				}
+				if (COUNT) touches += ref_touches(x ? P.bwt[1] : P.bwt[0], kq, lq, false);
 				// one row left: fetch its text position alongside this step's query (the step moves it one to the left)
-				sav[x] = 0u;
-				if (text_ok && q && kk[x] == ll[x]) sav[x] = P.bwt[x].sa_full[kk[x]];
-				if ((tmode >> x & 1u) && tp[x] > 0u && ((tp[x] - 1u) >> 5) != twtag[x]) {
-					twtag[x] = (tp[x] - 1u) >> 5;
-					twin[x] = *(const uint2*)(P.bwt[x].text + 2 * (size_t)twtag[x]);
-				}
+				if (text_ok && kk == ll) sav = BX(sa_full)[kk];
 			}
-#pragma unroll
-			for (int x = 0; x < 2; ++x) {
-				ck[x].c[0] = ck[x].c[1] = ck[x].c[2] = ck[x].c[3] = 0; cl[x] = ck[x];
-				if (c[x] < 4 && !(tmode >> x & 1u)) {
-					cl[x] = nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rl[x]);
-					if (kval[x]) ck[x] = two[x] ? nabwa_count4(qb[x][0], qb[x][1], qb[x][2], qb[x][3], rk[x])
-											   : nabwa_count4(qa[x][0], qa[x][1], qa[x][2], qa[x][3], rk[x]);
-				}
+			if (tmode && tp > 0u && ((tp - 1u) >> 5) != twtag) {
+				twtag = (tp - 1u) >> 5;
+				twin = *(const uint2*)(BX(text) + 2 * (size_t)twtag);
 			}
-#pragma unroll
-			for (int x = 0; x < 2; ++x) {
-				const int cc = c[x];
-				if (tmode >> x & 1u) {
-					bool ok = cc < 4 && tp[x] > 0u;
-					if (ok) {
-						const uint32_t q = tp[x] - 1u, wd = (q & 16u) ? twin[x].y : twin[x].x;
-						ok = (wd >> ((q & 15u) << 1) & 3u) == (uint32_t)cc;
-						if (ok) tp[x] = q;
-					}
-					if (cc > 3 && x == 0 && phase == 0) ++nN;
-					if (!ok) { tmode &= ~(1u << x); kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; }   // the restart of bwtaln.c:66-70
-					continue;
+			if (tmode) {
+				bool ok = cc < 4 && tp > 0u;
+				if (ok) {
+					const uint32_t t = tp - 1u, wd = (t & 16u) ? twin.y : twin.x;
+					ok = (wd >> ((t & 15u) << 1) & 3u) == (uint32_t)cc;
+					if (ok) tp = t;
 				}
-				const bool was_one = text_ok && cc < 4 && kk[x] == ll[x];
+				if (cc > 3 && x == 0u && phase == 0) ++nN;
+				if (!ok) { tmode = false; kk = 0; ll = BX(seq_len); ++bid; }   // the restart of bwtaln.c:66-70
+			} else {
+				const bool was_one = text_ok && cc < 4 && kk == ll;
 				if (cc < 4) {
-					const uint32_t L2c = cc == 0 ? P.bwt[x].L2[0] : (cc == 1 ? P.bwt[x].L2[1] : (cc == 2 ? P.bwt[x].L2[2] : P.bwt[x].L2[3]));
-					const uint32_t ok = cc == 0 ? ck[x].c[0] : (cc == 1 ? ck[x].c[1] : (cc == 2 ? ck[x].c[2] : ck[x].c[3]));
-					const uint32_t ol = cc == 0 ? cl[x].c[0] : (cc == 1 ? cl[x].c[1] : (cc == 2 ? cl[x].c[2] : cl[x].c[3]));
-					kk[x] = L2c + ok + 1u; ll[x] = L2c + ol;
-				} else if (x == 0 && phase == 0) ++nN;
-				if (kk[x] > ll[x] || cc > 3) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; ++bid[x]; }
-				else if (was_one) { tmode |= 1u << x; tp[x] = sav[x] - 1u; twtag[x] = 0xffffffffu; }
+					Occ4 ck, cl;
+					ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0;
+					cl = nabwa_count4(qa[0], qa[1], qa[2], qa[3], rl);
+					if (kval) {
+						const uint4 s0 = two ? qb[0] : qa[0], s1 = two ? qb[1] : qa[1], s2 = two ? qb[2] : qa[2], s3 = two ? qb[3] : qa[3];
+						ck = nabwa_count4(s0, s1, s2, s3, rk);
+					}
+					const uint32_t L2c = cc == 0 ? BX(L2[0]) : (cc == 1 ? BX(L2[1]) : (cc == 2 ? BX(L2[2]) : BX(L2[3])));
+					const uint32_t ok = cc == 0 ? ck.c[0] : (cc == 1 ? ck.c[1] : (cc == 2 ? ck.c[2] : ck.c[3]));
+					const uint32_t ol = cc == 0 ? cl.c[0] : (cc == 1 ? cl.c[1] : (cc == 2 ? cl.c[2] : cl.c[3]));
+					kk = L2c + ok + 1u; ll = L2c + ol;
+				} else if (x == 0u && phase == 0) ++nN;
+				if (kk > ll || cc > 3) { kk = 0; ll = BX(seq_len); ++bid; }
+				else if (was_one) { tmode = true; tp = sav - 1u; twtag = 0xffffffffu; }
 			}
 			out_pos(wi, false);
 			if (wi + 1 == n) out_pos(wi + 1, true);
 			++wi;
 			if (wi == n) {
-				if (phase == 0 && P.rd_cls) P.rd_cls[rid] = (bid[0] == 1 || bid[1] == 1) ? 1 : 0;   // only the terminator's ++: no restart (bwtaln.c:66-74)
+				if (phase == 0 && P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = bid == 1 ? 1 : 0;   // only the terminator's ++: no restart (bwtaln.c:66-74)
 				if (phase == 0 && len > P.seed_len) {
-					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = 0;
-					if (KT) { const uint2 kw = *(const uint2*)(P.rd_key + 6 * (size_t)rid + 4); wkey[0] = kw.x; wkey[1] = kw.y; tok = kw.x != 0xffffffffu && kw.y != 0xffffffffu; }
-#pragma unroll
-					for (int x = 0; x < 2; ++x) { kk[x] = 0; ll[x] = P.bwt[x].seq_len; bid[x] = 0; pw[x] = 0; }
-				} else { P.rd_nN[rid] = (uint8_t)(nN > 255 ? 255 : nN); run = false; }
+					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = false;
+					if (KT) { wkey = P.rd_key[6 * (size_t)rid + 4 + x]; tok = wkey != 0xffffffffu; }
+					kk = 0; ll = BX(seq_len); bid = 0; pw = 0;
+				} else { if (x == 0u) P.rd_nN[rid] = (uint8_t)(nN > 255 ? 255 : nN); run = false; }
 			}
 		}
 	}
@@ -292,8 +301,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, 3) void fm_width_kernel(const S
 		if (lane == 0 && P.touch_counter) atomicAdd(P.touch_counter + 1, touches);
 	}
 #undef WREC
+#undef BX
 }
-
 // =====================================================================================
 // Kernel S: bwt_match_gap (bwtgap.c:104-266), one read per lane, exact pop/push order.
 //
@@ -1101,7 +1110,7 @@ __global__ __launch_bounds__(256) void partition_kernel(int n, const uint8_t *__
 #pragma unroll
 	for (int g = 0; g < 16; ++g) {
 		const long i = first + g * 64 + lane;
-		const bool in = i < n; const uint8_t c = in ? cls[i] : 0;
+		const bool in = i < n; const uint8_t c = in ? (cls[2 * i] | cls[2 * i + 1]) : 0;   // either strand occurs exactly
 		ma[g] = __ballot(in && c != 0); mb[g] = __ballot(in && c == 0);
 		na += (unsigned int)__popcll(ma[g]); nb += (unsigned int)__popcll(mb[g]);
 	}

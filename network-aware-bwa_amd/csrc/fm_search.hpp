@@ -38,6 +38,7 @@ struct SearchParams {
 	int aln_cap;
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
 	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
+	int w_sync;                               // kernel W: lockstep waves (all reads of the batch have one length)
 	uint8_t *rd_cls;                          // kernel W -> partition: 1 = one strand of the read occurs exactly (no restart in its width pass)
 	const unsigned int *n_sync;               // first *n_sync work items are such reads: their waves run in lockstep (see fm_search_kernel)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches

@@ -389,7 +389,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
 	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
-	BCHK(hipMalloc(&b->d_cls, n ? n : 1)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 8));
+	BCHK(hipMalloc(&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 8));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
@@ -423,6 +423,11 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
 	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
+	{
+		int min_len = max_len;
+		for (int i = 0; i < n; ++i) { const int L = (int)(off[i + 1] - off[i]); if (L < min_len) min_len = L; }
+		P.w_sync = (n > 0 && min_len == max_len) ? env_int("NABWA_W_SYNC", 1) : 0;
+	}
 	if (P.aln_cap < 1) P.aln_cap = 1;
 
 	hipDeviceProp_t prop;
@@ -436,10 +441,12 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	if (blocks > need) blocks = need;
 	if (blocks < 1) blocks = 1;
 	b->n_blocks = (int)blocks;
+	if (getenv("NABWA_TIMING")) fprintf(stderr, "[nabwa] search kernel: %u score levels, %d blocks per CU (LDS %zu B per block), %ld blocks\n", NS1, occ,
+										(size_t)NS1 * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80, blocks);
 	BCHK(hipMalloc(&b->d_scratch, (size_t)blocks * NABWA_SEARCH_BLOCK * P.lane_stride));
 	int occw = nabwa_width_occupancy(); if (occw < 1) occw = 1;
 	long blocks_w = (long)prop.multiProcessorCount * occw;
-	if (blocks_w > need) blocks_w = need;
+	if (blocks_w > 2 * need) blocks_w = 2 * need;        /* kernel W: one lane per strand of a read */
 	if (blocks_w < 1) blocks_w = 1;
 	b->n_blocks_w = (int)blocks_w;
 	BCHK(hipMalloc(&b->d_wdata, (size_t)(n ? n : 1) * P.wstride));
@@ -521,7 +528,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
 	{	// the first pass edited these reads' width records in place (gap_shadow): rebuild them
 		SearchParams QW = Q; QW.touch_counter = 0;
-		long bw2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
+		long bw2 = (2 * (long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
 		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
 		nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
 	}
