@@ -138,7 +138,7 @@ def main():
         bytes_w = 48 * t_width + half_reads
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(),
                     "kernel": "fm_search_kernel<false,false>", "kernel_ms": round(k_ms, 3),
                     "bytes_per_read": round(bytes_alg / args.reads, 1),
                     "bucket_touches_per_read": round(t_search / args.reads, 1),
@@ -174,6 +174,19 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic():
+    """HBM bytes of one search-kernel launch from the committed counter pass of this kernel version (profiles/:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc.sh; both are 64-byte fabric requests
+    for this kernel's 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when the
+    file is missing -- counters cannot be collected from inside the timed run."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v6_pmc.json")
+    try:
+        d = json.load(open(f))["S"]
+        return round((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, 0)
+    except Exception:
+        return None
 
 
 def cpu_baseline(T, host_bwt, opt, seq, rseq, off, batch, args):
