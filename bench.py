@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("NABWA_BENCH_READS", 10_000_000)))
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--sub-ppm", type=int, default=2000)
+    ap.add_argument("--indel-ppm", type=int, default=0, help="per-base indel rate of the synthetic reads (not part of the headline workload)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
         p[2].free()
 
     # reads: this rank's shard (seeded by rank)
-    seq, rseq, off = synth.synth_reads(d_text, n, args.reads, args.read_len, args.sub_ppm, 0, 2 + 1000 * rank, device=dev)
+    seq, rseq, off = synth.synth_reads(d_text, n, args.reads, args.read_len, args.sub_ppm, args.indel_ppm, 2 + 1000 * rank, device=dev)
     d_text.free()
     opt = nabwa.gap_init_opt()
     # one end-to-end pass over host buffers (upload + both kernels + compacted download): the PCIe-inclusive rate

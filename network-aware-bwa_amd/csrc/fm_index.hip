@@ -113,25 +113,32 @@ extern "C" void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uin
 // Interval table, one level per launch: level t holds the SA interval of every string of t symbols (key = symbols
 // as base-4 digits, first consumed symbol most significant), computed from its parent at level t-1 by one backward
 // step with the search's own recurrences (bwt.c:237-252): k' = C(c) + Occ(c, k-1) + 1, l' = C(c) + Occ(c, l).
-__global__ __launch_bounds__(256) void kmer_level_kernel(DevBwt B, const uint2 *__restrict__ prev, uint2 *__restrict__ cur, uint32_t n_cur)
+__global__ __launch_bounds__(256) void kmer_level_kernel(DevBwt B, const uint2 *__restrict__ prev, uint2 *__restrict__ cur, uint64_t n_par)
 {
-	const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-	if (idx >= n_cur) return;
-	uint2 par = prev ? prev[idx >> 2] : make_uint2(0u, B.seq_len);
-	uint2 out = make_uint2(1u, 0u);
+	const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;       // one parent per thread: its four children share the rank query
+	if (idx >= n_par) return;
+	const uint2 par = prev ? prev[idx] : make_uint2(0u, B.seq_len);
+	uint2 out[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) out[c] = make_uint2(1u, 0u);
 	if (par.x <= par.y) {
-		const uint32_t c = idx & 3u;
 		Occ4 ck, cl;
 		nabwa_occ4_pair(B, par.x - 1u, par.y, ck, cl);
-		out.x = B.L2[c] + ck.c[c] + 1u; out.y = B.L2[c] + cl.c[c];
-		if (out.x > out.y) out = make_uint2(1u, 0u);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const uint32_t k = B.L2[c] + ck.c[c] + 1u, l = B.L2[c] + cl.c[c];
+			if (k <= l) out[c] = make_uint2(k, l);
+		}
 	}
-	cur[idx] = out;
+	uint4 *const dst = (uint4*)(cur + 4 * idx);
+	dst[0] = make_uint4(out[0].x, out[0].y, out[1].x, out[1].y);
+	dst[1] = make_uint4(out[2].x, out[2].y, out[3].x, out[3].y);
 }
 
-extern "C" void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s)
+extern "C" void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint64_t n_cur, hipStream_t s)
 {
-	hipLaunchKernelGGL(kmer_level_kernel, dim3((n_cur + 255) / 256), dim3(256), 0, s, *B, prev, cur, n_cur);
+	const uint64_t n_par = n_cur / 4;
+	hipLaunchKernelGGL(kmer_level_kernel, dim3((unsigned int)((n_par + 255) / 256)), dim3(256), 0, s, *B, prev, cur, n_par);
 }
 
 // Full suffix array, its inverse and the text from the BWT and the row-sampled SA (bwt.c:72-81 is the per-row

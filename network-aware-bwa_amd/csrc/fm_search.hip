@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 	const bool text_ok = (P.text_mode & 1) && P.bwt[0].sa_full && P.bwt[1].sa_full;
 	uint32_t kk = 0, ll = 0, pw = 0; int bid = 0;
 	uint32_t wkey = 0xffffffffu; bool tok = false;          // interval-table key of this phase's first KT symbols
-	const int KT = (int)P.bwt[0].kmer_T;
+	const int KT = (int)P.bwt[0].kmer_T, LW = (int)P.bwt[0].kmer_LW;
 	uint4 wacc = make_uint4(0, 0, 0, 0); uint64_t blo = 0, bhi = 0, slo = 0, shi = 0; int stag = -1;
 	unsigned long long touches = 0;
 
@@ -203,17 +203,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 			}
 		}
 		if (bulk) { /* chunk done */ }
-		else if (run && tok && wi + 4 <= KT && wi + 4 < n) {
+		else if (run && tok && wi + 4 <= LW && wi + 4 < n) {
 			// table trip: the intervals after wi+1 .. wi+4 symbols of this phase are entries of levels wi+1 .. wi+4 of the
 			// interval table (fm_index.hip) -- four independent 8-byte loads, the low levels cache-resident -- instead
 			// of four dependent rank queries.  An empty entry is the reference's restart (bwtaln.c:66-70): from there on
 			// the prefix is no longer the read's, so the rest of the phase steps normally.
 			uint2 tv[4];
-			const uint2 *const top = BX(kmer);
+			const uint2 *const lo = BX(kmer_lo);
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const int t = wi + u + 1;
-				tv[u] = (top - (((1u << (2 * KT)) - (1u << (2 * t))) / 3u))[wkey >> (2 * (KT - t))];
+				tv[u] = (lo + ((1u << (2 * t)) - 4u) / 3u)[wkey >> (2 * (KT - t))];
 			}
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {

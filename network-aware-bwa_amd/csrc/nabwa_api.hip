@@ -14,7 +14,7 @@
 
 extern "C" {
 void nabwa_launch_repack(const uint32_t *w, uint32_t seq_len, uint32_t n_buckets, uint4 *out, hipStream_t s);
-void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint32_t n_cur, hipStream_t s);
+void nabwa_launch_kmer_level(const DevBwt *B, const uint2 *prev, uint2 *cur, uint64_t n_cur, hipStream_t s);
 void nabwa_launch_sa_fill(const DevBwt *B, uint32_t *sa_full, uint32_t *isa, uint8_t *text_bytes, hipStream_t s);
 void nabwa_launch_text_pack(const uint8_t *bytes, uint32_t n, uint32_t n_words, uint32_t *out, hipStream_t s);
 void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
@@ -112,26 +112,43 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 	if (raw) HIPCHK(hipFree(raw));
 	B.bk = ix->bk[t_];
 	ix->bytes += (uint64_t)B.n_buckets * 64;
-	{	/* interval table for the tail jump: T = floor(log4(seq_len)), at most 15, unless NABWA_KMER_T says otherwise (0 = off) */
+	{	/* interval table: T = floor(log4(seq_len)) (about one row per key at the last level), at most 16 and no more than a
+		 * third of the free HBM; NABWA_KMER_T overrides (0 = off; 16 at GRCh38 size: +46 GB for -3 % search time).  Levels
+		 * 1..LW (LW = min(T, 12)) stay, for the width passes; the levels between LW and T are scaffolding. */
 		int T = 0;
-		for (uint64_t x = B.seq_len; x >= 4; x >>= 2) ++T;          /* floor(log4 n): about one row per key at the last level */
+		for (uint64_t x = B.seq_len; x >= 4; x >>= 2) ++T;
 		const char *e = getenv("NABWA_KMER_T");
 		if (e) T = atoi(e);
-		if (T > 15) T = 15;
+		if (T > 16) T = 16;
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(hipMemGetInfo(&free_b, &total_b));
+		while (T > 12 && (((size_t)1 << (2 * T)) + ((size_t)1 << (2 * T - 2))) * 8 > free_b / 3) --T;
 		if (T >= 1) {
-			size_t total = 0;
-			for (int t = 1; t <= T; ++t) total += (size_t)1 << (2 * t);
-			HIPCHK(hipMalloc(&ix->kmer[t_], total * 8));
+			const int LW = T < 12 ? T : 12;
+			size_t lo_n = 0;
+			for (int t = 1; t <= LW; ++t) lo_n += (size_t)1 << (2 * t);
+			HIPCHK(hipMalloc(&ix->kmer[t_], lo_n * 8));
 			uint2 *prev = 0, *cur = ix->kmer[t_];
-			for (int t = 1; t <= T; ++t) {
-				const uint32_t n_cur = 1u << (2 * t);
-				nabwa_launch_kmer_level(&B, prev, cur, n_cur, 0);
-				prev = cur; cur += n_cur;
+			for (int t = 1; t <= LW; ++t) {
+				nabwa_launch_kmer_level(&B, prev, cur, (uint64_t)1 << (2 * t), 0);
+				prev = cur; cur += (size_t)1 << (2 * t);
 			}
+			ix->bytes += lo_n * 8;
+			uint2 *tmp[2] = { 0, 0 };
+			for (int t = LW + 1; t <= T; ++t) {               /* ping-pong up to the last level, which stays */
+				uint2 *dst = 0;
+				HIPCHK(hipMalloc(&dst, ((size_t)1 << (2 * t)) * 8));
+				nabwa_launch_kmer_level(&B, prev, dst, (uint64_t)1 << (2 * t), 0);
+				HIPCHK(hipGetLastError());
+				HIPCHK(hipDeviceSynchronize());
+				if (tmp[0]) HIPCHK(hipFree(tmp[0]));
+				tmp[0] = tmp[1]; tmp[1] = dst; prev = dst;
+			}
+			if (tmp[0]) HIPCHK(hipFree(tmp[0]));
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipDeviceSynchronize());
-			B.kmer = prev; B.kmer_T = (uint32_t)T;
-			ix->bytes += total * 8;
+			if (T > LW) { ix->kmer_top[t_] = tmp[1]; ix->bytes += ((size_t)1 << (2 * T)) * 8; }
+			B.kmer = prev; B.kmer_T = (uint32_t)T; B.kmer_lo = ix->kmer[t_]; B.kmer_LW = (uint32_t)LW;
 		}
 	}
 	if (sa_words) {
@@ -174,7 +191,7 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
-	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; for (int t = 0; t < 2; ++t) ix->sa_full[t] = ix->isa[t] = ix->text[t] = 0; ix->bytes = 0; ix->ref = 0;
+	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; ix->kmer_top[0] = ix->kmer_top[1] = 0; for (int t = 0; t < 2; ++t) ix->sa_full[t] = ix->isa[t] = ix->text[t] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
 	if (r == NABWA_OK) r = build_one(ix, 1, bwt1, nw1, is_device != 0, sa1, ns1);
@@ -218,7 +235,7 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 {
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
-	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]);
+	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]); if (ix->kmer_top[t]) (void)hipFree(ix->kmer_top[t]);
 		if (ix->sa_full[t]) (void)hipFree(ix->sa_full[t]); if (ix->isa[t]) (void)hipFree(ix->isa[t]); if (ix->text[t]) (void)hipFree(ix->text[t]); }
 	delete ix->ref;
 	delete ix;

@@ -32,6 +32,8 @@ struct DevBwt {
 	uint32_t n_buckets;
 	uint32_t kmer_T;        // 0: no table.  Otherwise kmer[key] = SA interval {k, l} (k > l: empty) of the string whose
 	const uint2 *kmer;      // T symbols, in the order the backward search consumes them, are the base-4 digits of key
+	const uint2 *kmer_lo;   // levels 1..kmer_LW (= min(T, 12)) back to back, level t at offset (4^t - 4) / 3: the width passes'
+	uint32_t kmer_LW, pad_; // first steps; the levels between LW and T only exist while the table is built
 	                        // (first consumed symbol = most significant digit); built at load time (fm_index.hip)
 	// "text mode" companions, all derived from the BWT + the SA samples at load time (fm_index.hip), or null:
 	const uint32_t *sa_full;   // SA value of EVERY row (row 0: ~0u), so bwt_sa is one load

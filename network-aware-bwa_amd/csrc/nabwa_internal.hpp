@@ -21,7 +21,7 @@ struct nabwa_index {
 	uint4 *bk[2];
 	uint32_t *sa[2];
 	uint32_t *sa_full[2], *isa[2], *text[2];   // text-mode companions (nabwa_dev.hpp), null when switched off
-	uint2 *kmer[2];                // all levels 1..T of the interval table, level T last (DevBwt.kmer points at it)
+	uint2 *kmer[2], *kmer_top[2];  // interval table: levels 1..LW back to back; level T on its own when T > LW (else inside the former)
 	uint64_t bytes;
 	nabwa_reference *ref;
 };
