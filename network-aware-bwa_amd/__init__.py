@@ -388,6 +388,25 @@ class Index:
         _chk(lib().nabwa_occ4(self._h, which, len(k), _ptr(k), _ptr(out)))
         return out
 
+    def cal_sa_reg_gap_flat(self, opt, seq, rseq, off, per_read=False, cap_rows=None):
+        """The C one-shot entry (nabwa_cal_sa_reg_gap) on host buffers, results as flat arrays:
+        (n_aln int32[n], rows ALN_DT[total], max_entries int32[n]) -- what a C caller of the boundary gets."""
+        n = len(off) - 1
+        seq = np.ascontiguousarray(seq, np.uint8); rseq = np.ascontiguousarray(rseq, np.uint8)
+        off = np.ascontiguousarray(off, np.int64)
+        n_aln = np.zeros(max(n, 1), np.int32); maxe = np.zeros(max(n, 1), np.int32)
+        cap = int(cap_rows if cap_rows is not None else 2 * n + 1024)
+        while True:
+            buf = np.zeros(max(cap, 1), ALN_DT)
+            rows = C.c_int64()
+            rc = lib().nabwa_cal_sa_reg_gap(self._h, C.byref(opt), n, _ptr(off), _ptr(seq), _ptr(rseq), int(per_read),
+                                            _ptr(n_aln), _ptr(buf), cap, C.byref(rows), _ptr(maxe))
+            if rc == ECAP and rows.value > cap:
+                cap = rows.value
+                continue
+            _chk(rc)
+            return n_aln[:n], buf[:rows.value], maxe[:n]
+
     def cal_sa_reg_gap(self, opt, seq, rseq, off, per_read=False):
         """bwa_cal_sa_reg_gap (reference bwtaln.c:93-142) over a flat batch.
         Returns (list of per-read hit arrays, max_entries)."""

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "../../include/nabwa.h"
@@ -654,12 +655,20 @@ extern "C" int nabwa_cal_sa_reg_gap(nabwa_index_t *ix, const nabwa_gap_opt_t *op
 									int32_t *max_entries)
 {
 	nabwa_batch_t *b = 0;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
 	int r = nabwa_batch_create(ix, opt, n, off, seq, rseq, per_read, &b);
 	if (r != NABWA_OK) return r;
+	const double t1 = now();
 	r = nabwa_batch_run(b);
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
+	const double t2 = now();
 	if (r == NABWA_OK) r = nabwa_batch_fetch(b, n_aln, aln_out, aln_cap, n_rows, max_entries);
+	const double t3 = now();
 	nabwa_batch_destroy(b);
+	if (timing) fprintf(stderr, "[nabwa] cal_sa_reg_gap %d reads: upload + layout %.3f s, kernels %.3f s, compaction + download %.3f s, release %.3f s\n",
+						n, t1 - t0, t2 - t1, t3 - t2, now() - t3);
 	return r;
 }
 

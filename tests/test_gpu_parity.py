@@ -329,3 +329,19 @@ def test_more_than_64_score_levels_go_through_the_second_pass(gix, olib, oix):
     bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
     assert not bad, "GPU differs from the oracle for %d reads" % len(bad)
     assert np.array_equal(gmax, wmax)
+
+
+
+@pytest.mark.parametrize("per_read", [False, True])
+def test_one_shot_entry_flat(gix, olib, oix, per_read):
+    """nabwa_cal_sa_reg_gap on host buffers, as a C caller sees it: counts, rows in read order, max_entries; a row buffer
+    that is too small is answered with NABWA_ECAP and the size needed"""
+    rng = np.random.default_rng(21)
+    reads = random_reads(rng, 1000, toy_genome(), lens=(36, 50, 76, 100, 100, 150), err=0.02)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = T.default_opt()
+    want, wmax = T.oracle_cal_sa_reg_gap(olib, oix.h, opt, seq, rseq, off, per_read=int(per_read), n_threads=8)
+    n_aln, rows, maxe = gix.cal_sa_reg_gap_flat(to_gap_opt(opt), seq, rseq, off, per_read=per_read, cap_rows=10)   # too small first: resized by the answer
+    assert (n_aln == np.array([len(w) for w in want])).all()
+    assert rows.tobytes() == np.concatenate([np.asarray(w, nabwa.ALN_DT) for w in want]).tobytes()
+    assert np.array_equal(maxe, wmax)
