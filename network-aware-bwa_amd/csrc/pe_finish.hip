@@ -34,7 +34,6 @@ static void clear_record(nabwa_pe_t &r, int len, int full_len, int end)
 	nabwa_se_t &s = r.se;
 	memset(&s, 0, offsetof(nabwa_se_t, cigar));
 	s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = -1; s.nn = 0; s.rpos = 0; s.xt = 0;
-	for (int z = 0; z < NABWA_MAX_MULTI; ++z) s.multi[z].n_cigar = 0;
 	s.len = len; s.clip_len = len; s.full_len = full_len;
 	r.extra_flag = F_PD | (end ? F_R2 : F_R1);
 	r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0;

@@ -327,7 +327,6 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		nabwa_se_t &s = out[i];
 		memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
 		s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
-		for (int z = 0; z < NABWA_MAX_MULTI; ++z) s.multi[z].n_cigar = 0;
 		const int len = (int)(off[i + 1] - off[i]);
 		s.len = len; s.clip_len = len; s.full_len = full_len ? full_len[i] : len;
 		const nabwa_aln1_t *A = aln + a0; const int na = n_aln[i];
