@@ -6,29 +6,33 @@
 // decides which hits are found and in which order they are reported.
 //
 // Execution model: two persistent kernels per batch.  Kernel W (fm_width_kernel) runs the width
-// passes: every lane executes the same code on every trip (one step of two passes = two rank
-// queries), so its waves are fully converged.  Kernel S (fm_search_kernel) runs the search:
-// every lane is its own state machine (pop / exact-tail step / node expansion) and performs at
-// most ONE rank query -- Occ of all four bases at rows (k-1, l), one or two 64-byte bucket
-// fetches -- per trip.  In both, a lane that finishes a read draws the next one from a global
-// work counter (wave ballot + one atomic per wave).  v2 had both phases in one loop and ran at
-// 31 % VALU lane utilisation, issue-bound (profiles/r01_v2_pmc.json); hence the split.
+// passes: one lane = one strand of one read, every lane executes the same code on every trip, so its
+// waves are converged.  Kernel S (fm_search_kernel) runs the search: every lane is its own state machine
+// (pop / expansion / exact-tail step / tail jump / text tail / hit) and performs at most ONE rank query --
+// Occ of all four bases at rows (k-1, l), one or two 64-byte bucket fetches -- per trip.  A wave draws
+// work in blocks from a global counter.  v2 had both phases in one loop and ran at 31 % VALU lane
+// utilisation, issue-bound (profiles/r01_v2_pmc.json); hence the split.
 //
 // Memory discipline (v2).  With ~260 k reads in flight the caches hold ~128 B of L2 and ~1 KB of
 // Infinity Cache per lane, so every touch of lane-private state in HBM costs a 64-byte
 // transaction -- as much as the rank query it accompanies (v1 moved 4.5x the algorithmic bytes,
 // profiles/r01_v1_pmc.json).  Therefore:
 //   * the child that continues the current path (always the LAST push of an expansion) is kept
-//     in registers as the "pending" entry; it is the next pop whenever its score is not above the
-//     lowest score in memory (for the match child: always) and is spilled otherwise, so the
-//     observable pop order is unchanged;
+//     in registers as the "pending" entry (in arena format); it is the next pop whenever its score is
+//     not above the lowest score in memory (for the match child: always) and is spilled otherwise, so
+//     the observable pop order is unchanged;
 //   * an arena entry is one 16-byte word with its list link embedded; head[score] lives in LDS
-//     ([score][lane], 2 bytes each); a 128-bit register mask tracks the non-empty scores;
-//   * read bases and the per-position bound bytes are read through 16-byte register windows
-//     that stay valid for 8-16 steps of a descent;
+//     ([score][lane], 2 bytes each); a 64-bit register mask tracks the non-empty scores;
+//   * read bases and the per-position bound bytes are read through 16-byte windows in LDS, filled by
+//     global_load_lds_dwordx4, that stay valid for 8-16 steps of a descent;
 //   * the test "w[i-1] == w[i]" (bwtgap.c:208,212) is precomputed into bit 7 of the bound byte,
 //     so the 32-bit interval widths are only touched by gap_shadow (bwtgap.c:81-91);
 //   * the width passes write their results in 16-byte chunks (4 widths / 16 bound bytes).
+// Work avoidance (v5): exact tails near the read end jump through the interval table; an
+// interval of one row is carried as a text position and extended by text comparison, several levels per
+// trip; the gap children of an expansion are one grouped stack entry, materialised only if popped; the
+// next pop is fetched ahead into LDS while a tail is walked; reads with an exact occurrence (kernel W's
+// class) are searched first, by waves that refill all 64 lanes together.
 // First pass: bump allocation (arena = pushes that reach memory).  Reads that outgrow the arena
 // or the per-read hit list are flagged and re-run from scratch by the WIDE instantiation
 // (32-bit links, slot reuse, arena of max_entries+16 live entries) -- never on the CPU.
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 //      run the pre-checks that need no memory, choose what this lane does in this trip;
 //   2. issue every global load the lane needs -- arena entry, bound-byte window, read-base
 //      window, seed-bound window, one or two Occ buckets -- back to back, no use in between;
-//   3. consume: decode the entry, finish the pre-check, take an exact-tail step or expand.
+//   3. consume: park a fetched entry, finish the pre-check, take an exact-tail step, land a jump, expand, or record a hit.
 // When the bound window is stale at pop time the rank query is issued speculatively together
 // with the window; if the entry then turns out to be pruned (bwtgap.c:156) the counts are dropped.
 // =====================================================================================
