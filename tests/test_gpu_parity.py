@@ -345,3 +345,39 @@ def test_one_shot_entry_flat(gix, olib, oix, per_read):
     assert (n_aln == np.array([len(w) for w in want])).all()
     assert rows.tobytes() == np.concatenate([np.asarray(w, nabwa.ALN_DT) for w in want]).tobytes()
     assert np.array_equal(maxe, wmax)
+
+
+@pytest.mark.parametrize("env", [
+    {"NABWA_TEXT_MODE": "0"},                                   # no full SA / inverse / text: every interval stays in row form
+    {"NABWA_KMER_T": "0"},                                      # no interval table: every tail is walked
+    {"NABWA_KMER_T": "0", "NABWA_TEXT_MODE": "0"},              # the plain 2 GB index
+    {"NABWA_KMER_T": "5"},                                      # a table shallower than the width passes would like
+    {"NABWA_CLASS_SORT": "0", "NABWA_W_SYNC": "0"},             # batch order, no lockstep waves
+    {"NABWA_TEXT_KERNELS": "1"}, {"NABWA_TEXT_KERNELS": "2"},   # text mode in one kernel only
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_sai_parity_in_every_index_configuration(monkeypatch, env):
+    """the accelerating structures are optional: each way of switching them off gives the reference's .sai (default and
+    gap-heavy option sets) through the paths that remain"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ix = nabwa.Index.load(T.TOY, 0, True)
+    try:
+        for name, n_reads in (("default", 606), ("e3", 606), ("loggap", 150)):      # (-L -o 2 -e 8 is slow: a sample)
+            opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+            reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:n_reads]
+            seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
+            # per_read=False sizes the options by the longest read of the batch: keep the full batch's longest read in
+            per_read = False
+            if n_reads < 606:
+                per_read = None
+            if per_read is None:
+                full = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+                longest = max(range(len(full)), key=lambda i: len(full[i][1]))
+                reads = reads + [full[longest]]
+                gold = list(gold[:n_reads]) + [gold[longest]]
+                seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
+            got, _ = ix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off, per_read=False)
+            bad = [reads[i][0] for i in range(len(reads)) if got[i].tobytes() != gold[i].tobytes()]
+            assert not bad, "%s: GPU differs from the reference .sai for %d reads, e.g. %s" % (name, len(bad), bad[:5])
+    finally:
+        ix.close()
