@@ -419,6 +419,9 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// either form live side by side in the stacks.  s_tw: this lane's 16-base text word and its tag.
 	uint2 *const s_tw = s_key + NABWA_SEARCH_BLOCK;
 	uint32_t *const s_bw = (uint32_t*)(s_tw + NABWA_SEARCH_BLOCK), *const s_sw = s_bw + 4 * NABWA_SEARCH_BLOCK, *const s_sq = s_sw + 4 * NABWA_SEARCH_BLOCK;
+	// s_fb: per strand (byte a) the lower bound of differences of the read's first len-KT symbols, bound[len-KT-1] -- what
+	// decides whether every level down to depth KT is a forced match (see the tail jump); 0xff: unknown / no longer valid
+	uint32_t *const s_fb = s_sq + 4 * NABWA_SEARCH_BLOCK;
 	auto win_byte = [&](const uint32_t *W, const uint4 &q, uint32_t idx) -> uint32_t {
 		if (WIDE) { const uint32_t w = idx < 8u ? (idx < 4u ? q.x : q.y) : (idx < 12u ? q.z : q.w); return w >> ((idx & 3u) << 3) & 0xffu; }
 		return (uint32_t)((const uint8_t*)W)[(threadIdx.x << 4) + idx];
@@ -482,7 +485,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o; rid_w = rid;
 					mdmg = (uint32_t)P.rd_maxdiff[rid] | (uint32_t)P.rd_maxgapo[rid] << 8;
-					if (KT) s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 6 * (size_t)rid);   // interval-table keys of the two strands
+					if (KT) {
+						s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 6 * (size_t)rid);   // interval-table keys of the two strands
+						uint32_t fb = 0xffffu;
+						if (len > KT) { const uint8_t *const bb = REC + P.woff_bid + (len - KT - 1); fb = (uint32_t)(bb[0] & 127u) | (uint32_t)(bb[P.WLB] & 127u) << 8; }
+						s_fb[threadIdx.x] = fb;
+					}
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_score = -1; pf_slot = NIL;
 					if (text_ok) s_tw[threadIdx.x] = make_uint2(0u, 0x7fffffffu);
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		}
 		// what this lane does with its current entry in this trip
 		int kind = 0;                 // 1 expand, 2 exact-tail step, 3 hit without query (i == 0), 4 tail jump, 5 group member
-		bool need_win = false, spec = false; int win_hi = 0;
+		bool need_win = false, spec = false, forced = false; int win_hi = 0;
 		int grp_c = 0;
 		if (have && !finish && e_state == STATE_GROUP) {
 			// pop ONE member of a gap group, newest first (deletion of T, G, C, A, then the insertion); the rest goes back
@@ -580,7 +588,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 							else if (KT && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i <= KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
 								&& (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu) kind = 4;
 						}
-						else { kind = 1; --e_i; }
+						else {
+							// Forced matches.  Differences are allowed at a level only where the bound of the symbols still to
+							// come is below m (bwtgap.c:204-207); the bounds never grow towards the read's start, and this entry
+							// was not pruned, so bound[len-KT-1] == m means: on every level down to depth KT the only child is
+							// the matching one, popped at once (same score, newest) -- an exact walk in all but name.  For an entry
+							// whose path is known (as for the tail jump) the table gives the interval it arrives with, or that it dies.
+							forced = KT && l != TXM && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i < KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
+									 && (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu
+									 && (int)(s_fb[threadIdx.x] >> (e_a << 3) & 0xffu) == m;
+							if (forced) kind = 4; else { kind = 1; --e_i; }
+						}
 					}
 				}
 			}
@@ -716,6 +734,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		} else if (kind == 4) {                                 // landed at depth KT (len > KT, so the tail goes on)
 			k = r_km.x; l = r_km.y;
 			if (k > l) st = LS_POP;
+			else if (forced) { e_i = len - KT; e_ldp = 0; st = LS_HAVE; }   // arrives as the matching child it would have become
 			else { e_i = len - KT; st = LS_EXACT; }
 		} else if (kind == 7) {
 			// exact tail in text form: read symbols e_i-1, e_i-2, ... against the text to the left, as far as both 16-base words reach
@@ -791,6 +810,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 							*(uint2*)(bp + t0) = make_uint2(bb[0], bb[1]);
 						}
 						bw_a = -1;   // the bound window may be stale now
+						if (KT && e_ldp > len - KT - 1) s_fb[threadIdx.x] |= 0xffu << (e_a << 3);   // ... and so may the cached bound
 						out[n_aln] = make_uint4((uint32_t)e_mm | (uint32_t)e_go << 8 | (uint32_t)e_ge << 16 | (uint32_t)e_a << 24,
 												k, l, (uint32_t)score);
 						++n_aln;
@@ -942,7 +962,7 @@ extern "C" int nabwa_width_occupancy(void)
 
 extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
 {
-	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80;
+	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84;
 	if (P->touch_counter) {
 		if (wide) hipLaunchKernelGGL((fm_search_kernel<true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
 		else hipLaunchKernelGGL((fm_search_kernel<false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
@@ -955,7 +975,7 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 	int nb = 0;
 	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<true, false>, NABWA_SEARCH_BLOCK, 0)
 						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false, false>, NABWA_SEARCH_BLOCK,
-																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80);
+																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84);
 	return e == hipSuccess ? nb : 0;
 }
 

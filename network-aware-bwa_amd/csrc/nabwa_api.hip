@@ -113,11 +113,13 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 	if (raw) HIPCHK(hipFree(raw));
 	B.bk = ix->bk[t_];
 	ix->bytes += (uint64_t)B.n_buckets * 64;
-	{	/* interval table: T = floor(log4(seq_len)) (about one row per key at the last level), at most 16 and no more than a
-		 * third of the free HBM; NABWA_KMER_T overrides (0 = off; 16 at GRCh38 size: +46 GB for -3 % search time).  Levels
+	{	/* interval table: T = floor(log4(seq_len)) + 1 (about a quarter row per key at the last level: most walks that the table
+		 * replaces die inside it), at most 16 and no more than a third of the free HBM; NABWA_KMER_T overrides (0 = off).
+		 * GRCh38: T = 16, 34 GB per index; T = 15 costs 8 % of the search time and saves 52 GB.  Levels
 		 * 1..LW (LW = min(T, 12)) stay, for the width passes; the levels between LW and T are scaffolding. */
 		int T = 0;
 		for (uint64_t x = B.seq_len; x >= 4; x >>= 2) ++T;
+		T += 1;
 		const char *e = getenv("NABWA_KMER_T");
 		if (e) T = atoi(e);
 		if (T > 16) T = 16;
