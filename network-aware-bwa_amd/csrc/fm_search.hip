@@ -52,11 +52,13 @@
 #define STATE_GROUP 3   // arena only: the gap children of one expansion, see fm_search_kernel
 #define GRP_EXT 0x100u
 #define TXM 0xffffffffu   // l of an interval carried in text form (k = text position)
+#define KEYM 0xfffffffeu  // l of an interval carried in key form (k = path key: the reference symbols matched so far as base-4 digits)
+#define LVO(t_) ((size_t)((((uint64_t)1 << (2 * (t_))) - 4ull) / 3ull))   /* offset of level t in the interval table */
 #ifndef NABWA_W_WAVES
 #define NABWA_W_WAVES 5   // kernel W: waves per SIMD the register budget is bounded for (102 VGPRs)
 #endif
 #ifndef NABWA_WORK_CHUNK
-#define NABWA_WORK_CHUNK 256u
+#define NABWA_WORK_CHUNK 64u
 #endif
 #ifndef NABWA_RUN_MAX
 #define NABWA_RUN_MAX 4   // levels one text-form trip may walk (every lane of the wave waits for the longest walk)
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = false;
 						if (KT) { wkey = P.rd_key[6 * (size_t)rid + 2 + x]; tok = wkey != 0xffffffffu; }
 						kk = 0; ll = BX(seq_len); bid = 0; pw = 0; blo = bhi = 0;
-					} else { if (x == 0u) P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = 0; }
+					} else { if (x == 0u) P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = 0; }   // (an empty read: nothing to search)
 				} else done = true;
 			}
 		}
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
 				const int t = wi + u + 1;
-				tv[u] = (lo + ((1u << (2 * t)) - 4u) / 3u)[wkey >> (2 * (KT - t))];
+				tv[u] = (lo + (size_t)((((uint64_t)1 << (2 * t)) - 4ull) / 3ull))[wkey >> (2 * (KT - t))];
 			}
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 			if (wi + 1 == n) out_pos(wi + 1, true);
 			++wi;
 			if (wi == n) {
-				if (phase == 0 && P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = bid == 1 ? 1 : 0;   // only the terminator's ++: no restart (bwtaln.c:66-74)
+				if (phase == 0 && P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = (uint8_t)(bid - 1 > 4 ? 4 : bid - 1);   // restarts of this strand's pass (bid counts the terminator too, bwtaln.c:66-74)
 				if (phase == 0 && len > P.seed_len) {
 					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = false;
 					if (KT) { wkey = P.rd_key[6 * (size_t)rid + 4 + x]; tok = wkey != 0xffffffffu; }
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	int bw_base = -1, bw_a = -1;         // 16 bound bytes of strand bw_a from bw_base
 	int sw_base = -1, sw_a = -1;         // same for the seed bounds
 	uint4 wq_sq = make_uint4(0, 0, 0, 0), wq_bw = wq_sq, wq_sw = wq_sq;   // WIDE only (no LDS): the same windows in registers
-	unsigned long long touches = 0; uint32_t rd_touch = 0;               // COUNT only
+	unsigned long long touches = 0; uint32_t rd_touch = 0, rd_trips = 0;  // COUNT only
 	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0, st_txe = 0, st_txt = 0;
 	bool ovf = false;
 
@@ -435,6 +437,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #define BW_BYTE(i_) win_byte(s_bw, wq_bw, (uint32_t)(i_))
 #define SW_BYTE(i_) win_byte(s_sw, wq_sw, (uint32_t)(i_))
 #define SQ_BYTE(i_) win_byte(s_sq, wq_sq, (uint32_t)(i_))
+	// Key form.  With all levels of the interval table present, a gap-free entry of depth d <= KT (d = len - i reference symbols
+	// matched, substitutions included) needs no interval at all: its path key addresses level d, its four children are the
+	// 32 bytes at level d+1, its exact tail or forced walk lands at level KT under (key ++ the read's next symbols).  Such
+	// entries are carried as {k = key, l = KEYM}, are expanded without a rank query, and take on rows (one table load)
+	// when they are reported, reach depth KT, or yield a gap child that is popped.
+	const bool kf_ok = !WIDE && KT > 0 && (int)P.bwt[0].kmer_LW == KT && (int)P.bwt[1].kmer_LW == KT && (P.text_mode & 4);
 	const bool text_ok = !WIDE && (P.text_mode & 2) && P.bwt[0].sa_full && P.bwt[1].sa_full && P.bwt[0].seq_len < 0xfffffff0u;
 	uint32_t pf_slot = NIL;
 	bool finish = false;
@@ -463,15 +471,19 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		finish = false;
 		// ---------------------------------------------------------------- refill
 		unsigned long long need = __ballot(st == LS_IDLE);
-		// reads whose search is known to run alike (an exact occurrence exists: kernel W's class, sorted to the front) are
+		const bool any_busy = __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull;
+		// reads whose search is known to run alike (an exact occurrence exists: kernel W's class 0, sorted to the end) are
 		// taken 64 at a time by a wave with all lanes idle, so its lanes stay in step and its trips stay converged
-		if ((P.sync_refill || w_sync) && __ballot(st != LS_IDLE && st != LS_EXIT) != 0ull) need = 0ull;
+		if ((P.sync_refill || w_sync) && any_busy) need = 0ull;
 		if (need) {
 			if (w_next == w_end) {          // blocks of read numbers per wave, as in kernel W
-				unsigned int base = 0;
-				if (lane == 0) base = atomicAdd(P.work_counter, (unsigned int)NABWA_WORK_CHUNK);
-				w_next = __builtin_amdgcn_readfirstlane(base); w_end = w_next + NABWA_WORK_CHUNK;
-				w_sync = P.n_sync && w_end <= *P.n_sync;
+				unsigned int b0 = 0;
+				if (lane == 0) b0 = atomicAdd(P.work_counter, (unsigned int)NABWA_WORK_CHUNK);
+				w_next = __builtin_amdgcn_readfirstlane(b0); w_end = w_next + NABWA_WORK_CHUNK;
+				// class 0 (end of the work order): lockstep.  Class 2+ (start of the work order): also 64 reads at a time without
+				// refilling -- not for convergence but for the stragglers: the fewer lanes of a wave are still searching, the fewer
+				// code paths a trip runs through, and the launch waits for exactly those reads (cnt[2] = n_sync[-8])
+				w_sync = P.n_sync && (w_next >= *P.n_sync || w_next < P.n_sync[-8]);
 			}
 			const unsigned int rank = (unsigned int)__popcll(need & ((1ull << lane) - 1ull)), avail = w_end - w_next;
 			const unsigned int base = w_next;
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						if (len > KT) { const uint8_t *const bb = REC + P.woff_bid + (len - KT - 1); fb = (uint32_t)(bb[0] & 127u) | (uint32_t)(bb[P.WLB] & 127u) << 8; }
 						s_fb[threadIdx.x] = fb;
 					}
-					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; ovf = false;
+					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; rd_trips = 0; ovf = false;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_score = -1; pf_slot = NIL;
 					if (text_ok) s_tw[threadIdx.x] = make_uint2(0u, 0x7fffffffu);
 					if (len > 0 && (int)P.rd_nN[rid] <= MD_READ) {      // too many N: no search (bwtgap.c:118-123)
@@ -502,8 +514,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						best_cnt = 0;
 						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
 						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
-						push_mem(0, mk_entry(0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0));
-						pe = mk_entry(0u, P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 1); p_score = 0;
+						push_mem(0, mk_entry(0u, kf_ok ? KEYM : P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0));
+						pe = mk_entry(0u, kf_ok ? KEYM : P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 1); p_score = 0;
 						n_entries = 2;
 						st = LS_POP;
 					} else { P.n_aln[item] = 0; P.max_ent[item] = 0; P.status[item] = NABWA_ST_OK; }
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		// what this lane does with its current entry in this trip
 		int kind = 0;                 // 1 expand, 2 exact-tail step, 3 hit without query (i == 0), 4 tail jump, 5 group member
 		bool need_win = false, spec = false, forced = false; int win_hi = 0;
-		int grp_c = 0;
+		int grp_c = 0, mlev = -1, mpost = 0; uint32_t midx = 0; bool kx = false;      // mlev/midx: table entry that turns a key-form entry into rows (kind 6)
 		if (have && !finish && e_state == STATE_GROUP) {
 			// pop ONE member of a gap group, newest first (deletion of T, G, C, A, then the insertion); the rest goes back
 			// on the stack it came from, where it is again the top
@@ -561,7 +573,12 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			else if (more) push_mem(e_score, mk_entry(k + 1u, l, e_i + 1, (int)(3u | (more - 1u) << 9), e_mm, e_go, e_ge, STATE_GROUP, e_a));   // (text form) the next older level
 			if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 			if (ext) ++e_ge; else ++e_go;
-			if (j == 0) { e_state = STATE_I; e_ldp = e_i; }                 // the insertion keeps the parent's interval
+			if (l == KEYM) {                                                // key form: the parent (depth len - e_i - 1) or its child j-1, as rows
+				const int dp = len - e_i - 1;
+				kind = 6; st = LS_POP; have = false;
+				if (j == 0) { mpost = 1; mlev = dp; midx = k; } else { mpost = 2; mlev = dp + 1; midx = k * 4u + (uint32_t)(j - 1); }
+			}
+			else if (j == 0) { e_state = STATE_I; e_ldp = e_i; }            // the insertion keeps the parent's interval
 			else if (l == TXM) { k -= 1u; e_i += 1; e_state = STATE_D; e_ldp = e_i; }   // text form: the deleted base is the one to the left
 			else { kind = 5; grp_c = j - 1; st = LS_POP; have = false; }    // a deletion: re-derive its interval
 		}
@@ -569,7 +586,9 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			st = LS_POP;
 			m = max_diff - (e_mm + e_go); if (gape_mode) m -= e_ge;
 			if (m >= 0) {
-				if (e_i == 0) kind = 3;
+				const bool kf = l == KEYM;
+				const int d = len - e_i;                                      // depth of a gap-free entry
+				if (e_i == 0) { if (kf) { kind = 6; mlev = d; midx = k; } else kind = 3; }
 				else {
 					// the pre-check needs bound[e_i-1]; an expansion then needs bound[e_i-2] as well
 					const bool tail = m == 0 && (e_state == STATE_M || gape_mode || e_ge == P.max_gape);
@@ -580,36 +599,46 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						if (m < (int)(BW_BYTE(win_hi - bw_base) & 127u)) go = false;   // bwtgap.c:156
 					} else { need_win = true; spec = true; }
 					if (go) {
+						const bool rdkey_ok = KT && (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu;
+						// row form: the path is known when it is the read's own symbols with at most the one just consumed substituted
+						const bool row_known = l != TXM && !kf && (e_go | e_ge) == 0 && e_state == STATE_M && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i));
 						if (tail) {                                 // nothing may differ any more: exact tail (bwt.c:237-252)
 							kind = 2;                                   // its cursor is e_i: position e_i - 1 is consumed next
-							// tail jump: the path so far is the read's own last len-e_i symbols, at most one of them (the one
-							// just consumed) substituted, so the interval after KT symbols is one table entry away
+							// tail jump: the interval after KT symbols (the path so far, then the read's own) is one table entry away
 							if (l == TXM) kind = 7;                  // text form: compare the rest of the read with the text
-							else if (KT && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i <= KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
-								&& (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu) kind = 4;
+							else if (kf) { if (rdkey_ok) kind = 4; else { kind = 6; mlev = d; midx = k; } }
+							else if (rdkey_ok && row_known && d <= KT) kind = 4;
 						}
 						else {
 							// Forced matches.  Differences are allowed at a level only where the bound of the symbols still to
 							// come is below m (bwtgap.c:204-207); the bounds never grow towards the read's start, and this entry
 							// was not pruned, so bound[len-KT-1] == m means: on every level down to depth KT the only child is
 							// the matching one, popped at once (same score, newest) -- an exact walk in all but name.  For an entry
-							// whose path is known (as for the tail jump) the table gives the interval it arrives with, or that it dies.
-							forced = KT && l != TXM && (e_go | e_ge) == 0 && e_state == STATE_M && len - e_i < KT && (e_mm == 0 || (e_mm == 1 && e_ldp == e_i))
-									 && (e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x) != 0xffffffffu
-									 && (int)(s_fb[threadIdx.x] >> (e_a << 3) & 0xffu) == m;
-							if (forced) kind = 4; else { kind = 1; --e_i; }
+							// whose path is known the table gives the interval it arrives with, or that it dies.
+							forced = rdkey_ok && d < KT && (kf || row_known) && (int)(s_fb[threadIdx.x] >> (e_a << 3) & 0xffu) == m;
+							if (forced) kind = 4;
+							else if (kf && d >= KT) { kind = 6; mlev = d; midx = k; }     // depth KT: rows from here on
+							else { kind = 1; --e_i; kx = kf; }
 						}
 					}
 				}
 			}
 		} else if (st == LS_EXACT) kind = l == TXM ? 7 : 2;
+		// a key-form entry turned into rows becomes the current entry of the next trip; a popped gap member takes its shape now
+		auto rows_arrived = [&](uint32_t nk, uint32_t nl) {
+			k = nk; l = nl;
+			if (mpost == 1) { e_state = STATE_I; e_ldp = e_i; }
+			else if (mpost == 2) { e_i += 1; e_state = STATE_D; e_ldp = e_i; }
+			st = LS_HAVE;
+		};
+		if (kind == 6 && mlev == 0) { rows_arrived(0u, e_a ? P.bwt[0].seq_len : P.bwt[1].seq_len); kind = 0; }   // depth 0: every row
 
 		const int qb = 1 - e_a;
 		const bool tx = l == TXM && (kind == 1 || kind == 3 || kind == 7);
 		const int spos = (kind == 2 || kind == 7) ? e_i - 1 : e_i;
 		const int stag = (e_a << 20) | (spos >> 4);
 		const bool need_seq = (kind == 1 || kind == 2 || kind == 7) && stag != sq_tag;
-		bool query = (kind == 1 && !tx) || kind == 2 || kind == 5;
+		bool query = (kind == 1 && !tx && !kx) || kind == 2 || kind == 5;
 		// text word in front of the suffix (kinds 1 and 7 in text form)
 		uint2 tw = make_uint2(0u, 0u); bool need_tw = false;
 		if (tx && kind != 3 && k > 0u) {
@@ -618,7 +647,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			need_tw = tw.y != tag;
 			tw.y = tag;
 		}
-		const bool to_text = kind == 1 && !tx && text_ok && k == l;   // one row left: its children go on in text form
+		const bool to_text = kind == 1 && !tx && !kx && text_ok && k == l;   // one row left: its children go on in text form
 		if (kind == 2 && !need_seq && SQ_BYTE((uint32_t)spos & 15u) > 3u) query = false;   // an N: no query
 		const int ii = e_i - (len - P.seed_len);
 		const bool use_seed = kind == 1 && e_i > 0 && seeded && ii > 0;
@@ -645,17 +674,25 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		uint2 r_km = make_uint2(1u, 0u);
 		if (kind == 4) {
 			uint32_t key = e_a ? s_key[threadIdx.x].y : s_key[threadIdx.x].x;
-			if (e_mm) {     // the substituted symbol is the one k was derived with: k lies in (C(c), C(c+1)]
+			const int d = len - e_i;
+			if (l == KEYM) {          // the path so far, then the read's own next KT - d symbols
+				if (d > 0) { const uint32_t sh = 2u * (uint32_t)(KT - d); key = (k << sh) | (sh ? key & ((1u << sh) - 1u) : 0u); }
+			} else if (e_mm) {     // the substituted symbol is the one k was derived with: k lies in (C(c), C(c+1)]
 				const uint32_t c1 = qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1], c2 = qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2], c3 = qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3];
 				const uint32_t cs = (k > c1 ? 1u : 0u) + (k > c2 ? 1u : 0u) + (k > c3 ? 1u : 0u);
-				const uint32_t sh = 2u * (uint32_t)(KT - (len - e_i));
+				const uint32_t sh = 2u * (uint32_t)(KT - d);
 				key = (key & ~(3u << sh)) | cs << sh;
 			}
 			r_km = (qb ? P.bwt[1].kmer : P.bwt[0].kmer)[key];
 		}
+		if (kind == 6) r_km = ((qb ? P.bwt[1].kmer_lo : P.bwt[0].kmer_lo) + LVO(mlev))[midx];
 		// the rank query: Occ of all four bases at rows k-1 and l of index qb (bwt.c:159-216 conventions)
 		uint4 a0, a1, a2, a3, b0, b1, b2, b3; uint32_t rk = 0, rl = 0; bool kvalid = false, two = false;
 		a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = make_uint4(0, 0, 0, 0);
+		if (kx) {       // key form: the four children of this level, 32 bytes of the next table level
+			const uint4 *const ch = (const uint4*)((qb ? P.bwt[1].kmer_lo : P.bwt[0].kmer_lo) + LVO(len - e_i) + (size_t)k * 4);
+			a0 = ch[0]; a1 = ch[1];
+		}
 		if (query) {
 			const uint32_t primary = qb ? P.bwt[1].primary : P.bwt[0].primary;
 			const uint4 *bk = qb ? P.bwt[1].bk : P.bwt[0].bk;
@@ -681,6 +718,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 			if (pf_now) r_ent = ent[pf_cand];
 		}
+		if (COUNT && st != LS_IDLE && st != LS_EXIT) ++rd_trips;
 		if (COUNT) {   // trip statistics (instrumented build only): [2] trips, [3..] lane-trips by activity
 			const unsigned long long bx = __ballot(kind == 1), be = __ballot(kind == 2), bm = __ballot(want_ent),
 				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT), bj = __ballot(kind == 4), bt = __ballot(tx && kind == 1), b7 = __ballot(kind == 7);
@@ -712,6 +750,13 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 			if (COUNT && kind != 5) rd_touch += ref_touches(qb ? P.bwt[1] : P.bwt[0], k - 1u, l, kind == 1);   // (the reference derived a group's members in the parent's query)
 		}
+		if (kx && kind == 1) {
+			// key form: child j exists iff its table interval is not empty, and is again a key: present it to the generic
+			// expansion below as "counts" (with C(.) = 0) that yield {key * 4 + j, KEYM}
+			const uint32_t ek[4] = { a0.x, a0.z, a1.x, a1.z }, el[4] = { a0.y, a0.w, a1.y, a1.w };
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const bool ne = ek[j] <= el[j]; ck.c[j] = ne ? k * 4u + (uint32_t)j - 1u : 0u; cl.c[j] = ne ? KEYM : 0u; }
+		}
 		const bool tx1 = tx && kind == 1;
 		if (tx1) {
 			// the one row's only non-empty child is for the text base b to the left of the suffix, and it is the suffix
@@ -720,14 +765,16 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #pragma unroll
 			for (int j = 0; j < 4; ++j) { ck.c[j] = b == (uint32_t)j ? k - 2u : 0u; cl.c[j] = b == (uint32_t)j ? TXM : 0u; }
 		}
-		const uint32_t L2q0 = tx1 ? 0u : (qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0]), L2q1 = tx1 ? 0u : (qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1]);
-		const uint32_t L2q2 = tx1 ? 0u : (qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2]), L2q3 = tx1 ? 0u : (qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3]);
+		const bool syn = tx1 || (kx && kind == 1);
+		const uint32_t L2q0 = syn ? 0u : (qb ? P.bwt[1].L2[0] : P.bwt[0].L2[0]), L2q1 = syn ? 0u : (qb ? P.bwt[1].L2[1] : P.bwt[0].L2[1]);
+		const uint32_t L2q2 = syn ? 0u : (qb ? P.bwt[1].L2[2] : P.bwt[0].L2[2]), L2q3 = syn ? 0u : (qb ? P.bwt[1].L2[3] : P.bwt[0].L2[3]);
 		const uint32_t seqlen_q = qb ? P.bwt[1].seq_len : P.bwt[0].seq_len;
 #define L2Q(cc) ((cc) == 0 ? L2q0 : ((cc) == 1 ? L2q1 : ((cc) == 2 ? L2q2 : L2q3)))
 #define CK(cc) ((cc) == 0 ? ck.c[0] : ((cc) == 1 ? ck.c[1] : ((cc) == 2 ? ck.c[2] : ck.c[3])))
 #define CL(cc) ((cc) == 0 ? cl.c[0] : ((cc) == 1 ? cl.c[1] : ((cc) == 2 ? cl.c[2] : cl.c[3])))
 
-		if (kind == 5) {                                        // the popped deletion: one more base of the reference, same read position
+		if (kind == 6) rows_arrived(r_km.x, r_km.y);
+		else if (kind == 5) {                                   // the popped deletion: one more base of the reference, same read position
 			k = L2Q(grp_c) + CK(grp_c) + 1u; l = L2Q(grp_c) + CL(grp_c);
 			e_i += 1; e_state = STATE_D; e_ldp = e_i;
 			st = LS_HAVE;
@@ -819,7 +866,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 		} else if (kind == 1) {
 			// ---- node expansion (bwtgap.c:201-260); e_i is already decremented
-			const uint32_t occ = tx1 ? 1u : l - k + 1u;
+			const uint32_t occ = tx1 ? 1u : l - k + 1u;                   // (key form: only read by deletion-state parents, which are never in key form)
 			bool match_child = false;
 			bool allow_diff = true, allow_M = true;
 			if (e_i > 0) {
@@ -926,6 +973,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (finish) {
 			P.n_aln[item] = n_aln; P.max_ent[item] = max_ent; P.status[item] = (uint8_t)status;
 			if (COUNT && status == NABWA_ST_OK) touches += rd_touch;   // abandoned reads are counted by the wide pass
+			if (COUNT && P.touch_counter) { atomicMax(P.touch_counter + 13, (unsigned long long)rd_trips); if (rd_trips > 2000u) atomicAdd(P.touch_counter + 14, 1ull); if (rd_trips > 500u) atomicAdd(P.touch_counter + 15, 1ull); }
 			st = LS_IDLE;
 		}
 	}
@@ -1122,37 +1170,65 @@ extern "C" void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *
 					   aln2, aln_cap2, sum, rows);
 }
 
-// work order of the search kernel: reads of class 1 (kernel W) from the front, the others from the back.
-// One wave handles 16 consecutive groups of 64 reads with ONE atomic per class (single-address atomics cost ~11 ns each).
+// Work order of the search kernel by kernel W's class of a read = the smaller of its two strands' restart counts, i.e. a
+// lower bound of the differences of its best hit: 0 (an exact occurrence exists), 1, 2+.  A search can take 10^4 dependent
+// trips (tens of ms; the launch cannot end before its longest search does), so the long searches must START first:
+// order 2+, 1, 0.  Class 0 reads run alike and close the launch in lockstep waves (64 reads at a time); the others go lane
+// by lane.  (Tried: class 1 in lockstep waves -- its reads differ too much; a finer order 4+, 3, 2, 1, 0 -- the few hundred
+// longest searches then sit in ONE wave's first block and run one after the other; those reads one per wave, or their waves
+// at raised issue priority -- a trip is no shorter for it.  Mixed into the 2+ class they start in ~650 different waves at once.)
+// cnt: [0..2] class sizes (pass 1), [5..7] cursors (pass 2), [10] = first work item of class 0 (*n_sync of the search
+// kernel).  One wave handles 1024 consecutive reads with one atomic per class.
+#define NABWA_N_CLASS 3
+template <int PASS>
 __global__ __launch_bounds__(256) void partition_kernel(int n, const uint8_t *__restrict__ cls, int32_t *__restrict__ ids, unsigned int *__restrict__ cnt)
 {
 	const unsigned int lane = threadIdx.x & 63u;
 	const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
 	const long first = wave * 1024;
+	if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) { unsigned int x = 0; for (int q = 1; q < NABWA_N_CLASS; ++q) x += cnt[q]; cnt[10] = x; }
 	if (first >= n) return;
-	unsigned long long ma[16], mb[16]; unsigned int na = 0, nb = 0;
+	unsigned int num[NABWA_N_CLASS]; int cl[16];
+#pragma unroll
+	for (int q = 0; q < NABWA_N_CLASS; ++q) num[q] = 0;
 #pragma unroll
 	for (int g = 0; g < 16; ++g) {
 		const long i = first + g * 64 + lane;
-		const bool in = i < n; const uint8_t c = in ? (cls[2 * i] | cls[2 * i + 1]) : 0;   // either strand occurs exactly
-		ma[g] = __ballot(in && c != 0); mb[g] = __ballot(in && c == 0);
-		na += (unsigned int)__popcll(ma[g]); nb += (unsigned int)__popcll(mb[g]);
+		const uint8_t c0 = i < n ? cls[2 * i] : 0, c1 = i < n ? cls[2 * i + 1] : 0;
+		cl[g] = i < n ? (int)(c0 < c1 ? c0 : c1) : -1;
+		if (cl[g] > NABWA_N_CLASS - 1) cl[g] = NABWA_N_CLASS - 1;
+#pragma unroll
+		for (int q = 0; q < NABWA_N_CLASS; ++q) num[q] += (unsigned int)__popcll(__ballot(cl[g] == q));
 	}
-	unsigned int ba = 0, bb = 0;
-	if (lane == 0) { if (na) ba = atomicAdd(cnt, na); if (nb) bb = atomicAdd(cnt + 1, nb); }
-	ba = __shfl(ba, 0); bb = __shfl(bb, 0);
+	if (PASS == 1) {
+		if (lane == 0) for (int q = 0; q < NABWA_N_CLASS; ++q) if (num[q]) atomicAdd(cnt + q, num[q]);
+		return;
+	}
+	unsigned int base[NABWA_N_CLASS];
+#pragma unroll
+	for (int q = 0; q < NABWA_N_CLASS; ++q) base[q] = 0;
+	if (lane == 0) {
+		unsigned int start = 0;
+		for (int q = NABWA_N_CLASS - 1; q >= 0; --q) { if (num[q]) base[q] = start + atomicAdd(cnt + 5 + q, num[q]); start += cnt[q]; }
+	}
+#pragma unroll
+	for (int q = 0; q < NABWA_N_CLASS; ++q) base[q] = __shfl(base[q], 0);
 #pragma unroll
 	for (int g = 0; g < 16; ++g) {
 		const long i = first + g * 64 + lane;
 		const unsigned long long below = (1ull << lane) - 1ull;
-		if (ma[g] >> lane & 1ull) ids[ba + (unsigned int)__popcll(ma[g] & below)] = (int32_t)i;
-		if (mb[g] >> lane & 1ull) ids[(unsigned int)n - 1u - (bb + (unsigned int)__popcll(mb[g] & below))] = (int32_t)i;
-		ba += (unsigned int)__popcll(ma[g]); bb += (unsigned int)__popcll(mb[g]);
+#pragma unroll
+		for (int q = 0; q < NABWA_N_CLASS; ++q) {
+			const unsigned long long mq = __ballot(cl[g] == q);
+			if (cl[g] == q) ids[base[q] + (unsigned int)__popcll(mq & below)] = (int32_t)i;
+			base[q] += (unsigned int)__popcll(mq);
+		}
 	}
 }
 
 extern "C" void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(partition_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, n, cls, ids, cnt);
+	hipLaunchKernelGGL(partition_kernel<1>, dim3((n + 4095) / 4096), dim3(256), 0, s, n, cls, ids, cnt);
+	hipLaunchKernelGGL(partition_kernel<2>, dim3((n + 4095) / 4096), dim3(256), 0, s, n, cls, ids, cnt);
 }

@@ -39,7 +39,7 @@ struct SearchParams {
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
 	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
 	int w_sync;                               // kernel W: lockstep waves (all reads of the batch have one length)
-	uint8_t *rd_cls;                          // kernel W -> partition: 1 = one strand of the read occurs exactly (no restart in its width pass)
-	const unsigned int *n_sync;               // first *n_sync work items are such reads: their waves run in lockstep (see fm_search_kernel)
+	uint8_t *rd_cls;                          // kernel W -> partition: per strand the restarts of its width pass, clipped to 4
+	const unsigned int *n_sync;               // work items from *n_sync on are class-0 reads: their waves run in lockstep (see fm_search_kernel, partition_kernel)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
 };

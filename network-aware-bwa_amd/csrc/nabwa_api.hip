@@ -113,10 +113,10 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 	if (raw) HIPCHK(hipFree(raw));
 	B.bk = ix->bk[t_];
 	ix->bytes += (uint64_t)B.n_buckets * 64;
-	{	/* interval table: T = floor(log4(seq_len)) + 1 (about a quarter row per key at the last level: most walks that the table
-		 * replaces die inside it), at most 16 and no more than a third of the free HBM; NABWA_KMER_T overrides (0 = off).
-		 * GRCh38: T = 16, 34 GB per index; T = 15 costs 8 % of the search time and saves 52 GB.  Levels
-		 * 1..LW (LW = min(T, 12)) stay, for the width passes; the levels between LW and T are scaffolding. */
+	{	/* interval table, ALL levels 1..T back to back (level t at offset (4^t - 4) / 3): T = floor(log4(seq_len)) + 1 (about a
+		 * quarter row per key at the last level: most walks that the table replaces die inside it), at most 16 and no more
+		 * than 40 % of the free HBM; NABWA_KMER_T overrides (0 = off).  GRCh38: T = 16, 46 GB per index.  The search keeps
+		 * every gap-free entry of depth <= T as its path KEY and takes children, tails and forced walks from here. */
 		int T = 0;
 		for (uint64_t x = B.seq_len; x >= 4; x >>= 2) ++T;
 		T += 1;
@@ -125,33 +125,20 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 		if (T > 16) T = 16;
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
-		while (T > 12 && (((size_t)1 << (2 * T)) + ((size_t)1 << (2 * T - 2))) * 8 > free_b / 3) --T;
+		auto table_entries = [](int t) { size_t x = 0; for (int u = 1; u <= t; ++u) x += (size_t)1 << (2 * u); return x; };
+		while (T > 12 && table_entries(T) * 8 > free_b / 5 * 2) --T;
 		if (T >= 1) {
-			const int LW = T < 12 ? T : 12;
-			size_t lo_n = 0;
-			for (int t = 1; t <= LW; ++t) lo_n += (size_t)1 << (2 * t);
+			const size_t lo_n = table_entries(T);
 			HIPCHK(hipMalloc(&ix->kmer[t_], lo_n * 8));
 			uint2 *prev = 0, *cur = ix->kmer[t_];
-			for (int t = 1; t <= LW; ++t) {
+			for (int t = 1; t <= T; ++t) {
 				nabwa_launch_kmer_level(&B, prev, cur, (uint64_t)1 << (2 * t), 0);
 				prev = cur; cur += (size_t)1 << (2 * t);
 			}
-			ix->bytes += lo_n * 8;
-			uint2 *tmp[2] = { 0, 0 };
-			for (int t = LW + 1; t <= T; ++t) {               /* ping-pong up to the last level, which stays */
-				uint2 *dst = 0;
-				HIPCHK(hipMalloc(&dst, ((size_t)1 << (2 * t)) * 8));
-				nabwa_launch_kmer_level(&B, prev, dst, (uint64_t)1 << (2 * t), 0);
-				HIPCHK(hipGetLastError());
-				HIPCHK(hipDeviceSynchronize());
-				if (tmp[0]) HIPCHK(hipFree(tmp[0]));
-				tmp[0] = tmp[1]; tmp[1] = dst; prev = dst;
-			}
-			if (tmp[0]) HIPCHK(hipFree(tmp[0]));
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipDeviceSynchronize());
-			if (T > LW) { ix->kmer_top[t_] = tmp[1]; ix->bytes += ((size_t)1 << (2 * T)) * 8; }
-			B.kmer = prev; B.kmer_T = (uint32_t)T; B.kmer_lo = ix->kmer[t_]; B.kmer_LW = (uint32_t)LW;
+			ix->bytes += lo_n * 8;
+			B.kmer = prev; B.kmer_T = (uint32_t)T; B.kmer_lo = ix->kmer[t_]; B.kmer_LW = (uint32_t)T;
 		}
 	}
 	if (sa_words) {
@@ -409,7 +396,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
 	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
-	BCHK(hipMalloc(&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 8));
+	BCHK(hipMalloc(&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 64));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
@@ -429,7 +416,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
 	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key;
-	P.text_mode = env_int("NABWA_TEXT_KERNELS", 3);      /* bit 0: width kernel, bit 1: search kernel */
+	P.text_mode = env_int("NABWA_TEXT_KERNELS", 7);      /* bit 0: text mode in the width kernel, bit 1: in the search kernel, bit 2: key form in the search kernel */
 	if (ix->bwt[0].kmer_T != ix->bwt[1].kmer_T) P.bwt[0].kmer_T = P.bwt[1].kmer_T = 0;
 	P.ids = 0; P.n = n;
 	P.s_mm = opt->s_mm; P.s_gapo = opt->s_gapo; P.s_gape = opt->s_gape; P.mode = opt->mode;
@@ -475,7 +462,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	const size_t n1 = n ? n : 1;
 	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
 	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
-	BCHK(hipMalloc(&b->d_counter, 8)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
+	BCHK(hipMalloc(&b->d_counter, 16)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
 	BCHK(hipMalloc(&b->d_sum, 128));
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
@@ -489,17 +476,17 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	HIPCHK(hipSetDevice(b->ix->device));
 	b->unresolved = 0;
 	if (b->n == 0) return NABWA_OK;
-	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
 	HIPCHK(hipEventRecord(b->evw, b->stream));
 	SearchParams PW = b->P; PW.ids = 0; PW.rd_cls = b->class_sort ? b->d_cls : 0;
 	nabwa_launch_fm_width(&PW, b->n_blocks_w, b->stream);
 	if (b->class_sort) {      /* work order of the search: reads with an exact occurrence first, in lockstep waves */
-		HIPCHK(hipMemsetAsync(b->d_ncls, 0, 8, b->stream));
+		HIPCHK(hipMemsetAsync(b->d_ncls, 0, 64, b->stream));
 		nabwa_launch_partition(b->n, b->d_cls, b->d_perm, b->d_ncls, b->stream);
 	}
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
-	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls : 0;
+	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls + 10 : 0;
 	if (b->P.NS <= 64) nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
 	else {      /* the first-pass kernel tracks at most 64 score levels: such option blocks go through the second pass whole */
 		HIPCHK(hipMemsetAsync(b->d_status, NABWA_ST_OVERFLOW, b->n, b->stream));
@@ -545,7 +532,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	if (!b->d_scratch2) HIPCHK(hipMalloc(&b->d_scratch2, need));   // size only depends on the option block
 	Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)novf;
 	Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2;
-	HIPCHK(hipMemsetAsync(b->d_counter, 0, 8, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 	{	// the first pass edited these reads' width records in place (gap_shadow): rebuild them
 		SearchParams QW = Q; QW.touch_counter = 0;
 		long bw2 = (2 * (long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
@@ -592,11 +579,16 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 	HIPCHK(hipMemcpy(v, b->d_sum, 16, hipMemcpyDeviceToHost));
 	*n_bucket = v[0];                          /* search kernel (bwt_match_gap) */
 	if (n_bucket_width) *n_bucket_width = v[1];  /* width kernel (bwt_cal_width) */
+	if (getenv("NABWA_TRIP_STATS") && b->class_sort) {
+		unsigned int c[12];
+		HIPCHK(hipMemcpy(c, b->d_ncls, 48, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[nabwa] read classes by restarts 0 / 1 / 2+: %u / %u / %u\n", c[0], c[1], c[2]);
+	}
 	if (getenv("NABWA_TRIP_STATS")) {
 		unsigned long long t[16];
 		HIPCHK(hipMemcpy(t, b->d_sum, 128, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu text-expand %llu text-tail %llu\n",
-				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12]);
+		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu text-expand %llu text-tail %llu; longest read %llu trips, %llu reads over 2000 trips, %llu over 500\n",
+				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
 	}
 	return NABWA_OK;
 }
