@@ -1,0 +1,31 @@
+"""bench.py end to end on a small synthetic genome: one JSON line with the contract's fields, the roofline and cpu_baseline
+objects, and the GPU rows of the CPU sample bit-exact (the CPU leg runs the compiled reference when oracle/_ref travelled,
+the restatement otherwise)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipeline"]])
+def test_bench_line(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--genome-len", "30000000", "--reads", "200000", "--steps", "2",
+           "--warmup", "1", "--cpu-seconds", "3"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "reads/s" and d["value"] > 0
+    assert d["config"]["bit_exact_vs_cpu_sample"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] and d["roofline"]["kernel_ms"] > 0
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
+    assert abs(d["value"] - 200000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
