@@ -94,6 +94,7 @@ def main():
     d_text.free()
     opt = nabwa.gap_init_opt()
     # one end-to-end pass over host buffers (upload + both kernels + compacted download): the PCIe-inclusive rate
+    ix.cal_sa_reg_gap_flat(opt, seq[:off[1000]], rseq[:off[1000]], off[:1001], per_read=True)   # (loads the kernels' code objects once)
     torch.cuda.synchronize()
     t_pcie = time.time()
     _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq, rseq, off, per_read=True)      # the C one-shot entry on host buffers

@@ -394,10 +394,10 @@ class Index:
         n = len(off) - 1
         seq = np.ascontiguousarray(seq, np.uint8); rseq = np.ascontiguousarray(rseq, np.uint8)
         off = np.ascontiguousarray(off, np.int64)
-        n_aln = np.zeros(max(n, 1), np.int32); maxe = np.zeros(max(n, 1), np.int32)
-        cap = int(cap_rows if cap_rows is not None else 2 * n + 1024)
+        n_aln = np.empty(max(n, 1), np.int32); maxe = np.empty(max(n, 1), np.int32)
+        cap = int(cap_rows if cap_rows is not None else n + n // 8 + 1024)
         while True:
-            buf = np.zeros(max(cap, 1), ALN_DT)
+            buf = np.empty(max(cap, 1), ALN_DT)
             rows = C.c_int64()
             rc = lib().nabwa_cal_sa_reg_gap(self._h, C.byref(opt), n, _ptr(off), _ptr(seq), _ptr(rseq), int(per_read),
                                             _ptr(n_aln), _ptr(buf), cap, C.byref(rows), _ptr(maxe))
