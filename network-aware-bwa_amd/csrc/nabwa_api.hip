@@ -335,6 +335,9 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 {
 	if (!ix || !opt || !off || !out || n < 0 || (n && (!seq || !rseq))) return fail(NABWA_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(ix->device));
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tc0 = now();
 	// ---- per-read option derivation, on the host in double (bwtaln.c:102-106,125)
 	int max_len = 0;
 	for (int i = 0; i < n; ++i) {
@@ -379,6 +382,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		return fail(NABWA_EINVAL, "option block needs more than 128 score levels (unsupported)");
 	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
 
+	const double tc1 = now();
 	nabwa_batch *b = new nabwa_batch();
 	memset(b, 0, sizeof(*b));
 	b->ix = ix; b->opt = *opt; b->n = n;
@@ -412,6 +416,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		BCHK(hipMemcpy(b->d_mg, mg.data(), n, hipMemcpyHostToDevice));
 	}
 
+	const double tc2 = now();
 	SearchParams &P = b->P;
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
@@ -467,6 +472,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
 	*out = b;
+	if (timing) fprintf(stderr, "[nabwa] batch_create %d reads: host option derivation %.3f s, read upload + device layout %.3f s, working buffers %.3f s\n", n, tc1 - tc0, tc2 - tc1, now() - tc2);
 	return NABWA_OK;
 }
 
