@@ -370,6 +370,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	int sw_base = -1, sw_a = -1;         // same for the seed bounds
 	uint4 wq_sq = make_uint4(0, 0, 0, 0), wq_bw = wq_sq, wq_sw = wq_sq;   // WIDE only (no LDS): the same windows in registers
 	unsigned long long touches = 0; uint32_t rd_touch = 0, rd_trips = 0;  // COUNT only
+	uint32_t rk_kf = 0, rk_row2 = 0, rk_row1 = 0, rk_tx = 0, rk_pop = 0, rk_tail = 0, rk_jump = 0, rk_gap = 0;   // COUNT only: this read's trips by kind
 	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0, st_txe = 0, st_txt = 0;
 	bool ovf = false;
 
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						s_fb[threadIdx.x] = fb;
 					}
 					n_aln = 0; max_ent = 0; status = NABWA_ST_OK; rd_touch = 0; rd_trips = 0; ovf = false;
+					rk_kf = rk_row2 = rk_row1 = rk_tx = rk_pop = rk_tail = rk_jump = rk_gap = 0;
 					sq_tag = -1; bw_a = -1; sw_a = -1; p_score = -1; pf_slot = NIL;
 					if (text_ok) s_tw[threadIdx.x] = make_uint2(0u, 0x7fffffffu);
 					if (len > 0 && (int)P.rd_nN[rid] <= MD_READ) {      // too many N: no search (bwtgap.c:118-123)
@@ -718,7 +720,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 			if (pf_now) r_ent = ent[pf_cand];
 		}
-		if (COUNT && st != LS_IDLE && st != LS_EXIT) ++rd_trips;
+		if (COUNT && st != LS_IDLE && st != LS_EXIT) {
+			++rd_trips;
+			if (kind == 1) { if (kx) ++rk_kf; else if (tx) ++rk_tx; else if (two) ++rk_row2; else ++rk_row1; if (e_go | e_ge) ++rk_gap; }
+			else if (want_ent) ++rk_pop; else if (kind == 2 || kind == 7) ++rk_tail; else if (kind == 4) ++rk_jump;
+		}
 		if (COUNT) {   // trip statistics (instrumented build only): [2] trips, [3..] lane-trips by activity
 			const unsigned long long bx = __ballot(kind == 1), be = __ballot(kind == 2), bm = __ballot(want_ent),
 				bs = __ballot(spec), bq = __ballot(query), b2 = __ballot(query && two), bi = __ballot(st == LS_EXIT), bj = __ballot(kind == 4), bt = __ballot(tx && kind == 1), b7 = __ballot(kind == 7);
@@ -973,6 +979,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		if (finish) {
 			P.n_aln[item] = n_aln; P.max_ent[item] = max_ent; P.status[item] = (uint8_t)status;
 			if (COUNT && status == NABWA_ST_OK) touches += rd_touch;   // abandoned reads are counted by the wide pass
+			if (COUNT && P.touch_counter && rd_trips > 8000u) {
+				atomicAdd(P.touch_counter + 16, 1ull); atomicAdd(P.touch_counter + 17, (unsigned long long)rd_trips); atomicAdd(P.touch_counter + 18, (unsigned long long)rk_kf);
+				atomicAdd(P.touch_counter + 19, (unsigned long long)rk_row2); atomicAdd(P.touch_counter + 20, (unsigned long long)rk_row1); atomicAdd(P.touch_counter + 21, (unsigned long long)rk_tx);
+				atomicAdd(P.touch_counter + 22, (unsigned long long)rk_pop); atomicAdd(P.touch_counter + 23, (unsigned long long)rk_tail); atomicAdd(P.touch_counter + 24, (unsigned long long)rk_jump); atomicAdd(P.touch_counter + 25, (unsigned long long)rk_gap);
+			}
 			if (COUNT && P.touch_counter) { atomicMax(P.touch_counter + 13, (unsigned long long)rd_trips); if (rd_trips > 2000u) atomicAdd(P.touch_counter + 14, 1ull); if (rd_trips > 500u) atomicAdd(P.touch_counter + 15, 1ull); }
 			st = LS_IDLE;
 		}

@@ -468,7 +468,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
 	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
 	BCHK(hipMalloc(&b->d_counter, 16)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
-	BCHK(hipMalloc(&b->d_sum, 128));
+	BCHK(hipMalloc(&b->d_sum, 256));
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
 	*out = b;
@@ -569,7 +569,7 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 {
 	if (!b || !n_bucket) return fail(NABWA_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(b->ix->device));
-	HIPCHK(hipMemsetAsync(b->d_sum, 0, 128, b->stream));
+	HIPCHK(hipMemsetAsync(b->d_sum, 0, 256, b->stream));
 	b->P.touch_counter = b->d_sum;
 	/* the reference walks every exact tail row by row: count with the tail jump off (NABWA_TRIP_STATS=jump keeps it
 	 * on to profile the production trips; the touch totals are then not the reference's) */
@@ -591,10 +591,12 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 		fprintf(stderr, "[nabwa] read classes by restarts 0 / 1 / 2+: %u / %u / %u\n", c[0], c[1], c[2]);
 	}
 	if (getenv("NABWA_TRIP_STATS")) {
-		unsigned long long t[16];
-		HIPCHK(hipMemcpy(t, b->d_sum, 128, hipMemcpyDeviceToHost));
+		unsigned long long t[32];
+		HIPCHK(hipMemcpy(t, b->d_sum, 256, hipMemcpyDeviceToHost));
 		fprintf(stderr, "[nabwa] search kernel: wave-trips %llu; lane-trips: expand %llu exact %llu entry-load %llu spec %llu query %llu two-bucket %llu exited %llu tail-jump %llu text-expand %llu text-tail %llu; longest read %llu trips, %llu reads over 2000 trips, %llu over 500\n",
 				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
+		fprintf(stderr, "[nabwa] the %llu reads over 8000 trips: %llu trips = expansions key-form %llu, rows two-bucket %llu, rows one-bucket %llu, text %llu (of all: %llu with gaps); pops %llu, tail steps %llu, jumps %llu\n",
+				t[16], t[17], t[18], t[19], t[20], t[21], t[25], t[22], t[23], t[24]);
 	}
 	return NABWA_OK;
 }
