@@ -122,8 +122,20 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 	bool tmode = false; uint32_t tp = 0, twtag = 0xffffffffu; uint2 twin = make_uint2(0u, 0u);
 	const bool text_ok = (P.text_mode & 1) && P.bwt[0].sa_full && P.bwt[1].sa_full;
 	uint32_t kk = 0, ll = 0, pw = 0; int bid = 0;
-	uint32_t wkey = 0xffffffffu; bool tok = false;          // interval-table key of this phase's first KT symbols
+	uint32_t wkey = 0xffffffffu; bool tok = false; int tbase = 0;   // interval-table key of the KT symbols from position tbase of this phase (the current restart point)
 	const int KT = (int)P.bwt[0].kmer_T, LW = (int)P.bwt[0].kmer_LW;
+	// after a restart (bwtaln.c:66-70) the pattern begins anew at the next position: its key comes from the packed read
+	auto rekey = [&](int from) {
+		tok = false; tbase = from;
+		if (!KT || !P.rd_pack || from + 4 >= n) return;
+		const int PW = P.pack_stride / 2;
+		const uint32_t *const pk = P.rd_pack + (size_t)rid * P.pack_stride + x * PW;
+		if (pk[PW - 1]) return;                                   // an N somewhere in this strand: step by step
+		const int q = sbase + from;
+		const uint32_t w0 = pk[q >> 4], w1 = pk[(q >> 4) + 1], sh = ((uint32_t)q & 15u) << 1;
+		const uint32_t k16 = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+		wkey = k16 >> (2 * (16 - KT)); tok = true;
+	};
 	uint4 wacc = make_uint4(0, 0, 0, 0); uint64_t blo = 0, bhi = 0, slo = 0, shi = 0; int stag = -1;
 	unsigned long long touches = 0;
 
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 					if (len > 0) {
 						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = false;
 						if (KT) { wkey = P.rd_key[6 * (size_t)rid + 2 + x]; tok = wkey != 0xffffffffu; }
+						tbase = 0;
 						kk = 0; ll = BX(seq_len); bid = 0; pw = 0; blo = bhi = 0;
 					} else { if (x == 0u) P.rd_nN[rid] = 0; if (P.rd_cls) P.rd_cls[2 * (size_t)rid + x] = 0; }   // (an empty read: nothing to search)
 				} else done = true;
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 			}
 		}
 		if (bulk) { /* chunk done */ }
-		else if (run && tok && wi + 4 <= LW && wi + 4 < n) {
+		else if (run && tok && wi - tbase + 4 <= LW && wi + 4 < n) {
 			// table trip: the intervals after wi+1 .. wi+4 symbols of this phase are entries of levels wi+1 .. wi+4 of the
 			// interval table (fm_index.hip) -- four independent 8-byte loads, the low levels cache-resident -- instead
 			// of four dependent rank queries.  An empty entry is the reference's restart (bwtaln.c:66-70): from there on
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 			const uint2 *const lo = BX(kmer_lo);
 #pragma unroll
 			for (int u = 0; u < 4; ++u) {
-				const int t = wi + u + 1;
+				const int t = wi - tbase + u + 1;
 				tv[u] = (lo + (size_t)((((uint64_t)1 << (2 * t)) - 4ull) / 3ull))[wkey >> (2 * (KT - t))];
 			}
 #pragma unroll
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 				if (dead) { kk = 0; ll = BX(seq_len); ++bid; }
 				out_pos(wi, false);
 				++wi;
-				if (dead) { tok = false; break; }
+				if (dead) { rekey(wi); break; }
 			}
 		} else if (run) {
 			const int pos = sbase + wi;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 					if (ok) tp = t;
 				}
 				if (cc > 3 && x == 0u && phase == 0) ++nN;
-				if (!ok) { tmode = false; kk = 0; ll = BX(seq_len); ++bid; }   // the restart of bwtaln.c:66-70
+				if (!ok) { tmode = false; kk = 0; ll = BX(seq_len); ++bid; rekey(wi + 1); }   // the restart of bwtaln.c:66-70
 			} else {
 				const bool was_one = text_ok && cc < 4 && kk == ll;
 				if (cc < 4) {
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 					const uint32_t ol = cc == 0 ? cl.c[0] : (cc == 1 ? cl.c[1] : (cc == 2 ? cl.c[2] : cl.c[3]));
 					kk = L2c + ok + 1u; ll = L2c + ol;
 				} else if (x == 0u && phase == 0) ++nN;
-				if (kk > ll || cc > 3) { kk = 0; ll = BX(seq_len); ++bid; }
+				if (kk > ll || cc > 3) { kk = 0; ll = BX(seq_len); ++bid; rekey(wi + 1); }
 				else if (was_one) { tmode = true; tp = sav - 1u; twtag = 0xffffffffu; }
 			}
 			out_pos(wi, false);
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 				if (phase == 0 && len > P.seed_len) {
 					phase = 1; wi = 0; n = P.seed_len; sbase = len - P.seed_len; tmode = false;
 					if (KT) { wkey = P.rd_key[6 * (size_t)rid + 4 + x]; tok = wkey != 0xffffffffu; }
+					tbase = 0;
 					kk = 0; ll = BX(seq_len); bid = 0; pw = 0;
 				} else { if (x == 0u) P.rd_nN[rid] = (uint8_t)(nN > 255 ? 255 : nN); run = false; }
 			}
@@ -1043,7 +1057,7 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ rseq,
 													const int64_t *__restrict__ off, const int64_t *__restrict__ poff,
 													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len,
-													uint32_t *__restrict__ rd_key, int T, int seed_len)
+													uint32_t *__restrict__ rd_key, int T, int seed_len, uint32_t *__restrict__ rd_pack, int pack_stride)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
@@ -1069,13 +1083,28 @@ __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__
 		}
 	}
 	for (int v = 0; v < 6; ++v) rd_key[6 * (size_t)i + v] = key[v];
+	// both strands 2 bits per base, base j in word j>>4 from the TOP bits down, so that the 16 symbols from any position are
+	// one 32-bit extract in table-key order; the word after the last says whether the strand holds an N (then: no keys)
+	if (rd_pack) {
+		uint32_t *const pk = rd_pack + (size_t)i * pack_stride;
+		const int PW = pack_stride / 2;
+		for (int st = 0; st < 2; ++st) {
+			const uint8_t *src = (st ? rseq : seq) + o; uint32_t anyN = 0;
+			for (int w = 0; w < PW - 1; ++w) {
+				uint32_t x = 0;
+				for (int t = 0; t < 16; ++t) { const int j = w * 16 + t; const uint32_t c = j < L ? src[j] : 0u; anyN |= c > 3u ? 1u : 0u; x |= (c & 3u) << (30 - 2 * t); }
+				pk[st * PW + w] = x;
+			}
+			pk[st * PW + PW - 1] = anyN;
+		}
+	}
 }
 
 extern "C" void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, hipStream_t s)
+									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T, seed_len);
+	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T, seed_len, rd_pack, pack_stride);
 }
 
 // ids of the reads whose first pass was abandoned (arena or hit list outgrown)

@@ -38,6 +38,7 @@ struct SearchParams {
 	int aln_cap;
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
 	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
+	const uint32_t *rd_pack; int pack_stride;  // both strands of every read 2 bits per base (pad_reads_kernel); words per read
 	int w_sync;                               // kernel W: lockstep waves (all reads of the batch have one length)
 	uint8_t *rd_cls;                          // kernel W -> partition: per strand the restarts of its width pass, clipped to 4
 	const unsigned int *n_sync;               // work items from *n_sync on are class-0 reads: their waves run in lockstep (see fm_search_kernel, partition_kernel)

@@ -36,7 +36,7 @@ void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, c
 int nabwa_search_occupancy(int wide, int ns);
 void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, hipStream_t s);
+							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -274,7 +274,7 @@ struct nabwa_batch {
 	hipEvent_t ev0, ev1, evw;
 	float last_ms;
 	// device inputs
-	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; uint32_t *d_key; uint8_t *d_cls; int32_t *d_perm; unsigned int *d_ncls; int max_len;
+	uint8_t *d_seq, *d_rseq, *d_md, *d_mg; int64_t *d_poff; int32_t *d_len; uint32_t *d_key, *d_pack; int pack_stride; uint8_t *d_cls; int32_t *d_perm; unsigned int *d_ncls; int max_len;
 	// first pass
 	SearchParams P; int class_sort; uint32_t NS_wide; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
@@ -315,7 +315,7 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->ix->device);
-	void *ptrs[] = { b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
+	void *ptrs[] = { b->d_pack, b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -400,6 +400,8 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
 	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
 	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
+	b->pack_stride = 2 * ((max_len + 15) / 16 + 2);
+	BCHK(hipMalloc(&b->d_pack, (size_t)(n ? n : 1) * b->pack_stride * 4));
 	BCHK(hipMalloc(&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 64));
 	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 	if (n) {
@@ -409,7 +411,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		BCHK(hipMemcpy(raw_r, rseq, (size_t)off[n], hipMemcpyHostToDevice));
 		BCHK(hipMemcpy(raw_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->d_key,
-							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, opt->seed_len, b->stream);
+							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, opt->seed_len, b->d_pack, b->pack_stride, b->stream);
 		BCHK(hipStreamSynchronize(b->stream));
 		BCHK(hipFree(raw_s)); BCHK(hipFree(raw_r)); BCHK(hipFree(raw_off));
 		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));
@@ -420,7 +422,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	SearchParams &P = b->P;
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
-	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key;
+	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key; P.rd_pack = b->d_pack; P.pack_stride = b->pack_stride;
 	P.text_mode = env_int("NABWA_TEXT_KERNELS", 7);      /* bit 0: text mode in the width kernel, bit 1: in the search kernel, bit 2: key form in the search kernel */
 	if (ix->bwt[0].kmer_T != ix->bwt[1].kmer_T) P.bwt[0].kmer_T = P.bwt[1].kmer_T = 0;
 	P.ids = 0; P.n = n;
