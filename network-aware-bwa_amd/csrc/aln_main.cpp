@@ -1,0 +1,392 @@
+// aln_main.cpp -- `nabwa_aln`: the reference's `bwa aln` command (bwtaln.c:178-395) on top of libnabwa.so.
+//
+//   nabwa_aln [options] <prefix> <in.fq>  >  out.sai
+//
+// Same option letters, same gap_opt_t header, same record stream: the .sai it writes is byte-identical to the one
+// `bwa aln` writes for the same arguments (tests/test_gpu_aln_cli.py), so the reference's samse / sampe / bam2bam -0/-1/-2
+// consume it unchanged.  SURVEY.md 8f-4.  Host side only: FASTA/FASTQ parsing, read encoding and the batch plan live
+// here, every SA interval comes from the GPU through nabwa_cal_sa_reg_gap.  No CPU search path exists.
+//
+// Batch plan.  The reference calls bwa_cal_sa_reg_gap on 0x40000 reads at a time (bwtaln.c:207) and that chunking is
+// visible in the output in one corner: max_gapo is clamped to the max_diff of the LONGEST read of the call
+// (bwtaln.c:104-105).  We keep the chunk boundaries as bookkeeping, give the GPU runs of consecutive chunks whose clamp
+// comes out the same (normally: everything that was read), and split only where it differs.
+//
+// Not taken over: -b/-0/-1/-2 (BAM input is outside this path) are refused.  One deliberate difference:
+// resuming into an existing -f file (attempt_recovery, bwtaln.c:259-296) continues the record stream; the reference
+// writes a second copy of the 64-byte header at the resume point (bwtaln.c:387 is unconditional), which makes the
+// resumed file unreadable.  A resumed file here equals the file of an uninterrupted run.
+#include <ctype.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/nabwa.h"
+
+#define MODE_BAM_ANY   (0x20 | 0x40 | 0x80 | 0x100)   /* BWA_MODE_BAM*, bwtaln.h:137-140 */
+#define MODE_CFY       0x08
+#define MODE_IL13      0x200
+#define MAX_BCLEN      63                              /* bwtaln.h:30 */
+#define REF_CHUNK      0x40000                         /* reads per bwa_cal_sa_reg_gap call, bwtaln.c:207 */
+#define MIN_RDLEN      35                              /* bwtaln.h:28 */
+#define BARCODE_LOW_Q  13                              /* bwaseqio.c:170 */
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FASTA / FASTQ records the way kseq_read delivers them (kseq.h:155-193): a record starts at the next '>' or '@';
+// the name ends at the first white space, the rest of the line is the comment; sequence characters are gathered
+// up to the next '>', '+' or '@' WHEREVER it stands; after a '+' line, quality characters (33..127) are gathered
+// until there are as many as bases, and one more character is consumed.
+struct Fastx {
+	gzFile fp = nullptr;
+	std::vector<unsigned char> buf;
+	int have = 0, at = 0, pending = 0;
+	bool eof = false;
+	std::string name, comment, seq, qual;
+
+	bool open(const char *fn)
+	{
+		fp = strcmp(fn, "-") == 0 ? gzdopen(fileno(stdin), "r") : gzopen(fn, "r");
+		buf.resize(1 << 20);
+		return fp != nullptr;
+	}
+	void close() { if (fp) gzclose(fp); fp = nullptr; }
+	int ch()
+	{
+		if (at >= have) {
+			if (eof) return -1;
+			have = gzread(fp, buf.data(), (unsigned)buf.size()); at = 0;
+			if (have <= 0) { eof = true; have = 0; return -1; }
+		}
+		return buf[at++];
+	}
+	/* length of the sequence, -1 at the end of the input, -2 for a truncated quality string */
+	int next()
+	{
+		int c;
+		if (!pending) {
+			do c = ch(); while (c != -1 && c != '>' && c != '@');
+			if (c == -1) return -1;
+		}
+		pending = 0;
+		name.clear(); comment.clear(); seq.clear(); qual.clear();
+		while ((c = ch()) != -1 && !isspace(c)) name.push_back((char)c);
+		if (c == -1 && name.empty()) return -1;
+		if (c != '\n' && c != -1) while ((c = ch()) != -1 && c != '\n') comment.push_back((char)c);
+		while ((c = ch()) != -1 && c != '>' && c != '+' && c != '@') if (isgraph(c)) seq.push_back((char)c);
+		if (c == '>' || c == '@') pending = c;
+		if (c != '+') return (int)seq.size();
+		do c = ch(); while (c != -1 && c != '\n');
+		if (c == -1) return -2;
+		while ((c = ch()) != -1 && qual.size() < seq.size()) if (c >= 33 && c <= 127) qual.push_back((char)c);
+		if (qual.size() != seq.size()) return -2;
+		return (int)seq.size();
+	}
+};
+
+static uint8_t nt4(unsigned char c)         /* nst_nt4_table (bntseq.c:39-56); its 5 for '-' is "not a base" like 4 everywhere on this path */
+{
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	default: return 4;
+	}
+}
+
+struct Batch {                      /* what one GPU call (or a few) consumes */
+	std::vector<int64_t> off{0};
+	std::vector<uint8_t> seq, rseq;
+	std::vector<int> chunk_max_len;  /* longest read of each REF_CHUNK-sized piece */
+	int n() const { return (int)off.size() - 1; }
+};
+
+struct Source {                     /* bwa_read_seq (bwaseqio.c:172-252) minus the bwa_seq_t records */
+	Fastx fx;
+	int mode, trim_qual;
+	long n_trimmed = 0, n_tot = 0;
+
+	/* reads the next record that survives the filters; appends it to b unless b is null (skipping) */
+	bool one(Batch *b)
+	{
+		const int l_bc = (int)((unsigned)mode >> 24);
+		for (;;) {
+			if (fx.next() < 0) return false;
+			if ((mode & MODE_CFY) && !fx.comment.empty()) {             /* Casava filter flag: "...:Y..." */
+				const size_t p = fx.comment.find(':');
+				if (p != std::string::npos && p + 1 < fx.comment.size() && fx.comment[p + 1] == 'Y') continue;
+			}
+			if ((int)fx.seq.size() <= l_bc) continue;                    /* nothing left after the barcode (also: empty reads) */
+			break;
+		}
+		if (!b) return true;
+		const int full = (int)fx.seq.size() - l_bc;
+		const char *s = fx.seq.data() + l_bc;
+		int len = full;
+		if (!fx.qual.empty() && trim_qual >= 1) {                        /* bwa_trim_read, bwaseqio.c:110-123 */
+			const int shift = 33 + ((mode & MODE_IL13) ? 31 : 0);
+			const char *q = fx.qual.data() + l_bc;
+			int sum = 0, best = 0, best_l = full - 1;
+			for (int l = full - 1; l >= MIN_RDLEN - 1; --l) {
+				sum += trim_qual - ((int)(unsigned char)q[l] - shift);
+				if (sum < 0) break;
+				if (sum > best) { best = sum; best_l = l; }
+			}
+			len = best_l + 1;
+			n_trimmed += full - len;
+		}
+		n_tot += full;
+		if (len > 65535) { fprintf(stderr, "[nabwa_aln] read '%s' is longer than 65535 bases\n", fx.name.c_str()); exit(1); }
+		const bool comp = mode & NABWA_MODE_COMPREAD;
+		const size_t at = b->seq.size();
+		b->seq.resize(at + len); b->rseq.resize(at + len);
+		for (int i = 0; i < len; ++i) {                                  /* seq: the read reversed; rseq: its reverse complement */
+			const uint8_t c = nt4((unsigned char)s[len - 1 - i]);
+			b->seq[at + i] = c;
+			b->rseq[at + i] = comp && c < 4 ? 3 - c : c;
+		}
+		const int idx = b->n();
+		if (idx % REF_CHUNK == 0) b->chunk_max_len.push_back(0);
+		if (len > b->chunk_max_len.back()) b->chunk_max_len.back() = len;
+		b->off.push_back((int64_t)(at + len));
+		return true;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct Resume { int skip = 0; long at = 0; bool found = false; };
+
+/* attempt_recovery (bwtaln.c:259-296): count the complete records of an earlier, interrupted run */
+static Resume look_for_earlier_output(const char *fn, nabwa_gap_opt_t *opt)
+{
+	Resume r;
+	FILE *f = fopen(fn, "rb");
+	nabwa_gap_opt_t old;
+	if (f && fread(&old, 1, sizeof(old), f) == sizeof(old)) {
+		fprintf(stderr, "[nabwa_aln] %s exists, attempting recovery.\n", fn);
+		std::vector<nabwa_aln1_t> rows;
+		for (;;) {
+			int32_t n_aln;
+			r.at = ftell(f);
+			if (fread(&n_aln, 1, 4, f) < 4 || n_aln < 0) break;
+			rows.resize(n_aln ? n_aln : 1);
+			if (n_aln && fread(rows.data(), sizeof(nabwa_aln1_t), n_aln, f) < (size_t)n_aln) break;
+			++r.skip;
+		}
+		fprintf(stderr, "[nabwa_aln] %d records up to position %ld.\n", r.skip, r.at);
+		*opt = old;
+		r.found = true;
+	}
+	if (f) fclose(f);
+	return r;
+}
+
+static int usage(const nabwa_gap_opt_t *o)
+{
+	fprintf(stderr, "\nUsage:   nabwa_aln [options] <prefix> <in.fq>\n\n");
+	fprintf(stderr, "Options: -n NUM    max #diff (int) or missing prob under 0.02 err rate (float) [%.2f]\n", o->fnr);
+	fprintf(stderr, "         -o INT    maximum number of gap opens [%d]\n", o->max_gapo);
+	fprintf(stderr, "         -e INT    maximum number of gap extensions, -1 for disabling long gaps [-1]\n");
+	fprintf(stderr, "         -i INT    do not put an indel within INT bp towards the ends [%d]\n", o->indel_end_skip);
+	fprintf(stderr, "         -d INT    maximum occurrences for extending a long deletion [%d]\n", o->max_del_occ);
+	fprintf(stderr, "         -l INT    seed length [%d]\n", o->seed_len);
+	fprintf(stderr, "         -k INT    maximum differences in the seed [%d]\n", o->max_seed_diff);
+	fprintf(stderr, "         -m INT    maximum entries in the queue [%d]\n", o->max_entries);
+	fprintf(stderr, "         -t INT    recorded in the header, otherwise unused (as in the reference) [%d]\n", o->n_threads);
+	fprintf(stderr, "         -M INT    mismatch penalty [%d]\n", o->s_mm);
+	fprintf(stderr, "         -O INT    gap open penalty [%d]\n", o->s_gapo);
+	fprintf(stderr, "         -E INT    gap extension penalty [%d]\n", o->s_gape);
+	fprintf(stderr, "         -R INT    stop searching when there are >INT equally best hits [%d]\n", o->max_top2);
+	fprintf(stderr, "         -q INT    quality threshold for read trimming down to %dbp [%d]\n", MIN_RDLEN, o->trim_qual);
+	fprintf(stderr, "         -f FILE   file to write output to instead of stdout (resumes an interrupted run)\n");
+	fprintf(stderr, "         -B INT    length of barcode\n");
+	fprintf(stderr, "         -c        input sequences are in the color space\n");
+	fprintf(stderr, "         -L        log-scaled gap penalty for long deletions\n");
+	fprintf(stderr, "         -N        non-iterative mode: search for all n-difference hits\n");
+	fprintf(stderr, "         -I        the input is in the Illumina 1.3+ FASTQ-like format\n");
+	fprintf(stderr, "         -Y        filter Casava-filtered sequences\n");
+	fprintf(stderr, "         (-b -0 -1 -2: BAM input is not available in this tool)\n\n");
+	fprintf(stderr, "Environment: NABWA_DEVICE (GPU ordinal, 0), NABWA_ALN_BATCH (reads per GPU batch, 4194304)\n\n");
+	return 1;
+}
+
+int main(int argc, char *argv[])
+{
+	nabwa_gap_opt_t opt;
+	nabwa_gap_init_opt(&opt);
+	int c, opte = -1;
+	const char *ofile = nullptr;
+	Resume resume;
+	while ((c = getopt(argc, argv, "n:o:e:i:d:l:k:cLR:m:t:NM:O:E:q:f:b012IYB:")) >= 0) {
+		switch (c) {
+		case 'n':
+			if (strstr(optarg, ".")) { opt.fnr = (float)atof(optarg); opt.max_diff = -1; }
+			else { opt.max_diff = atoi(optarg); opt.fnr = -1.0f; }
+			break;
+		case 'o': opt.max_gapo = atoi(optarg); break;
+		case 'e': opte = atoi(optarg); break;
+		case 'M': opt.s_mm = atoi(optarg); break;
+		case 'O': opt.s_gapo = atoi(optarg); break;
+		case 'E': opt.s_gape = atoi(optarg); break;
+		case 'd': opt.max_del_occ = atoi(optarg); break;
+		case 'i': opt.indel_end_skip = atoi(optarg); break;
+		case 'l': opt.seed_len = atoi(optarg); break;
+		case 'k': opt.max_seed_diff = atoi(optarg); break;
+		case 'm': opt.max_entries = atoi(optarg); break;
+		case 't': opt.n_threads = atoi(optarg); break;
+		case 'L': opt.mode |= NABWA_MODE_LOGGAP; break;
+		case 'R': opt.max_top2 = atoi(optarg); break;
+		case 'q': opt.trim_qual = atoi(optarg); break;
+		case 'c': opt.mode &= ~NABWA_MODE_COMPREAD; break;
+		case 'N': opt.mode |= NABWA_MODE_NONSTOP; opt.max_top2 = 0x7fffffff; break;
+		case 'f': ofile = optarg; resume = look_for_earlier_output(optarg, &opt); break;   /* later options still apply, as in the reference */
+		case 'b': opt.mode |= 0x20; break;
+		case '0': opt.mode |= 0x40; break;
+		case '1': opt.mode |= 0x80; break;
+		case '2': opt.mode |= 0x100; break;
+		case 'I': opt.mode |= MODE_IL13; break;
+		case 'Y': opt.mode |= MODE_CFY; break;
+		case 'B': opt.mode |= atoi(optarg) << 24; break;
+		default: return 1;
+		}
+	}
+	if (opte > 0) { opt.max_gape = opte; opt.mode &= ~NABWA_MODE_GAPE; }
+	if (optind + 2 > argc) return usage(&opt);
+	if (opt.mode & MODE_BAM_ANY) { fprintf(stderr, "[nabwa_aln] BAM input (-b -0 -1 -2) is not available in this tool\n"); return 1; }
+	if ((int)((unsigned)opt.mode >> 24) > MAX_BCLEN) { fprintf(stderr, "[nabwa_aln] the maximum barcode length is %d.\n", MAX_BCLEN); return 1; }
+	if (opt.fnr > 0.0f)
+		for (int i = 17, k = 0; i <= 250; ++i) {
+			const int l = nabwa_cal_maxdiff(i, 0.02, opt.fnr);
+			if (l != k) fprintf(stderr, "[nabwa_aln] %dbp reads: max_diff = %d\n", i, l);
+			k = l;
+		}
+	const char *prefix = argv[optind], *reads = argv[optind + 1];
+
+	// ---- the index: no GPU, no output
+	nabwa_index_t *ix = nullptr;
+	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;
+	const std::string sa_path = std::string(prefix) + ".sa", rsa_path = std::string(prefix) + ".rsa";
+	const int with_sa = access(sa_path.c_str(), R_OK) == 0 && access(rsa_path.c_str(), R_OK) == 0;   /* optional: lets the library build its text-mode companions */
+	if (nabwa_index_load(prefix, device, with_sa, 0, &ix) != NABWA_OK) {
+		fprintf(stderr, "[nabwa_aln] cannot set up the index on GPU %d: %s\n", device, nabwa_last_error());
+		return 2;
+	}
+
+	FILE *out = stdout;
+	if (ofile) {
+		out = fopen(ofile, resume.found ? "rb+" : "wb");
+		if (!out) { fprintf(stderr, "[nabwa_aln] fail to open file '%s': ", ofile); perror(nullptr); return 2; }
+		if (resume.found && fseek(out, resume.at, SEEK_SET) != 0) { fprintf(stderr, "[nabwa_aln] seek failed, aborting.\n"); return 2; }
+	}
+	if (!resume.found && fwrite(&opt, sizeof(opt), 1, out) != 1) { perror("[nabwa_aln] write"); return 2; }
+
+	Source src;
+	src.mode = opt.mode; src.trim_qual = opt.trim_qual;
+	if (!src.fx.open(reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
+	if (resume.skip) {
+		fprintf(stderr, "[nabwa_aln] skipping %d sequences.\n", resume.skip);
+		for (int i = 0; i < resume.skip; ++i)
+			if (!src.one(nullptr)) { fprintf(stderr, "[nabwa_aln] EOF while skipping done work. Aborting.\n"); return 1; }
+	}
+
+	// ---- reader thread: parses and encodes the next batches while the GPU works on the current one
+	long batch_reads = getenv("NABWA_ALN_BATCH") ? atol(getenv("NABWA_ALN_BATCH")) : (4l << 20);
+	if (batch_reads < REF_CHUNK) batch_reads = REF_CHUNK;
+	batch_reads -= batch_reads % REF_CHUNK;                               /* batches end on the reference's chunk boundaries */
+	std::mutex mu; std::condition_variable cv;
+	std::deque<std::unique_ptr<Batch>> ready; bool done = false;
+	std::thread reader([&]() {
+		for (bool eof = false; !eof; ) {
+			std::unique_ptr<Batch> b(new Batch);
+			while (b->n() < batch_reads) {
+				if (!src.one(b.get())) { eof = true; break; }
+				if (b->seq.size() >= (1ull << 30) && b->n() % REF_CHUNK == 0) break;   /* long reads: bound the bases of a batch as well */
+			}
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return ready.size() < 2; });
+			if (b->n()) ready.push_back(std::move(b));
+			if (eof) done = true;
+			cv.notify_all();
+		}
+	});
+
+	long tot = 0; int status = 0;
+	std::vector<int32_t> n_aln, max_entries;
+	std::vector<nabwa_aln1_t> rows;
+	std::vector<char> obuf;
+	for (;;) {
+		std::unique_ptr<Batch> b;
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return !ready.empty() || done; });
+			if (ready.empty()) break;
+			b = std::move(ready.front()); ready.pop_front();
+			cv.notify_all();
+		}
+		if (status) continue;                                             /* drain the reader after a failure */
+		// runs of chunks with the same max_gapo clamp -> one GPU call each
+		const int n_chunks = (int)b->chunk_max_len.size();
+		auto clamp_of = [&](int ch) {
+			const int md = opt.fnr > 0.0f ? nabwa_cal_maxdiff(b->chunk_max_len[ch], 0.02, opt.fnr) : opt.max_diff;
+			return md < opt.max_gapo ? md : opt.max_gapo;
+		};
+		for (int c0 = 0; c0 < n_chunks && !status; ) {
+			int c1 = c0 + 1;
+			while (c1 < n_chunks && clamp_of(c1) == clamp_of(c0)) ++c1;
+			const int r0 = c0 * REF_CHUNK, r1 = c1 * REF_CHUNK < b->n() ? c1 * REF_CHUNK : b->n(), n = r1 - r0;
+			std::vector<int64_t> off(n + 1);
+			const int64_t base = b->off[r0];
+			for (int i = 0; i <= n; ++i) off[i] = b->off[r0 + i] - base;
+			n_aln.resize(n); max_entries.resize(n);
+			int64_t cap = (int64_t)n + n / 4 + 1024, n_rows = 0;
+			int rc;
+			for (;;) {
+				rows.resize(cap);
+				rc = nabwa_cal_sa_reg_gap(ix, &opt, n, off.data(), b->seq.data() + base, b->rseq.data() + base, 0,
+										  n_aln.data(), rows.data(), cap, &n_rows, max_entries.data());
+				if (rc != NABWA_ECAP) break;
+				cap = 0; for (int i = 0; i < n; ++i) cap += n_aln[i];
+			}
+			if (rc != NABWA_OK) { fprintf(stderr, "[nabwa_aln] GPU search failed: %s\n", nabwa_last_error()); status = 2; break; }
+			// the record stream: n_aln, then the rows (bwtaln.c:242-246)
+			obuf.resize((size_t)n * 4 + (size_t)n_rows * sizeof(nabwa_aln1_t));
+			char *w = obuf.data(); const nabwa_aln1_t *r = rows.data();
+			for (int i = 0; i < n; ++i) {
+				memcpy(w, &n_aln[i], 4); w += 4;
+				memcpy(w, r, (size_t)n_aln[i] * sizeof(nabwa_aln1_t)); w += (size_t)n_aln[i] * sizeof(nabwa_aln1_t); r += n_aln[i];
+			}
+			if (fwrite(obuf.data(), 1, obuf.size(), out) != obuf.size()) { perror("[nabwa_aln] write"); status = 2; break; }
+			tot += n;
+			fprintf(stderr, "[nabwa_aln] %ld sequences have been processed.\n", tot);
+			c0 = c1;
+		}
+	}
+	reader.join();
+	if (src.n_tot && opt.trim_qual >= 1) fprintf(stderr, "[nabwa_aln] %.1f%% bases are trimmed.\n", 100.0 * src.n_trimmed / src.n_tot);
+	src.fx.close();
+	nabwa_index_destroy(ix);
+	if (fflush(out) != 0) status = status ? status : 2;
+	if (out != stdout) fclose(out);
+	if (status) return status;
+	if (ofile) {                                                          /* final_rename (utils.c:159-173): "x.sai_" becomes "x.sai" once complete */
+		std::string nf(ofile);
+		size_t e = nf.size();
+		while (e > 0 && nf[e - 1] == '_') --e;
+		if (e > 0 && nf[e - 1] != '/' && e < nf.size()) {
+			nf.resize(e);
+			fprintf(stderr, "[nabwa_aln] finished, renaming %s to %s.\n", ofile, nf.c_str());
+			rename(ofile, nf.c_str());
+		}
+	}
+	fprintf(stderr, "[nabwa_aln] finished cleanly, shutting down.\n");
+	return 0;
+}

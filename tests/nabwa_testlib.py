@@ -76,6 +76,18 @@ def read_fastq(path):
     return out
 
 
+def read_fasta(path):
+    """[(name, sequence)] of a FASTA file"""
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                out.append([line[1:].split()[0], []])
+            elif out:
+                out[-1][1].append(line.strip())
+    return [(n, "".join(p)) for n, p in out]
+
+
 def trim_len(qual, trim_qual, min_len=35):
     """bwa_trim_read, reference bwaseqio.c:110-123."""
     L = len(qual)

@@ -60,6 +60,21 @@ def test_no_cpu_fallback_without_gpu():
     assert e.value.code == nabwa.ENODEV
 
 
+def test_aln_tool_is_built_and_has_no_cpu_path():
+    """nabwa_aln (the `bwa aln` command line) is built with the library; without a device it writes
+    nothing and says why."""
+    import subprocess
+    tool = os.path.join(T.ROOT, "network-aware-bwa_amd", "nabwa_aln")
+    if not os.path.exists(tool):
+        nabwa.build()
+    r = subprocess.run([tool], capture_output=True)
+    assert r.returncode == 1 and b"Usage:   nabwa_aln [options] <prefix> <in.fq>" in r.stderr
+    if nabwa.lib().nabwa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([tool, T.TOY, os.path.join(T.GOLDEN, "reads_se_head.fq")], capture_output=True)
+    assert r.returncode == 2 and r.stdout == b"" and b"cannot set up the index" in r.stderr
+
+
 def test_encode_read_matches_reference_encoding():
     """nabwa_encode_read == what bam1_to_seq / bwa_read_seq produce (checked against the test helper whose
     output reproduces the reference's .sai files bit for bit, incl. -q trimming and the reverse-flag undo)"""
