@@ -96,8 +96,12 @@ def main():
     # one end-to-end pass over host buffers (upload + both kernels + compacted download): the PCIe-inclusive rate
     ix.cal_sa_reg_gap_flat(opt, seq[:off[1000]], rseq[:off[1000]], off[:1001], per_read=True)   # (loads the kernels' code objects once)
     torch.cuda.synchronize()
-    t_pcie = time.time()
+    t_pcie_first = time.time()
     _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq, rseq, off, per_read=True)      # the C one-shot entry on host buffers
+    t_pcie_first = time.time() - t_pcie_first           # first call: the working buffers come from hipMalloc
+    del _na, _rows, _maxe
+    t_pcie = time.time()
+    _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq, rseq, off, per_read=True)      # what a streaming caller sees: buffers from the index's pool
     t_pcie = time.time() - t_pcie
     del _na, _rows, _maxe
     batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
@@ -185,7 +189,8 @@ def main():
                           "single_batch_ms": round(k_ms + w_ms, 3),
                           "second_pass_reads": n2, "hits": n_rows, "checksum": "%016x" % checksum,
                           "bit_exact_vs_cpu_sample": bit_exact,
-                          "pcie_inclusive_reads_per_s": round(args.reads / t_pcie, 1)},
+                          "pcie_inclusive_reads_per_s": round(args.reads / t_pcie, 1),
+                          "pcie_inclusive_first_call_reads_per_s": round(args.reads / t_pcie_first, 1)},
                "roofline": roofline, "cpu_baseline": cpu}
     for b in batches:
         b.close()

@@ -1053,58 +1053,93 @@ extern "C" int nabwa_search_occupancy(int wide, int ns)
 }
 
 // re-lay the reads out with every read starting on a 16-byte boundary (register windows load 16 bases), and form
-// the interval-table keys: the first T symbols the search consumes (positions len-1 down to len-T) of each strand
+// the interval-table keys: the first T symbols the search consumes (positions len-1 down to len-T) of each strand.
+// 16 lanes per read, one 16-base chunk of both strands per lane and turn: loads and stores of a read are consecutive
+// across its lanes (one thread per read walking bytes took 62 ms for 10 M reads; this form streams at HBM rate).
 __global__ __launch_bounds__(256) void pad_reads_kernel(int n, const uint8_t *__restrict__ seq, const uint8_t *__restrict__ rseq,
 													const int64_t *__restrict__ off, const int64_t *__restrict__ poff,
 													uint8_t *__restrict__ pseq, uint8_t *__restrict__ prseq, int32_t *__restrict__ rd_len,
-													uint32_t *__restrict__ rd_key, int T, int seed_len, uint32_t *__restrict__ rd_pack, int pack_stride)
+													uint32_t *__restrict__ rd_key, int T, int seed_len, uint32_t *__restrict__ rd_pack, int pack_stride,
+													const uint8_t *__restrict__ md_tab, const uint8_t *__restrict__ mg_tab,
+													uint8_t *__restrict__ rd_md, uint8_t *__restrict__ rd_mg)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
+	const int t = threadIdx.x & 15;
+	const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+	if (i >= n) return;                                          /* whole 16-lane groups leave together */
 	const int64_t o = off[i], p = poff[i];
-	const int L = (int)(off[i + 1] - o), PL = (int)(poff[i + 1] - p);
-	rd_len[i] = L;
-	for (int j = 0; j < PL; ++j) { pseq[p + j] = j < L ? seq[o + j] : 4; prseq[p + j] = j < L ? rseq[o + j] : 4; }
-	// keys (first consumed symbol = most significant digit): [0,1] kernel S, from position L-1 downwards, seq / rseq;
-	// [2,3] kernel W full passes, from position 0 upwards; [4,5] kernel W seed passes, from position L-seed_len upwards
-	uint32_t key[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
-	if (T > 0 && L > T) {
-		for (int v = 0; v < 3; ++v) {
-			if (v == 2 && !(L > seed_len && seed_len > T)) break;
-			uint32_t a = 0, b = 0; bool oka = true, okb = true;
-			for (int t = 1; t <= T; ++t) {
-				const int pos = v == 0 ? L - t : (v == 1 ? t - 1 : L - seed_len + t - 1);
-				const uint32_t x = seq[o + pos], y = rseq[o + pos];
-				oka = oka && x < 4u; okb = okb && y < 4u;
-				a = a << 2 | (x & 3u); b = b << 2 | (y & 3u);
+	const int L = (int)(off[i + 1] - o), NC = (int)(poff[i + 1] - p) >> 4;
+	if (t == 0) { rd_len[i] = L; rd_md[i] = md_tab[L]; rd_mg[i] = mg_tab[L]; }      /* max_diff / max_gapo of a read follow from its length (host tables) */
+	// both strands 2 bits per base as well, base j in word j>>4 from the TOP bits down, so that the 16 symbols from any position
+	// are one 32-bit extract in table-key order; the word after the last says whether the strand holds an N (then: no keys)
+	const int PW = pack_stride / 2;
+	uint32_t *const pk = rd_pack ? rd_pack + (size_t)i * pack_stride : 0;
+	const int n_turns = pk && PW - 1 > NC ? PW - 1 : NC;
+	uint32_t anyN[2] = { 0u, 0u };
+	for (int c = t; c < n_turns; c += 16) {
+		for (int st = 0; st < 2; ++st) {
+			const uint8_t *src = (st ? rseq : seq) + o + 16 * c;
+			uint32_t w[4] = { 0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u };
+			const int have = L - 16 * c;                          /* bases of this chunk that exist */
+			if (have >= 16) __builtin_memcpy(w, src, 16);
+			else {
+#pragma unroll
+				for (int k = 0; k < 16; ++k) if (k < have) { const uint32_t v = src[k]; w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | v << (8 * (k & 3)); }
 			}
-			if (oka) key[2 * v] = a;
-			if (okb) key[2 * v + 1] = b;
+			if (c < NC) *(uint4*)((st ? prseq : pseq) + p + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+			if (pk && c < PW - 1) {
+				uint32_t x = 0;
+#pragma unroll
+				for (int k = 0; k < 16; ++k) {
+					const uint32_t v = k < have ? (w[k >> 2] >> (8 * (k & 3)) & 0xffu) : 0u;
+					anyN[st] |= v > 3u ? 1u : 0u;
+					x |= (v & 3u) << (30 - 2 * k);
+				}
+				pk[st * PW + c] = x;
+			}
 		}
 	}
-	for (int v = 0; v < 6; ++v) rd_key[6 * (size_t)i + v] = key[v];
-	// both strands 2 bits per base, base j in word j>>4 from the TOP bits down, so that the 16 symbols from any position are
-	// one 32-bit extract in table-key order; the word after the last says whether the strand holds an N (then: no keys)
-	if (rd_pack) {
-		uint32_t *const pk = rd_pack + (size_t)i * pack_stride;
-		const int PW = pack_stride / 2;
-		for (int st = 0; st < 2; ++st) {
-			const uint8_t *src = (st ? rseq : seq) + o; uint32_t anyN = 0;
-			for (int w = 0; w < PW - 1; ++w) {
-				uint32_t x = 0;
-				for (int t = 0; t < 16; ++t) { const int j = w * 16 + t; const uint32_t c = j < L ? src[j] : 0u; anyN |= c > 3u ? 1u : 0u; x |= (c & 3u) << (30 - 2 * t); }
-				pk[st * PW + w] = x;
+	if (pk) {
+		for (int m = 8; m; m >>= 1) { anyN[0] |= __shfl_xor(anyN[0], m, 16); anyN[1] |= __shfl_xor(anyN[1], m, 16); }
+		if (t < 2) pk[t * PW + PW - 1] = anyN[t];
+	}
+	// keys (first consumed symbol = most significant digit): [0,1] kernel S, from position L-1 downwards, seq / rseq;
+	// [2,3] kernel W full passes, from position 0 upwards; [4,5] kernel W seed passes, from position L-seed_len upwards
+	if (t < 6) {
+		const int v = t >> 1;
+		uint32_t key = 0xffffffffu;
+		if (T > 0 && L > T && (v < 2 || (L > seed_len && seed_len > T))) {
+			const uint8_t *src = ((t & 1) ? rseq : seq) + o;
+			uint32_t a = 0; bool ok = true;
+			for (int q = 1; q <= T; ++q) {
+				const int pos = v == 0 ? L - q : (v == 1 ? q - 1 : L - seed_len + q - 1);
+				const uint32_t x = src[pos];
+				ok = ok && x < 4u; a = a << 2 | (x & 3u);
 			}
-			pk[st * PW + PW - 1] = anyN;
+			if (ok) key = a;
 		}
+		rd_key[6 * (size_t)i + t] = key;
 	}
 }
 
 extern "C" void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride, hipStream_t s)
+									   uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride,
+									   const uint8_t *md_tab, const uint8_t *mg_tab, uint8_t *rd_md, uint8_t *rd_mg, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T, seed_len, rd_pack, pack_stride);
+	hipLaunchKernelGGL(pad_reads_kernel, dim3((n + 15) / 16), dim3(256), 0, s, n, seq, rseq, off, poff, pseq, prseq, rd_len, rd_key, T, seed_len, rd_pack, pack_stride,
+					   md_tab, mg_tab, rd_md, rd_mg);
+}
+
+// padded length of every read (starts go on 16-byte boundaries), and 0 after the last: input of the scan that gives the starts
+__global__ __launch_bounds__(256) void padded_len_kernel(int n, const int64_t *__restrict__ off, int64_t *__restrict__ plen)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i <= n) plen[i] = i < n ? (off[i + 1] - off[i] + 15) / 16 * 16 : 0;
+}
+
+extern "C" void nabwa_launch_padded_len(int n, const int64_t *off, int64_t *plen, hipStream_t s)
+{
+	hipLaunchKernelGGL(padded_len_kernel, dim3(n / 256 + 1), dim3(256), 0, s, n, off, plen);
 }
 
 // ids of the reads whose first pass was abandoned (arena or hit list outgrown)

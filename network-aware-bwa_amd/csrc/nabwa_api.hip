@@ -7,7 +7,10 @@
 #include <string.h>
 #include <math.h>
 #include <chrono>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 #include "../../include/nabwa.h"
 #include "fm_search.hpp"
@@ -35,8 +38,10 @@ void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, c
 						 uint4 *out, hipStream_t s);
 int nabwa_search_occupancy(int wide, int ns);
 void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s);
+void nabwa_launch_padded_len(int n, const int64_t *off, int64_t *plen, hipStream_t s);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
-							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride, hipStream_t s);
+							uint8_t *pseq, uint8_t *prseq, int32_t *rd_len, uint32_t *rd_key, int T, int seed_len, uint32_t *rd_pack, int pack_stride,
+							const uint8_t *md_tab, const uint8_t *mg_tab, uint8_t *rd_md, uint8_t *rd_mg, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -173,6 +178,124 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 	return NABWA_OK;
 }
 
+static int env_int(const char *name, int dflt)
+{
+	const char *s = getenv(name);
+	return s && *s ? atoi(s) : dflt;
+}
+
+/* Working buffers come from a per-index pool: a streaming caller makes one batch after the other, of about the same
+ * size, and hipMalloc of the search arena (tens of GB) costs 0.5 - 1 s each time -- more than the search itself.
+ * A released buffer is kept (up to NABWA_POOL_GB, default 48) and handed to the next request it fits within 25 %;
+ * everything cached goes back to the driver when an allocation fails and when the index is destroyed. */
+struct nabwa_dev_pool {
+	std::mutex mu;
+	struct Blk { void *p; size_t bytes; };
+	std::vector<Blk> idle;                         /* oldest first */
+	std::unordered_map<void*, size_t> live;
+	size_t idle_bytes = 0, limit = 0;
+	/* staged uploads (pageable caller memory -> pinned slots -> HBM), set up by the first large upload */
+	enum { UP_THREADS = 4, UP_SLOT = 32 << 20 };
+	uint8_t *pin = 0; hipStream_t up_stream[UP_THREADS] = {}; hipEvent_t up_ev[UP_THREADS][2] = {};
+};
+
+/* hipMemcpy from pageable memory runs at ~15 GB/s here (one staging thread inside the runtime); four host threads
+ * copying into their own pinned slots while the previous slot is in flight reach the link rate.  Jobs: {dst, src, bytes}. */
+struct UploadJob { void *dst; const void *src; size_t bytes; };
+static hipError_t staged_upload(nabwa_index *ix, const UploadJob *jobs, int n_jobs)
+{
+	nabwa_dev_pool *pl = ix->pool;
+	size_t total = 0;
+	for (int j = 0; j < n_jobs; ++j) total += jobs[j].bytes;
+	const int T = nabwa_dev_pool::UP_THREADS; const size_t SLOT = nabwa_dev_pool::UP_SLOT;
+	if (total < ((size_t)env_int("NABWA_STAGED_MIN_MB", 256) << 20) || total == 0) {       /* small: not worth four threads */
+		for (int j = 0; j < n_jobs; ++j)
+			if (jobs[j].bytes) { hipError_t e = hipMemcpy(jobs[j].dst, jobs[j].src, jobs[j].bytes, hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
+		return hipSuccess;
+	}
+	std::lock_guard<std::mutex> lk(pl->mu);                  /* one staged upload at a time per index */
+	if (!pl->pin) {
+		hipError_t e = hipHostMalloc((void**)&pl->pin, (size_t)T * 2 * SLOT, hipHostMallocDefault);
+		if (e != hipSuccess) { pl->pin = 0; return e; }
+		for (int t = 0; t < T; ++t) {
+			if ((e = hipStreamCreateWithFlags(&pl->up_stream[t], hipStreamNonBlocking)) != hipSuccess) return e;
+			for (int k = 0; k < 2; ++k) if ((e = hipEventCreateWithFlags(&pl->up_ev[t][k], hipEventDisableTiming)) != hipSuccess) return e;
+		}
+	}
+	struct Piece { uint8_t *dst; const uint8_t *src; size_t bytes; };
+	std::vector<Piece> pieces;
+	for (int j = 0; j < n_jobs; ++j)
+		for (size_t o = 0; o < jobs[j].bytes; o += SLOT)
+			pieces.push_back({ (uint8_t*)jobs[j].dst + o, (const uint8_t*)jobs[j].src + o, jobs[j].bytes - o < SLOT ? jobs[j].bytes - o : SLOT });
+	hipError_t err[T];
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; ++t) {
+		err[t] = hipSuccess;
+		th.emplace_back([&, t]() {
+			hipError_t e = hipSetDevice(ix->device);
+			int used = 0;
+			for (size_t i = t; i < pieces.size() && e == hipSuccess; i += T, ++used) {
+				const int k = used & 1;
+				uint8_t *slot = pl->pin + ((size_t)t * 2 + k) * SLOT;
+				if (used >= 2) e = hipEventSynchronize(pl->up_ev[t][k]);       /* the copy that last used this slot is done */
+				if (e != hipSuccess) break;
+				memcpy(slot, pieces[i].src, pieces[i].bytes);
+				e = hipMemcpyAsync(pieces[i].dst, slot, pieces[i].bytes, hipMemcpyHostToDevice, pl->up_stream[t]);
+				if (e == hipSuccess) e = hipEventRecord(pl->up_ev[t][k], pl->up_stream[t]);
+			}
+			const hipError_t e2 = hipStreamSynchronize(pl->up_stream[t]);
+			err[t] = e != hipSuccess ? e : e2;
+		});
+	}
+	for (auto &x : th) x.join();
+	for (int t = 0; t < T; ++t) if (err[t] != hipSuccess) return err[t];
+	return hipSuccess;
+}
+
+static void pool_flush(nabwa_dev_pool *pl)         /* caller holds the lock */
+{
+	for (auto &k : pl->idle) (void)hipFree(k.p);
+	pl->idle.clear(); pl->idle_bytes = 0;
+}
+
+static hipError_t pool_malloc(nabwa_index *ix, void **out, size_t bytes)
+{
+	nabwa_dev_pool *pl = ix->pool;
+	if (bytes == 0) bytes = 1;
+	const size_t gran = bytes >= (8u << 20) ? (2u << 20) : 256;
+	const size_t need = (bytes + gran - 1) / gran * gran;
+	std::lock_guard<std::mutex> lk(pl->mu);
+	size_t best = pl->idle.size();
+	for (size_t i = 0; i < pl->idle.size(); ++i)
+		if (pl->idle[i].bytes >= need && pl->idle[i].bytes <= need + need / 4 + 4096 && (best == pl->idle.size() || pl->idle[i].bytes < pl->idle[best].bytes)) best = i;
+	if (best != pl->idle.size()) {
+		*out = pl->idle[best].p; pl->live[*out] = pl->idle[best].bytes; pl->idle_bytes -= pl->idle[best].bytes;
+		pl->idle.erase(pl->idle.begin() + best);
+		return hipSuccess;
+	}
+	hipError_t e = hipMalloc(out, need);
+	if (e != hipSuccess && !pl->idle.empty()) { (void)hipGetLastError(); pool_flush(pl); e = hipMalloc(out, need); }
+	if (e == hipSuccess) pl->live[*out] = need;
+	return e;
+}
+
+static hipError_t pool_free(nabwa_index *ix, void *p)
+{
+	if (!p) return hipSuccess;
+	nabwa_dev_pool *pl = ix->pool;
+	std::lock_guard<std::mutex> lk(pl->mu);
+	auto it = pl->live.find(p);
+	if (it == pl->live.end()) return hipFree(p);
+	const size_t bytes = it->second;
+	pl->live.erase(it);
+	if (bytes > pl->limit) return hipFree(p);
+	pl->idle.push_back({ p, bytes }); pl->idle_bytes += bytes;
+	while (pl->idle_bytes > pl->limit) {            /* the oldest go first */
+		(void)hipFree(pl->idle.front().p); pl->idle_bytes -= pl->idle.front().bytes; pl->idle.erase(pl->idle.begin());
+	}
+	return hipSuccess;
+}
+
 extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t *bwt0, uint64_t nw0,
 									   const uint32_t *bwt1, uint64_t nw1, const uint32_t *sa0, uint64_t ns0,
 									   const uint32_t *sa1, uint64_t ns1, nabwa_index_t **out)
@@ -181,6 +304,8 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	if (nabwa_device_count() <= device) return fail(NABWA_ENODEV, "no such HIP device");
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
+	ix->pool = new nabwa_dev_pool();
+	ix->pool->limit = (size_t)env_int("NABWA_POOL_GB", 48) << 30;
 	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; ix->kmer_top[0] = ix->kmer_top[1] = 0; for (int t = 0; t < 2; ++t) ix->sa_full[t] = ix->isa[t] = ix->text[t] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);
@@ -227,6 +352,15 @@ extern "C" void nabwa_index_destroy(nabwa_index_t *ix)
 	(void)hipSetDevice(ix->device);
 	for (int t = 0; t < 2; ++t) { if (ix->bk[t]) (void)hipFree(ix->bk[t]); if (ix->sa[t]) (void)hipFree(ix->sa[t]); if (ix->kmer[t]) (void)hipFree(ix->kmer[t]); if (ix->kmer_top[t]) (void)hipFree(ix->kmer_top[t]);
 		if (ix->sa_full[t]) (void)hipFree(ix->sa_full[t]); if (ix->isa[t]) (void)hipFree(ix->isa[t]); if (ix->text[t]) (void)hipFree(ix->text[t]); }
+	if (ix->pool) {
+		{ std::lock_guard<std::mutex> lk(ix->pool->mu); pool_flush(ix->pool); }
+		if (ix->pool->pin) (void)hipHostFree(ix->pool->pin);
+		for (int t = 0; t < nabwa_dev_pool::UP_THREADS; ++t) {
+			if (ix->pool->up_stream[t]) (void)hipStreamDestroy(ix->pool->up_stream[t]);
+			for (int k = 0; k < 2; ++k) if (ix->pool->up_ev[t][k]) (void)hipEventDestroy(ix->pool->up_ev[t][k]);
+		}
+		delete ix->pool;
+	}
 	delete ix->ref;
 	delete ix;
 }
@@ -285,12 +419,6 @@ struct nabwa_batch {
 	unsigned long long *d_sum;
 };
 
-static int env_int(const char *name, int dflt)
-{
-	const char *s = getenv(name);
-	return s && *s ? atoi(s) : dflt;
-}
-
 static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int seed_len, uint32_t NS)
@@ -318,7 +446,8 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 	void *ptrs[] = { b->d_pack, b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
 					 b->d_status2, b->d_aln2, b->d_sum };
-	for (void *p : ptrs) if (p) (void)hipFree(p);
+	if (b->stream) (void)hipStreamSynchronize(b->stream);      /* the buffers go back to the pool, not to the driver: nothing may still use them */
+	for (void *p : ptrs) if (p) (void)pool_free(b->ix, p);
 	if (b->ev0) (void)hipEventDestroy(b->ev0);
 	if (b->ev1) (void)hipEventDestroy(b->ev1);
 	if (b->evw) (void)hipEventDestroy(b->evw);
@@ -339,24 +468,54 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tc0 = now();
 	// ---- per-read option derivation, on the host in double (bwtaln.c:102-106,125)
-	int max_len = 0;
-	for (int i = 0; i < n; ++i) {
-		const int64_t L = off[i + 1] - off[i];
-		if (L < 0 || L > 65535) return fail(NABWA_EINVAL, "read length outside 0..65535");
-		if (L > max_len) max_len = (int)L;
+	// One threaded pass over the read boundaries: validity, the lengths that occur, the padded size.  Everything per read
+	// that follows from its length alone (max_diff, max_gapo) is a table over lengths, applied on the device.
+	int max_len = 0, min_len = 65535; int64_t padded_total = 0; bool bad_len = false;
+	std::vector<uint8_t> seen(65536, 0);
+	{
+		const int NT = n >= (1 << 20) ? 4 : 1;
+		struct Part { int mx = 0, mn = 65535; int64_t padded = 0; bool bad = false; std::vector<uint8_t> seen; };
+		std::vector<Part> part(NT);
+		std::vector<std::thread> th;
+		for (int t = 0; t < NT; ++t) {
+			part[t].seen.assign(65536, 0);
+			auto work = [&, t]() {
+				Part &q = part[t];
+				const int64_t i0 = (int64_t)n * t / NT, i1 = (int64_t)n * (t + 1) / NT;
+				for (int64_t i = i0; i < i1; ++i) {
+					const int64_t L = off[i + 1] - off[i];
+					if (L < 0 || L > 65535) { q.bad = true; continue; }
+					q.seen[L] = 1; q.padded += (L + 15) / 16 * 16;
+					if (L > q.mx) q.mx = (int)L;
+					if (L < q.mn) q.mn = (int)L;
+				}
+			};
+			if (NT == 1) work(); else th.emplace_back(work);
+		}
+		for (auto &x : th) x.join();
+		for (auto &q : part) {
+			bad_len |= q.bad; padded_total += q.padded;
+			if (q.mx > max_len) max_len = q.mx;
+			if (q.mn < min_len) min_len = q.mn;
+			for (int L = 0; L < 65536; ++L) seen[L] |= q.seen[L];
+		}
 	}
+	if (bad_len) return fail(NABWA_EINVAL, "read length outside 0..65535");
 	std::vector<int> md_of(max_len + 1, opt->max_diff);
 	if (opt->fnr > 0.0f) for (int L = 0; L <= max_len; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
-	std::vector<uint8_t> md(n ? n : 1), mg(n ? n : 1);
+	std::vector<uint8_t> md_tab(max_len + 1, 0), mg_tab(max_len + 1, 0);     /* by read length: what the search of such a read runs with */
 	uint32_t NS = 1;
-	for (int i = 0; i < n; ++i) {
-		const int L = (int)(off[i + 1] - off[i]);
+	int mdx = 0, mgx = 0;
+	for (int L = 0; L <= max_len; ++L) {
+		if (!seen[L]) continue;
 		const int md_sizing = md_of[per_read ? L : max_len];
 		int g = opt->max_gapo; if (md_sizing < g) g = md_sizing;
 		const int d = md_of[L];
 		/* first-pass arena entries keep n_mm / n_gapo in 4 bits and n_gape in 5 (fm_search.hip) */
 		if (d < 0 || d > 14 || g < 0 || g > 15) return fail(NABWA_EINVAL, "max_diff > 14 or max_gapo > 15 (unsupported)");
-		md[i] = (uint8_t)d; mg[i] = (uint8_t)g;
+		md_tab[L] = (uint8_t)d; mg_tab[L] = (uint8_t)g;
+		if (d > mdx) mdx = d;
+		if (g > mgx) mgx = g;
 		const long ns = (long)(md_sizing + 1) * opt->s_mm + (long)(g + 1) * opt->s_gapo + (long)(opt->max_gape + 1) * opt->s_gape;
 		if (ns > (long)NS) NS = (uint32_t)ns;
 	}
@@ -366,8 +525,6 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	 * is the reference's initial best_score, a value that is compared, never an index; the second pass still sizes by it.) */
 	uint32_t NS1 = 1;
 	{
-		int mdx = 0, mgx = 0;
-		for (int i = 0; i < n; ++i) { if (md[i] > mdx) mdx = md[i]; if (mg[i] > mgx) mgx = mg[i]; }
 		const bool gape_counts = opt->mode & NABWA_MODE_GAPE;
 		for (int a = 0; a <= mdx + 1; ++a)
 			for (int g = 0; g <= mgx; ++g)
@@ -391,31 +548,40 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	BCHK(hipEventCreate(&b->ev1));
 	BCHK(hipEventCreate(&b->evw));
 	// reads: upload as given, then re-lay out on the device with 16-byte aligned starts
-	std::vector<int64_t> poff(n + 1);
-	poff[0] = 0;
-	for (int i = 0; i < n; ++i) poff[i + 1] = poff[i] + ((off[i + 1] - off[i] + 15) / 16) * 16;
-	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1, pnb = (size_t)poff[n] + 64;
+	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1, pnb = (size_t)padded_total + 64;
 	if ((uint64_t)pnb >= (1ull << 32)) { nabwa_batch_destroy(b); return fail(NABWA_EINVAL, "batch holds 4 Gi padded bases or more: split it (lane state keeps a 32-bit read offset)"); }
 	b->max_len = max_len;
-	BCHK(hipMalloc(&b->d_seq, pnb)); BCHK(hipMalloc(&b->d_rseq, pnb));
-	BCHK(hipMalloc(&b->d_poff, (size_t)(n + 1) * 8)); BCHK(hipMalloc(&b->d_len, (size_t)(n ? n : 1) * 4));
-	BCHK(hipMalloc(&b->d_md, n ? n : 1)); BCHK(hipMalloc(&b->d_mg, n ? n : 1)); BCHK(hipMalloc(&b->d_key, (size_t)(n ? n : 1) * 24));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_seq, pnb)); BCHK(pool_malloc(b->ix, (void**)&b->d_rseq, pnb));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_poff, (size_t)(n + 1) * 8)); BCHK(pool_malloc(b->ix, (void**)&b->d_len, (size_t)(n ? n : 1) * 4));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_md, n ? n : 1)); BCHK(pool_malloc(b->ix, (void**)&b->d_mg, n ? n : 1)); BCHK(pool_malloc(b->ix, (void**)&b->d_key, (size_t)(n ? n : 1) * 24));
 	b->pack_stride = 2 * ((max_len + 15) / 16 + 2);
-	BCHK(hipMalloc(&b->d_pack, (size_t)(n ? n : 1) * b->pack_stride * 4));
-	BCHK(hipMalloc(&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(hipMalloc(&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(hipMalloc(&b->d_ncls, 64));
-	BCHK(hipMemcpy(b->d_poff, poff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_pack, (size_t)(n ? n : 1) * b->pack_stride * 4));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_cls, (size_t)(n ? n : 1) * 2)); BCHK(pool_malloc(b->ix, (void**)&b->d_perm, (size_t)(n ? n : 1) * 4)); BCHK(pool_malloc(b->ix, (void**)&b->d_ncls, 64));
+	if (n == 0) BCHK(hipMemset(b->d_poff, 0, 8));
 	if (n) {
 		uint8_t *raw_s = 0, *raw_r = 0; int64_t *raw_off = 0;
-		BCHK(hipMalloc(&raw_s, nb)); BCHK(hipMalloc(&raw_r, nb)); BCHK(hipMalloc(&raw_off, (size_t)(n + 1) * 8));
-		BCHK(hipMemcpy(raw_s, seq, (size_t)off[n], hipMemcpyHostToDevice));
-		BCHK(hipMemcpy(raw_r, rseq, (size_t)off[n], hipMemcpyHostToDevice));
-		BCHK(hipMemcpy(raw_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+		BCHK(pool_malloc(b->ix, (void**)&raw_s, nb)); BCHK(pool_malloc(b->ix, (void**)&raw_r, nb)); BCHK(pool_malloc(b->ix, (void**)&raw_off, (size_t)(n + 1) * 8));
+		const UploadJob jobs[3] = { { raw_s, seq, (size_t)off[n] }, { raw_r, rseq, (size_t)off[n] }, { raw_off, off, (size_t)(n + 1) * 8 } };
+		const double tu0 = now();
+		BCHK(staged_upload(ix, jobs, 3));
+		if (timing) fprintf(stderr, "[nabwa] upload of %.2f GB: %.3f s (%.3f s into batch_create)\n", 2e-9 * (double)off[n], now() - tu0, tu0 - tc0);
+		// padded starts: exclusive scan of the padded lengths, on the device
+		int64_t *plen = 0; void *d_tmp = 0; size_t tmp_bytes = 0; uint8_t *d_tab = 0;
+		BCHK(pool_malloc(b->ix, (void**)&plen, (size_t)(n + 1) * 8));
+		nabwa_launch_padded_len(n, raw_off, plen, b->stream);
+		BCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, plen, b->d_poff, n + 1, b->stream));
+		BCHK(pool_malloc(b->ix, &d_tmp, tmp_bytes ? tmp_bytes : 16));
+		BCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, plen, b->d_poff, n + 1, b->stream));
+		BCHK(pool_malloc(b->ix, (void**)&d_tab, 2 * (size_t)(max_len + 1)));
+		BCHK(hipMemcpyAsync(d_tab, md_tab.data(), max_len + 1, hipMemcpyHostToDevice, b->stream));
+		BCHK(hipMemcpyAsync(d_tab + max_len + 1, mg_tab.data(), max_len + 1, hipMemcpyHostToDevice, b->stream));
 		nabwa_launch_pad_reads(n, raw_s, raw_r, raw_off, b->d_poff, b->d_seq, b->d_rseq, b->d_len, b->d_key,
-							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, opt->seed_len, b->d_pack, b->pack_stride, b->stream);
+							   ix->bwt[0].kmer_T == ix->bwt[1].kmer_T ? (int)ix->bwt[0].kmer_T : 0, opt->seed_len, b->d_pack, b->pack_stride,
+							   d_tab, d_tab + max_len + 1, b->d_md, b->d_mg, b->stream);
 		BCHK(hipStreamSynchronize(b->stream));
-		BCHK(hipFree(raw_s)); BCHK(hipFree(raw_r)); BCHK(hipFree(raw_off));
-		BCHK(hipMemcpy(b->d_md, md.data(), n, hipMemcpyHostToDevice));
-		BCHK(hipMemcpy(b->d_mg, mg.data(), n, hipMemcpyHostToDevice));
+		if (timing) fprintf(stderr, "[nabwa] re-layout kernel done %.3f s into batch_create\n", now() - tc0);
+		BCHK(pool_free(b->ix, raw_s)); BCHK(pool_free(b->ix, raw_r)); BCHK(pool_free(b->ix, raw_off));
+		BCHK(pool_free(b->ix, plen)); BCHK(pool_free(b->ix, d_tmp)); BCHK(pool_free(b->ix, d_tab));
 	}
 
 	const double tc2 = now();
@@ -438,8 +604,6 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
 	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
 	{
-		int min_len = max_len;
-		for (int i = 0; i < n; ++i) { const int L = (int)(off[i + 1] - off[i]); if (L < min_len) min_len = L; }
 		P.w_sync = (n > 0 && min_len == max_len) ? env_int("NABWA_W_SYNC", 1) : 0;
 	}
 	if (P.aln_cap < 1) P.aln_cap = 1;
@@ -457,20 +621,20 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	b->n_blocks = (int)blocks;
 	if (getenv("NABWA_TIMING")) fprintf(stderr, "[nabwa] search kernel: %u score levels, %d blocks per CU (LDS %zu B per block), %ld blocks\n", NS1, occ,
 										(size_t)NS1 * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 80, blocks);
-	BCHK(hipMalloc(&b->d_scratch, (size_t)blocks * NABWA_SEARCH_BLOCK * P.lane_stride));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_scratch, (size_t)blocks * NABWA_SEARCH_BLOCK * P.lane_stride));
 	int occw = nabwa_width_occupancy(); if (occw < 1) occw = 1;
 	long blocks_w = (long)prop.multiProcessorCount * occw;
 	if (blocks_w > 2 * need) blocks_w = 2 * need;        /* kernel W: one lane per strand of a read */
 	if (blocks_w < 1) blocks_w = 1;
 	b->n_blocks_w = (int)blocks_w;
-	BCHK(hipMalloc(&b->d_wdata, (size_t)(n ? n : 1) * P.wstride));
-	BCHK(hipMalloc(&b->d_nN, n ? n : 1));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_wdata, (size_t)(n ? n : 1) * P.wstride));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_nN, n ? n : 1));
 	P.wdata = b->d_wdata; P.rd_nN = b->d_nN;
 	const size_t n1 = n ? n : 1;
-	BCHK(hipMalloc(&b->d_naln, n1 * 4)); BCHK(hipMalloc(&b->d_maxent, n1 * 4)); BCHK(hipMalloc(&b->d_wide_idx, n1 * 4));
-	BCHK(hipMalloc(&b->d_status, n1)); BCHK(hipMalloc(&b->d_aln, n1 * (size_t)P.aln_cap * 16));
-	BCHK(hipMalloc(&b->d_counter, 16)); BCHK(hipMalloc(&b->d_novf, 4)); BCHK(hipMalloc(&b->d_ovf_ids, n1 * 4));
-	BCHK(hipMalloc(&b->d_sum, 256));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_naln, n1 * 4)); BCHK(pool_malloc(b->ix, (void**)&b->d_maxent, n1 * 4)); BCHK(pool_malloc(b->ix, (void**)&b->d_wide_idx, n1 * 4));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_status, n1)); BCHK(pool_malloc(b->ix, (void**)&b->d_aln, n1 * (size_t)P.aln_cap * 16));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_counter, 16)); BCHK(pool_malloc(b->ix, (void**)&b->d_novf, 4)); BCHK(pool_malloc(b->ix, (void**)&b->d_ovf_ids, n1 * 4));
+	BCHK(pool_malloc(b->ix, (void**)&b->d_sum, 256));
 	P.scratch = b->d_scratch; P.n_aln = b->d_naln; P.max_ent = b->d_maxent; P.status = b->d_status; P.aln = b->d_aln;
 	P.work_counter = b->d_counter;
 	*out = b;
@@ -523,11 +687,11 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	// max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140)
 	if (b->n2 < (int)novf) {
 		void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
-		for (void *p : old) if (p) (void)hipFree(p);
+		for (void *p : old) if (p) (void)pool_free(b->ix, p);
 		b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
 		b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
-		HIPCHK(hipMalloc(&b->d_naln2, (size_t)novf * 4)); HIPCHK(hipMalloc(&b->d_maxent2, (size_t)novf * 4));
-		HIPCHK(hipMalloc(&b->d_status2, novf)); HIPCHK(hipMalloc(&b->d_aln2, (size_t)novf * b->aln_cap2 * 16));
+		HIPCHK(pool_malloc(b->ix, (void**)&b->d_naln2, (size_t)novf * 4)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_maxent2, (size_t)novf * 4));
+		HIPCHK(pool_malloc(b->ix, (void**)&b->d_status2, novf)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_aln2, (size_t)novf * b->aln_cap2 * 16));
 		b->n2 = (int)novf;
 	}
 	SearchParams Q = b->P;
@@ -537,7 +701,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	const long max_blocks2 = env_int("NABWA_WIDE_BLOCKS", 2);
 	if (blocks2 > max_blocks2) blocks2 = max_blocks2;
 	const size_t need = (size_t)blocks2 * NABWA_SEARCH_BLOCK * Q.lane_stride;
-	if (!b->d_scratch2) HIPCHK(hipMalloc(&b->d_scratch2, need));   // size only depends on the option block
+	if (!b->d_scratch2) HIPCHK(pool_malloc(b->ix, (void**)&b->d_scratch2, need));   // size only depends on the option block
 	Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)novf;
 	Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2;
 	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
@@ -627,9 +791,9 @@ extern "C" int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t 
 	if (b->n == 0) return NABWA_OK;
 	// device-side compaction: exclusive scan of n_aln, then gather rows
 	uint32_t *d_off = 0; void *d_tmp = 0; size_t tmp_bytes = 0; uint4 *d_rows = 0;
-	HIPCHK(hipMalloc(&d_off, (size_t)(b->n + 1) * 4));
+	HIPCHK(pool_malloc(b->ix, (void**)&d_off, (size_t)(b->n + 1) * 4));
 	HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (const uint32_t*)b->d_naln, d_off, b->n, b->stream));
-	HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+	HIPCHK(pool_malloc(b->ix, (void**)&d_tmp, tmp_bytes ? tmp_bytes : 16));
 	HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (const uint32_t*)b->d_naln, d_off, b->n, b->stream));
 	uint32_t last_off = 0; int32_t last_n = 0;
 	HIPCHK(hipMemcpyAsync(&last_off, d_off + (b->n - 1), 4, hipMemcpyDeviceToHost, b->stream));
@@ -642,14 +806,14 @@ extern "C" int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t 
 	int rc = NABWA_OK;
 	if (total > aln_cap || (total && !aln_out)) rc = fail(NABWA_ECAP, "aln_cap too small");
 	else if (total) {
-		HIPCHK(hipMalloc(&d_rows, (size_t)total * 16));
+		HIPCHK(pool_malloc(b->ix, (void**)&d_rows, (size_t)total * 16));
 		nabwa_launch_gather(b->n, b->d_naln, d_off, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2,
 							d_rows, b->stream);
 		HIPCHK(hipMemcpyAsync(aln_out, d_rows, (size_t)total * 16, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));
-		HIPCHK(hipFree(d_rows));
+		HIPCHK(pool_free(b->ix, d_rows));
 	}
-	HIPCHK(hipFree(d_off)); HIPCHK(hipFree(d_tmp));
+	HIPCHK(pool_free(b->ix, d_off)); HIPCHK(pool_free(b->ix, d_tmp));
 	return rc;
 }
 

@@ -24,6 +24,7 @@ struct nabwa_index {
 	uint2 *kmer[2], *kmer_top[2];  // interval table: levels 1..LW back to back; level T on its own when T > LW (else inside the former)
 	uint64_t bytes;
 	nabwa_reference *ref;
+	struct nabwa_dev_pool *pool;   // released working buffers of earlier batches, kept for the next one (nabwa_api.hip)
 };
 
 int nabwa_fail(int code, const char *fmt, const char *a = "");

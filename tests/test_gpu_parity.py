@@ -347,6 +347,40 @@ def test_one_shot_entry_flat(gix, olib, oix, per_read):
     assert np.array_equal(maxe, wmax)
 
 
+def test_staged_upload_and_pooled_buffers_on_a_large_batch(gix, olib, oix, monkeypatch):
+    """Host buffers of >= 256 MiB go up through four threads and pinned slots (nabwa_api.hip: staged_upload), and the
+    working buffers of a call are handed to the next one (pool).  2.2 M reads x 100 bases x {seq, rseq} = 440 MB: every
+    thread re-uses its slots.  Same answer as the plain hipMemcpy path on fresh buffers, and as the oracle on a sample."""
+    rng = np.random.default_rng(99)
+    code = np.full(256, 4, np.uint8)
+    for i, ch in enumerate("ACGT"):
+        code[ord(ch)] = i
+    g = code[np.frombuffer(toy_genome().upper().encode(), np.uint8)]
+    n, L = 2_200_000, 100
+    pos = rng.integers(0, len(g) - L, n)
+    reads = g[pos[:, None] + np.arange(L)[None, :]]
+    mut = rng.random(reads.shape) < 0.004
+    reads[mut] = rng.integers(0, 4, int(mut.sum())).astype(np.uint8)
+    flip = rng.random(n) < 0.5                                   # half of them from the other strand
+    reads[flip] = np.where(reads[flip] < 4, 3 - reads[flip], 4)[:, ::-1]
+    seq = np.ascontiguousarray(reads[:, ::-1]).reshape(-1)
+    rseq = np.where(seq < 4, 3 - seq, seq).astype(np.uint8)
+    off = (np.arange(n + 1, dtype=np.int64) * L)
+    opt = to_gap_opt(T.default_opt())
+    monkeypatch.setenv("NABWA_STAGED_MIN_MB", "1000000")         # plain hipMemcpy
+    a = gix.cal_sa_reg_gap_flat(opt, seq, rseq, off, per_read=True)
+    monkeypatch.setenv("NABWA_STAGED_MIN_MB", "0")               # staged, into the buffers the first call released
+    b = gix.cal_sa_reg_gap_flat(opt, seq, rseq, off, per_read=True)
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    m = 3000
+    want, wmax = T.oracle_cal_sa_reg_gap(olib, oix.h, T.default_opt(), seq[:m * L], rseq[:m * L], off[:m + 1], per_read=1, n_threads=8)
+    n_aln, rows, maxe = b
+    assert (n_aln[:m] == np.array([len(w) for w in want])).all()
+    assert rows[:int(n_aln[:m].sum())].tobytes() == np.concatenate([np.asarray(w, nabwa.ALN_DT) for w in want]).tobytes()
+    assert np.array_equal(maxe[:m], wmax)
+
+
 @pytest.mark.parametrize("env", [
     {"NABWA_TEXT_MODE": "0"},                                   # no full SA / inverse / text: every interval stays in row form
     {"NABWA_KMER_T": "0"},                                      # no interval table: every tail is walked
