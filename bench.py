@@ -207,7 +207,7 @@ def pmc_traffic():
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc.sh; both are 64-byte fabric requests
     for this kernel's 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when the
     file is missing -- counters cannot be collected from inside the timed run."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v8_pmc.json")
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v9_pmc.json")
     try:
         d = json.load(open(f))["S"]
         return round((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, 0)
