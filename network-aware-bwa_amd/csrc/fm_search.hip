@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				const unsigned int idx = base + rank;
 				if (idx < (unsigned int)P.n) {
 					const uint32_t rid = P.ids ? (uint32_t)P.ids[idx] : idx;
-					item = WIDE ? idx : rid;                             // results: by list position (second pass) / by read (first pass)
+					item = WIDE ? (P.res_slot ? (uint32_t)P.res_slot[rid] : idx) : rid;   // results: by slot (wide passes) / by read (first pass)
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o; rid_w = rid;
@@ -569,6 +569,10 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 							const uint4 r = s_pf[threadIdx.x];
 							take_entry(r, 0u, ent_slot);
 							pf_slot = NIL;
+							if (!finish) have = true;
+						} else if (WIDE && P.wide_inline) {                   // a wide pass is a few lanes walking dependent trips: waiting for the
+							const uint4 r = ent[ent_slot];                     // entry here costs the others little and saves this lane a whole trip
+							take_entry(r, lnk[ent_slot], ent_slot);
 							if (!finish) have = true;
 						} else want_ent = true;
 					}
@@ -1161,13 +1165,26 @@ extern "C" void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids,
 __global__ __launch_bounds__(256) void scatter_wide_kernel(int n2, const int32_t *__restrict__ ids, const int32_t *__restrict__ n_aln2,
 													   const int32_t *__restrict__ max_ent2, const uint8_t *__restrict__ status2,
 													   int32_t *__restrict__ n_aln, int32_t *__restrict__ max_ent,
-													   uint8_t *__restrict__ status, int32_t *__restrict__ wide_idx)
+													   uint8_t *__restrict__ status, const int32_t *__restrict__ wide_idx)
+{
+	const int q = blockIdx.x * 256 + threadIdx.x;
+	if (q >= n2) return;
+	const int rid = ids[q], j = wide_idx[rid];       /* j: the read's row in the wide result arrays (assign_slots_kernel) */
+	if (status2[j] == NABWA_ST_OK) { n_aln[rid] = n_aln2[j]; max_ent[rid] = max_ent2[j]; status[rid] = NABWA_ST_WIDE; }
+	else { n_aln[rid] = 0; max_ent[rid] = max_ent2[j]; status[rid] = NABWA_ST_OVERFLOW; }
+}
+
+// the reads that go to the wide passes get a row each in the wide result arrays; it stays theirs over the tiers
+__global__ __launch_bounds__(256) void assign_slots_kernel(int n2, const int32_t *__restrict__ ids, int32_t *__restrict__ wide_idx)
 {
 	const int j = blockIdx.x * 256 + threadIdx.x;
-	if (j >= n2) return;
-	const int rid = ids[j];
-	if (status2[j] == NABWA_ST_OK) { n_aln[rid] = n_aln2[j]; max_ent[rid] = max_ent2[j]; wide_idx[rid] = j; status[rid] = NABWA_ST_WIDE; }
-	else { n_aln[rid] = 0; max_ent[rid] = max_ent2[j]; status[rid] = NABWA_ST_OVERFLOW; }
+	if (j < n2) wide_idx[ids[j]] = j;
+}
+
+extern "C" void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s)
+{
+	if (n2 <= 0) return;
+	hipLaunchKernelGGL(assign_slots_kernel, dim3((n2 + 255) / 256), dim3(256), 0, s, n2, ids, wide_idx);
 }
 
 extern "C" void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,

@@ -15,6 +15,8 @@ struct SearchParams {
 	const int32_t *rd_len;
 	const uint8_t *rd_maxdiff, *rd_maxgapo;   // per read: max_diff and clamped max_gapo (host-side FP, bwtaln.c:104-105,125)
 	const int32_t *ids;                       // work item -> read id (wide pass), or null
+	int wide_inline;                          // wide passes: pop and classify in one trip (NABWA_WIDE_INLINE, default 1)
+	const int32_t *res_slot;                  // wide passes: read id -> row of the wide result arrays (stable over the tiers), or null = list position
 	int n;
 	// gap_opt_t fields that are uniform over the batch
 	int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries, max_gape, max_seed_diff, seed_len, max_top2;

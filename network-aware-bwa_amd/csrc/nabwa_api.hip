@@ -30,6 +30,7 @@ void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int al
 						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
 void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, hipStream_t s);
+void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s);
 void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
 							   const uint8_t *status2, int32_t *n_aln, int32_t *max_ent, uint8_t *status,
 							   int32_t *wide_idx, hipStream_t s);
@@ -414,7 +415,7 @@ struct nabwa_batch {
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
 	unsigned int *d_counter, *d_novf; int32_t *d_ovf_ids;
 	// wide pass (allocated on demand)
-	int n2, aln_cap2; uint8_t *d_scratch2; int32_t *d_naln2, *d_maxent2; uint8_t *d_status2; uint4 *d_aln2;
+	int n2, aln_cap2; uint8_t *d_scratch2; size_t scratch2_bytes; int32_t *d_naln2, *d_maxent2; uint8_t *d_status2; uint4 *d_aln2;
 	int unresolved;
 	unsigned long long *d_sum;
 };
@@ -683,46 +684,91 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	HIPCHK(hipEventElapsedTime(&b->last_ms_w, b->evw, b->ev0));
 	if (n_second_pass) *n_second_pass = (int)novf;
 	if (novf == 0) return NABWA_OK;
-	// ---- wide pass: the flagged reads again, from scratch, with slot reuse and an arena that holds
-	// max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140)
-	if (b->n2 < (int)novf) {
-		void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
-		for (void *p : old) if (p) (void)pool_free(b->ix, p);
-		b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
-		b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
-		HIPCHK(pool_malloc(b->ix, (void**)&b->d_naln2, (size_t)novf * 4)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_maxent2, (size_t)novf * 4));
-		HIPCHK(pool_malloc(b->ix, (void**)&b->d_status2, novf)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_aln2, (size_t)novf * b->aln_cap2 * 16));
-		b->n2 = (int)novf;
+	// ---- the flagged reads again, from scratch, in tiers of growing arenas and shrinking lane counts (all tiers share one
+	// scratch allocation of NABWA_WIDE_GB; a tier gets as many lanes as arenas of its size fit into it):
+	//   A  the first-pass kernel once more with the largest arena its 16-bit links address (65534 pushes);
+	//   B  the WIDE kernel (slot reuse, 32-bit links, results in the wide arrays) with 2^19 live entries;
+	//   C  the WIDE kernel with max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140).
+	// With default options almost nothing gets here.  With the options ancient-DNA pipelines use (-n 0.01 -o 2 -l 16500, the
+	// seed off) a third of the reads outgrow the first pass and a few per cent hold > 65536 live entries.
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const uint64_t cap_full = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
+	size_t budget = (size_t)env_int("NABWA_WIDE_GB", 64) << 30;
+	{
+		size_t fr = 0, tot = 0;
+		HIPCHK(hipMemGetInfo(&fr, &tot));
+		size_t avail = fr + b->scratch2_bytes;
+		{ std::lock_guard<std::mutex> lk(b->ix->pool->mu); avail += b->ix->pool->idle_bytes; }
+		avail = avail > ((size_t)4 << 30) ? avail - ((size_t)4 << 30) : 0;
+		if (budget > avail) budget = avail;
 	}
-	SearchParams Q = b->P;
-	uint64_t cap2 = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
-	layout(Q, (uint32_t)cap2, true, b->max_len, b->opt.seed_len, b->NS_wide);
-	long blocks2 = ((long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
-	const long max_blocks2 = env_int("NABWA_WIDE_BLOCKS", 2);
-	if (blocks2 > max_blocks2) blocks2 = max_blocks2;
-	const size_t need = (size_t)blocks2 * NABWA_SEARCH_BLOCK * Q.lane_stride;
-	if (!b->d_scratch2) HIPCHK(pool_malloc(b->ix, (void**)&b->d_scratch2, need));   // size only depends on the option block
-	Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)novf;
-	Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2;
-	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-	{	// the first pass edited these reads' width records in place (gap_shadow): rebuild them
-		SearchParams QW = Q; QW.touch_counter = 0;
-		long bw2 = (2 * (long)novf + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
-		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
-		nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
+	struct Tier { uint64_t cap; bool wide; };
+	std::vector<Tier> tiers;
+	if (env_int("NABWA_TIER_A", 1) && b->P.NS <= 64 && b->P.cap < 65534) tiers.push_back({ 65534, false });
+	const uint64_t cap_b = (uint64_t)env_int("NABWA_TIER_B_CAP", 1 << 19);          /* (tests shrink it to reach tier C) */
+	if (env_int("NABWA_TIER_B", 1) && cap_full > cap_b && cap_b >= 16) tiers.push_back({ cap_b, true });
+	tiers.push_back({ cap_full, true });
+	unsigned int cur = novf;
+	bool slots = false;
+	for (size_t ti = 0; ti < tiers.size() && cur; ++ti) {
+		const Tier T = tiers[ti];
+		const double tt0 = now();
+		SearchParams Q = b->P;
+		layout(Q, (uint32_t)T.cap, T.wide, b->max_len, b->opt.seed_len, T.wide ? b->NS_wide : b->P.NS);
+		long blocks = ((long)cur + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
+		long fit = (long)(budget / ((size_t)NABWA_SEARCH_BLOCK * Q.lane_stride));
+		if (T.wide && ti + 1 == tiers.size() && getenv("NABWA_WIDE_BLOCKS")) fit = env_int("NABWA_WIDE_BLOCKS", 2);
+		if (fit < 1) fit = 1;
+		if (blocks > fit) blocks = fit;
+		if (blocks > 4096) blocks = 4096;
+		const size_t need = (size_t)blocks * NABWA_SEARCH_BLOCK * Q.lane_stride;
+		if (b->scratch2_bytes < need) {
+			if (b->d_scratch2) { HIPCHK(pool_free(b->ix, b->d_scratch2)); b->d_scratch2 = 0; b->scratch2_bytes = 0; }
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_scratch2, need));
+			b->scratch2_bytes = need;
+		}
+		if (T.wide && !slots) {       /* rows of the wide result arrays for the reads that are left now */
+			if (b->n2 < (int)cur) {
+				void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
+				for (void *p : old) if (p) (void)pool_free(b->ix, p);
+				b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
+				b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
+				HIPCHK(pool_malloc(b->ix, (void**)&b->d_naln2, (size_t)cur * 4)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_maxent2, (size_t)cur * 4));
+				HIPCHK(pool_malloc(b->ix, (void**)&b->d_status2, cur)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_aln2, (size_t)cur * b->aln_cap2 * 16));
+				b->n2 = (int)cur;
+			}
+			nabwa_launch_assign_slots((int)cur, b->d_ovf_ids, b->d_wide_idx, b->stream);
+			slots = true;
+		}
+		Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)cur; Q.n_sync = 0; Q.w_sync = 0;
+		Q.wide_inline = env_int("NABWA_WIDE_INLINE", 1);
+		if (T.wide) { Q.res_slot = b->d_wide_idx; Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2; }
+		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
+		{	// the pass before edited these reads' width records in place (gap_shadow): rebuild them
+			SearchParams QW = Q; QW.touch_counter = 0; QW.rd_cls = 0;
+			QW.n_aln = b->d_naln; QW.max_ent = b->d_maxent; QW.status = b->d_status; QW.aln = b->d_aln; QW.aln_cap = b->P.aln_cap;
+			long bw2 = (2 * (long)cur + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
+			if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
+			nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
+		}
+		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
+		nabwa_launch_fm_search(&Q, (int)blocks, T.wide ? 1 : 0, b->stream);
+		if (T.wide) nabwa_launch_scatter_wide((int)cur, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
+											  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
+		HIPCHK(hipGetLastError());
+		// what is still flagged goes on to the next tier; after the last one it is reported (hit list > NABWA_ALNCAP2), never dropped
+		HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
+		nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
+		unsigned int left = 0;
+		HIPCHK(hipMemcpyAsync(&left, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		if (timing) fprintf(stderr, "[nabwa] tier %s, arena of %llu entries: %u reads on %ld blocks, %u left, %.3f s\n",
+							T.wide ? "wide" : "first-pass kernel", (unsigned long long)T.cap, cur, blocks, left, now() - tt0);
+		cur = left;
 	}
-	nabwa_launch_fm_search(&Q, (int)blocks2, 1, b->stream);
-	nabwa_launch_scatter_wide((int)novf, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
-							  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
-	HIPCHK(hipGetLastError());
-	// any read that outgrew even the wide pass (hit list > NABWA_ALNCAP2) is reported, never dropped
-	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
-	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
-	unsigned int left = 0;
-	HIPCHK(hipMemcpyAsync(&left, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
-	HIPCHK(hipStreamSynchronize(b->stream));
-	b->unresolved = (int)left;
-	if (left) return fail(NABWA_ECAP, "reads with more hits than NABWA_ALNCAP2 rows");
+	b->unresolved = (int)cur;
+	if (cur) return fail(NABWA_ECAP, "reads with more hits than NABWA_ALNCAP2 rows");
 	return NABWA_OK;
 }
 

@@ -187,6 +187,29 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     b.close()
 
 
+@pytest.mark.parametrize("env", [
+    {"NABWA_CAP1": "48"},                                                    # tier A (first-pass kernel, 65534-entry arena) takes them all
+    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0"},                               # straight to the slot-reusing kernel
+    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0", "NABWA_TIER_B_CAP": "64"},     # tier B too small for some: they reach the full-size tier C
+    {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1", "NABWA_TIER_B_CAP": "40"},    # A fails on the hit lists, B on the arena, C finishes
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_tiers_of_the_flagged_reads_are_bit_exact(gix, monkeypatch, env):
+    """reads that outgrow the first pass are re-run in tiers of growing arenas (nabwa_api.hip: nabwa_batch_sync); whichever
+    tier finishes a read, the rows are the reference's -- on the option set ancient-DNA pipelines use (deep searches)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_adna.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    n2 = b.sync()
+    got, _ = b.fetch()
+    b.close()
+    assert n2 > 100
+    assert all(got[i].tobytes() == gold[i].tobytes() for i in range(len(reads)))
+
+
 def test_rerun_is_idempotent(gix):
     opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
     reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
