@@ -687,7 +687,8 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	// ---- the flagged reads again, from scratch, in tiers of growing arenas and shrinking lane counts (all tiers share one
 	// scratch allocation of NABWA_WIDE_GB; a tier gets as many lanes as arenas of its size fit into it):
 	//   A  the first-pass kernel once more with the largest arena its 16-bit links address (65534 pushes);
-	//   B  the WIDE kernel (slot reuse, 32-bit links, results in the wide arrays) with 2^19 live entries;
+	//   B  the WIDE kernel (slot reuse, 32-bit links, results in the wide arrays) with 2^17, then 2^19 live entries
+	//      (each only while more reads are left than the last tier has lanes for);
 	//   C  the WIDE kernel with max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140).
 	// With default options almost nothing gets here.  With the options ancient-DNA pipelines use (-n 0.01 -o 2 -l 16500, the
 	// seed off) a third of the reads outgrow the first pass and a few per cent hold > 65536 live entries.
@@ -706,13 +707,26 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	struct Tier { uint64_t cap; bool wide; };
 	std::vector<Tier> tiers;
 	if (env_int("NABWA_TIER_A", 1) && b->P.NS <= 64 && b->P.cap < 65534) tiers.push_back({ 65534, false });
-	const uint64_t cap_b = (uint64_t)env_int("NABWA_TIER_B_CAP", 1 << 19);          /* (tests shrink it to reach tier C) */
+	const uint64_t cap_b = (uint64_t)env_int("NABWA_TIER_B_CAP", 1 << 17);          /* (tests shrink it to reach tier C) */
 	if (env_int("NABWA_TIER_B", 1) && cap_full > cap_b && cap_b >= 16) tiers.push_back({ cap_b, true });
+	if (env_int("NABWA_TIER_B", 1) && cap_full > (1u << 19) && cap_b < (1u << 19)) tiers.push_back({ 1u << 19, true });
 	tiers.push_back({ cap_full, true });
+	/* an intermediate wide tier is skipped when the full-size tier has lanes for what is left (two reads per lane): the
+	 * largest searches are dependent chains of tens of seconds, and the sooner they start in the arena that can hold them
+	 * the sooner the launch ends; the intermediate tiers only exist to keep that last tier from becoming work-bound */
+	long lanes_full = 0;
+	{
+		SearchParams QL = b->P;
+		layout(QL, (uint32_t)cap_full, true, b->max_len, b->opt.seed_len, b->NS_wide);
+		lanes_full = (long)(budget / QL.lane_stride) / NABWA_SEARCH_BLOCK * NABWA_SEARCH_BLOCK;
+		if (lanes_full < NABWA_SEARCH_BLOCK) lanes_full = NABWA_SEARCH_BLOCK;
+	}
+	const bool may_skip = env_int("NABWA_TIER_SKIP", 1) != 0;
 	unsigned int cur = novf;
 	bool slots = false;
 	for (size_t ti = 0; ti < tiers.size() && cur; ++ti) {
 		const Tier T = tiers[ti];
+		if (T.wide && ti + 1 < tiers.size() && may_skip && (long)cur <= 2 * lanes_full) continue;
 		const double tt0 = now();
 		SearchParams Q = b->P;
 		layout(Q, (uint32_t)T.cap, T.wide, b->max_len, b->opt.seed_len, T.wide ? b->NS_wide : b->P.NS);

@@ -190,8 +190,8 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
 @pytest.mark.parametrize("env", [
     {"NABWA_CAP1": "48"},                                                    # tier A (first-pass kernel, 65534-entry arena) takes them all
     {"NABWA_CAP1": "48", "NABWA_TIER_A": "0"},                               # straight to the slot-reusing kernel
-    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0", "NABWA_TIER_B_CAP": "64"},     # tier B too small for some: they reach the full-size tier C
-    {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1", "NABWA_TIER_B_CAP": "40"},    # A fails on the hit lists, B on the arena, C finishes
+    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0", "NABWA_TIER_B_CAP": "64", "NABWA_TIER_SKIP": "0"},     # tier B too small for some: they go on to the larger tiers
+    {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1", "NABWA_TIER_B_CAP": "40", "NABWA_TIER_SKIP": "0"},    # A fails on the hit lists, B on the arena, the next ones finish
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_tiers_of_the_flagged_reads_are_bit_exact(gix, monkeypatch, env):
     """reads that outgrow the first pass are re-run in tiers of growing arenas (nabwa_api.hip: nabwa_batch_sync); whichever
