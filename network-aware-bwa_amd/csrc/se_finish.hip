@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
@@ -322,6 +323,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 	/* ---- phase 1, host, record order: hit choice with the caller's RNG stream (bwase.c:19-95) */
 	std::vector<uint8_t> which; std::vector<uint32_t> rows;           /* SA lookups: [main of each mapped read][multi...] */
 	std::vector<int> look_rec, look_multi;
+	which.reserve((size_t)n + n / 4); rows.reserve((size_t)n + n / 4); look_rec.reserve((size_t)n + n / 4); look_multi.reserve((size_t)n + n / 4);
 	size_t a0 = 0;
 	for (int i = 0; i < n; ++i) {
 		nabwa_se_t &s = out[i];
@@ -348,19 +350,36 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data());
 		if (r != NABWA_OK) return r;
 	}
-	for (size_t t = 0; t < rows.size(); ++t) {                                   /* bwase.c:146-151, bam2bam.c:635-636 */
-		nabwa_se_t &s = out[look_rec[t]];
-		const uint32_t p = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
-		if (look_multi[t] < 0) s.pos = p; else s.multi[look_multi[t]].pos = p;
-	}
-	/* bwa_approx_mapQ (bwase.c:113-122) */
-	for (int i = 0; i < n; ++i) {
-		nabwa_se_t &s = out[i];
-		if (s.type == 0) continue;
-		const int md = opt->fnr > 0.0f ? nabwa_cal_maxdiff(s.len, 0.02, opt->fnr) : opt->max_diff;
-		const int q = approx_mapq(s, md);
-		s.mapQ = s.seQ = q;
-	}
+	int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+	if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
+	if (n < 4096) nt = 1;
+	auto in_threads = [&](size_t count, const std::function<void(size_t, size_t)> &f) {
+		if (nt == 1) { f(0, count); return; }
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back(f, count * t / nt, count * (t + 1) / nt);
+		for (auto &x : th) x.join();
+	};
+	/* positions (bwase.c:146-151, bam2bam.c:635-636): every looked-up row belongs to one record field, so slices are independent */
+	in_threads(rows.size(), [&](size_t lo, size_t hi) {
+		for (size_t t = lo; t < hi; ++t) {
+			nabwa_se_t &s = out[look_rec[t]];
+			const uint32_t p = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
+			if (look_multi[t] < 0) s.pos = p; else s.multi[look_multi[t]].pos = p;
+		}
+	});
+	/* bwa_approx_mapQ (bwase.c:113-122); max_diff of a read follows from its length: one table instead of a Poisson sum per read */
+	int longest = 0;
+	for (int i = 0; i < n; ++i) if (out[i].len > longest) longest = out[i].len;
+	std::vector<int> md_of(longest + 1, opt->max_diff);
+	if (opt->fnr > 0.0f) for (int L = 0; L <= longest; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
+	in_threads((size_t)n, [&](size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			nabwa_se_t &s = out[i];
+			if (s.type == 0) continue;
+			const int q = approx_mapq(s, md_of[s.len]);
+			s.mapQ = s.seQ = q;
+		}
+	});
 
 	t2 = now();
 	/* ---- phase 3, GPU: gap refinement of every gapped hit as one batch of global alignments (bwase.c:189-237) */
@@ -390,14 +409,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 			s.xt = s.nn > 10 ? 'N' : "NURM"[s.type];
 		}
 	};
-	{
-		int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
-		if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
-		if (n < 4096) nt = 1;
-		std::vector<std::thread> th;
-		for (int t = 0; t < nt; ++t) th.emplace_back(phase4, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
-		for (auto &x : th) x.join();
-	}
+	in_threads((size_t)n, [&](size_t lo, size_t hi) { phase4((int)lo, (int)hi); });
 	if (timing) fprintf(stderr, "[nabwa] se_finish %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) %.3f s, refinement (%zu jobs) %.3f s, md/flags %.3f s\n",
 						n, t1 - t0, rows.size(), t2 - t1, n_jobs, t3 - t2, now() - t3);
 	return NABWA_OK;
