@@ -34,6 +34,14 @@ GOLDEN_RUNS = {
 }
 
 
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(TOOL):          # the tool is built with the library (csrc/Makefile: all)
+        import importlib
+        importlib.import_module("network-aware-bwa_amd").build()
+    assert os.path.exists(TOOL)
+
+
 def run_tool(args, env=None):
     e = dict(os.environ)
     e.update(env or {})
