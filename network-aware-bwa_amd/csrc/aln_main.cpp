@@ -190,30 +190,50 @@ static Resume look_for_earlier_output(const char *fn, nabwa_gap_opt_t *opt)
 	return r;
 }
 
+// The command line of `bwa aln` (bwtaln.c:303-340) as one table: option letter -> what it sets.  The getopt string, the
+// parser and the usage text are all generated from it.
+struct Opt {
+	char letter;
+	int nabwa_gap_opt_t::*field;       // integer option: the member it sets ...
+	int set_bits, clear_bits;          // ... or flag: mode bits it sets / clears
+	const char *arg, *help;
+};
+static const Opt OPTS[] = {
+	{ 'n', nullptr, 0, 0, "NUM", "differences allowed: a count, or (with a '.') the fraction of reads that may be missed at 2% base error" },
+	{ 'o', &nabwa_gap_opt_t::max_gapo, 0, 0, "INT", "gap opens allowed" },
+	{ 'e', nullptr, 0, 0, "INT", "gap extensions allowed; -1: long gaps off, extensions count as differences" },
+	{ 'i', &nabwa_gap_opt_t::indel_end_skip, 0, 0, "INT", "no indel within INT bases of the read ends" },
+	{ 'd', &nabwa_gap_opt_t::max_del_occ, 0, 0, "INT", "a long deletion is only extended while the interval holds at most INT rows" },
+	{ 'l', &nabwa_gap_opt_t::seed_len, 0, 0, "INT", "seed length" },
+	{ 'k', &nabwa_gap_opt_t::max_seed_diff, 0, 0, "INT", "differences allowed in the seed" },
+	{ 'm', &nabwa_gap_opt_t::max_entries, 0, 0, "INT", "a search is cut off beyond INT queued entries" },
+	{ 't', &nabwa_gap_opt_t::n_threads, 0, 0, "INT", "written to the header; no other effect (as in the reference)" },
+	{ 'M', &nabwa_gap_opt_t::s_mm, 0, 0, "INT", "mismatch penalty" },
+	{ 'O', &nabwa_gap_opt_t::s_gapo, 0, 0, "INT", "gap open penalty" },
+	{ 'E', &nabwa_gap_opt_t::s_gape, 0, 0, "INT", "gap extension penalty" },
+	{ 'R', &nabwa_gap_opt_t::max_top2, 0, 0, "INT", "go on to sub-optimal hits only while there are at most INT best ones" },
+	{ 'q', &nabwa_gap_opt_t::trim_qual, 0, 0, "INT", "trim the 3' end by quality INT (never below 35 bases)" },
+	{ 'f', nullptr, 0, 0, "FILE", "write here instead of stdout; continues an interrupted FILE, renames 'x_' to 'x' when done" },
+	{ 'B', nullptr, 0, 0, "INT", "the first INT bases are a barcode" },
+	{ 'c', nullptr, 0, NABWA_MODE_COMPREAD, nullptr, "colour-space reads: reverse, do not complement" },
+	{ 'L', nullptr, NABWA_MODE_LOGGAP, 0, nullptr, "log-scaled penalty for long deletions" },
+	{ 'N', nullptr, NABWA_MODE_NONSTOP, 0, nullptr, "do not stop at the best score: every hit within the allowed differences" },
+	{ 'I', nullptr, MODE_IL13, 0, nullptr, "qualities are Illumina 1.3+ (offset 64)" },
+	{ 'Y', nullptr, MODE_CFY, 0, nullptr, "drop reads whose Casava comment says 'filtered'" },
+	{ 'b', nullptr, 0x20, 0, nullptr, nullptr }, { '0', nullptr, 0x40, 0, nullptr, nullptr },      /* BAM input: accepted by the parser, refused below */
+	{ '1', nullptr, 0x80, 0, nullptr, nullptr }, { '2', nullptr, 0x100, 0, nullptr, nullptr },
+};
+
 static int usage(const nabwa_gap_opt_t *o)
 {
-	fprintf(stderr, "\nUsage:   nabwa_aln [options] <prefix> <in.fq>\n\n");
-	fprintf(stderr, "Options: -n NUM    max #diff (int) or missing prob under 0.02 err rate (float) [%.2f]\n", o->fnr);
-	fprintf(stderr, "         -o INT    maximum number of gap opens [%d]\n", o->max_gapo);
-	fprintf(stderr, "         -e INT    maximum number of gap extensions, -1 for disabling long gaps [-1]\n");
-	fprintf(stderr, "         -i INT    do not put an indel within INT bp towards the ends [%d]\n", o->indel_end_skip);
-	fprintf(stderr, "         -d INT    maximum occurrences for extending a long deletion [%d]\n", o->max_del_occ);
-	fprintf(stderr, "         -l INT    seed length [%d]\n", o->seed_len);
-	fprintf(stderr, "         -k INT    maximum differences in the seed [%d]\n", o->max_seed_diff);
-	fprintf(stderr, "         -m INT    maximum entries in the queue [%d]\n", o->max_entries);
-	fprintf(stderr, "         -t INT    recorded in the header, otherwise unused (as in the reference) [%d]\n", o->n_threads);
-	fprintf(stderr, "         -M INT    mismatch penalty [%d]\n", o->s_mm);
-	fprintf(stderr, "         -O INT    gap open penalty [%d]\n", o->s_gapo);
-	fprintf(stderr, "         -E INT    gap extension penalty [%d]\n", o->s_gape);
-	fprintf(stderr, "         -R INT    stop searching when there are >INT equally best hits [%d]\n", o->max_top2);
-	fprintf(stderr, "         -q INT    quality threshold for read trimming down to %dbp [%d]\n", MIN_RDLEN, o->trim_qual);
-	fprintf(stderr, "         -f FILE   file to write output to instead of stdout (resumes an interrupted run)\n");
-	fprintf(stderr, "         -B INT    length of barcode\n");
-	fprintf(stderr, "         -c        input sequences are in the color space\n");
-	fprintf(stderr, "         -L        log-scaled gap penalty for long deletions\n");
-	fprintf(stderr, "         -N        non-iterative mode: search for all n-difference hits\n");
-	fprintf(stderr, "         -I        the input is in the Illumina 1.3+ FASTQ-like format\n");
-	fprintf(stderr, "         -Y        filter Casava-filtered sequences\n");
+	fprintf(stderr, "\nUsage:   nabwa_aln [options] <prefix> <in.fq>   >   out.sai\n\n");
+	for (const Opt &d : OPTS) {
+		if (!d.help) continue;
+		char dflt[32] = "";
+		if (d.field) snprintf(dflt, sizeof dflt, " [%d]", o->*d.field);
+		else if (d.letter == 'n') snprintf(dflt, sizeof dflt, " [%.2f]", o->fnr);
+		fprintf(stderr, "         -%c %-5s %s%s\n", d.letter, d.arg ? d.arg : "", d.help, dflt);
+	}
 	fprintf(stderr, "         (-b -0 -1 -2: BAM input is not available in this tool)\n\n");
 	fprintf(stderr, "Environment: NABWA_DEVICE (GPU ordinal, 0), NABWA_ALN_BATCH (reads per GPU batch, 4194304)\n\n");
 	return 1;
@@ -226,37 +246,24 @@ int main(int argc, char *argv[])
 	int c, opte = -1;
 	const char *ofile = nullptr;
 	Resume resume;
-	while ((c = getopt(argc, argv, "n:o:e:i:d:l:k:cLR:m:t:NM:O:E:q:f:b012IYB:")) >= 0) {
-		switch (c) {
-		case 'n':
-			if (strstr(optarg, ".")) { opt.fnr = (float)atof(optarg); opt.max_diff = -1; }
+	std::string letters;
+	for (const Opt &d : OPTS) { letters += d.letter; if (d.arg) letters += ':'; }
+	while ((c = getopt(argc, argv, letters.c_str())) >= 0) {
+		const Opt *d = nullptr;
+		for (const Opt &x : OPTS) if (x.letter == c) d = &x;
+		if (!d) return 1;
+		if (d->field) { opt.*(d->field) = atoi(optarg); continue; }
+		opt.mode = (opt.mode | d->set_bits) & ~d->clear_bits;
+		switch (c) {           /* the four that are more than a field or a flag */
+		case 'n':              /* "0.04" is a miss rate, "4" a count */
+			if (strchr(optarg, '.')) { opt.fnr = (float)atof(optarg); opt.max_diff = -1; }
 			else { opt.max_diff = atoi(optarg); opt.fnr = -1.0f; }
 			break;
-		case 'o': opt.max_gapo = atoi(optarg); break;
 		case 'e': opte = atoi(optarg); break;
-		case 'M': opt.s_mm = atoi(optarg); break;
-		case 'O': opt.s_gapo = atoi(optarg); break;
-		case 'E': opt.s_gape = atoi(optarg); break;
-		case 'd': opt.max_del_occ = atoi(optarg); break;
-		case 'i': opt.indel_end_skip = atoi(optarg); break;
-		case 'l': opt.seed_len = atoi(optarg); break;
-		case 'k': opt.max_seed_diff = atoi(optarg); break;
-		case 'm': opt.max_entries = atoi(optarg); break;
-		case 't': opt.n_threads = atoi(optarg); break;
-		case 'L': opt.mode |= NABWA_MODE_LOGGAP; break;
-		case 'R': opt.max_top2 = atoi(optarg); break;
-		case 'q': opt.trim_qual = atoi(optarg); break;
-		case 'c': opt.mode &= ~NABWA_MODE_COMPREAD; break;
-		case 'N': opt.mode |= NABWA_MODE_NONSTOP; opt.max_top2 = 0x7fffffff; break;
-		case 'f': ofile = optarg; resume = look_for_earlier_output(optarg, &opt); break;   /* later options still apply, as in the reference */
-		case 'b': opt.mode |= 0x20; break;
-		case '0': opt.mode |= 0x40; break;
-		case '1': opt.mode |= 0x80; break;
-		case '2': opt.mode |= 0x100; break;
-		case 'I': opt.mode |= MODE_IL13; break;
-		case 'Y': opt.mode |= MODE_CFY; break;
+		case 'N': opt.max_top2 = 0x7fffffff; break;
 		case 'B': opt.mode |= atoi(optarg) << 24; break;
-		default: return 1;
+		case 'f': ofile = optarg; resume = look_for_earlier_output(optarg, &opt); break;   /* options after -f still apply, as in the reference */
+		default: break;
 		}
 	}
 	if (opte > 0) { opt.max_gape = opte; opt.mode &= ~NABWA_MODE_GAPE; }
