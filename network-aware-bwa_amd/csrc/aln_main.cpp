@@ -278,6 +278,32 @@ int main(int argc, char *argv[])
 		}
 	const char *prefix = argv[optind], *reads = argv[optind + 1];
 
+	// ---- NABWA_ALN_PARSE_ONLY: stop after the host side (no index, no GPU, no .sai) and say what the reads look like after
+	// parsing, filtering, trimming and encoding: "reads N bases M fnv H" (=2: also one line per read "len fnv").  Lets the CPU
+	// tests check this file's share of the work against an independent restatement, and times the parser.
+	if (getenv("NABWA_ALN_PARSE_ONLY")) {
+		const bool per_read = atoi(getenv("NABWA_ALN_PARSE_ONLY")) >= 2;
+		Source src;
+		src.mode = opt.mode; src.trim_qual = opt.trim_qual;
+		if (!src.fx.open(reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
+		auto fnv = [](uint64_t h, const uint8_t *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; };
+		uint64_t all = 1469598103934665603ull; long n_reads = 0, n_bases = 0;
+		for (;;) {
+			Batch b;
+			while (b.n() < REF_CHUNK && src.one(&b)) {}
+			if (b.n() == 0) break;
+			for (int i = 0; i < b.n(); ++i) {
+				const size_t o = (size_t)b.off[i], len = (size_t)(b.off[i + 1] - b.off[i]);
+				uint64_t h = fnv(fnv(1469598103934665603ull, b.seq.data() + o, len), b.rseq.data() + o, len);
+				if (per_read) printf("%zu %016llx\n", len, (unsigned long long)h);
+				all = fnv(all, (const uint8_t*)&h, 8); n_bases += (long)len;
+			}
+			n_reads += b.n();
+		}
+		printf("reads %ld bases %ld fnv %016llx\n", n_reads, n_bases, (unsigned long long)all);
+		return 0;
+	}
+
 	// ---- the index: no GPU, no output
 	nabwa_index_t *ix = nullptr;
 	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;

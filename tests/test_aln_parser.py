@@ -1,0 +1,178 @@
+"""The host side of `nabwa_aln` without a GPU (NABWA_ALN_PARSE_ONLY): FASTA/FASTQ parsing as kseq_read does it
+(kseq.h:155-193), the filters, barcode removal, quality trimming and encoding of bwa_read_seq (bwaseqio.c:172-252),
+checked read by read against an independent restatement written here from those descriptions.  (That the tool's .sai is
+byte-identical to the reference's for the same files is the GPU test, tests/test_gpu_aln_cli.py.)"""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+import test_gpu_aln_cli as CLI          # the awkward inputs are built by the same helpers
+
+TOOL = CLI.TOOL
+FNV0, FNVP, M64 = 1469598103934665603, 1099511628211, (1 << 64) - 1
+
+
+def fnv(h, data):
+    for b in data:
+        h = ((h ^ b) * FNVP) & M64
+    return h
+
+
+def kseq_records(data):
+    """(name, comment, seq, qual) records of a byte string, the way kseq_read cuts them; stops at a truncated quality"""
+    i, n, pending, out = 0, len(data), False, []
+
+    def getc():
+        nonlocal i
+        if i >= n:
+            return -1
+        i += 1
+        return data[i - 1]
+
+    while True:
+        if not pending:
+            c = getc()
+            while c != -1 and c not in (62, 64):           # '>' '@'
+                c = getc()
+            if c == -1:
+                return out
+        pending = False
+        name, comment, seq, qual = bytearray(), bytearray(), bytearray(), bytearray()
+        c = getc()
+        while c != -1 and not chr(c).isspace():
+            name.append(c)
+            c = getc()
+        if c == -1 and not name:
+            return out
+        if c != 10 and c != -1:
+            c = getc()
+            while c != -1 and c != 10:
+                comment.append(c)
+                c = getc()
+        c = getc()
+        while c != -1 and c not in (62, 43, 64):            # '>' '+' '@'
+            if 33 <= c <= 126:
+                seq.append(c)
+            c = getc()
+        if c in (62, 64):
+            pending = True
+        if c != 43:
+            out.append((bytes(name), bytes(comment), bytes(seq), b""))
+            continue
+        c = getc()
+        while c != -1 and c != 10:
+            c = getc()
+        if c == -1:
+            return out
+        c = getc()
+        while c != -1 and len(qual) < len(seq):
+            if 33 <= c <= 127:
+                qual.append(c)
+            c = getc()
+        if len(qual) != len(seq):
+            return out
+        out.append((bytes(name), bytes(comment), bytes(seq), bytes(qual)))
+
+
+def expected_lines(data, trim_qual=0, barcode=0, casava=False, il13=False, comp=True):
+    code = {65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3}
+    lines, n_bases, total = [], 0, FNV0
+    for name, comment, seq, qual in kseq_records(data):
+        if casava and comment:
+            p = comment.find(b":")
+            if p >= 0 and p + 1 < len(comment) and comment[p + 1:p + 2] == b"Y":
+                continue
+        if len(seq) <= barcode:
+            continue
+        seq, qual = seq[barcode:], qual[barcode:]
+        ln = len(seq)
+        if qual and trim_qual >= 1:
+            shift = 33 + (31 if il13 else 0)
+            s, best, best_l = 0, 0, ln - 1
+            for l in range(ln - 1, 33, -1):
+                s += trim_qual - (qual[l] - shift)
+                if s < 0:
+                    break
+                if s > best:
+                    best, best_l = s, l
+            ln = best_l + 1
+        fwd = [code.get(c, 4) for c in seq[:ln]]
+        rev = bytes(reversed(fwd))
+        rc = bytes((3 - c if (comp and c < 4) else c) for c in rev)
+        h = fnv(fnv(FNV0, rev), rc)
+        lines.append("%d %016x" % (ln, h))
+        total = fnv(total, h.to_bytes(8, "little"))
+        n_bases += ln
+    lines.append("reads %d bases %d fnv %016x" % (len(lines), n_bases, total))
+    return lines
+
+
+def tool_lines(args, path):
+    env = dict(os.environ, NABWA_ALN_PARSE_ONLY="2")
+    r = subprocess.run([TOOL] + args + ["unused_prefix", path], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    return r.stdout.split("\n")[:-1]
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    if not os.path.exists(TOOL):
+        import importlib
+        importlib.import_module("network-aware-bwa_amd").build()
+    d = tmp_path_factory.mktemp("fx")
+    rng = np.random.default_rng(77)
+    recs = CLI.awkward_reads(rng)
+    out = {}
+    out["fq"] = str(d / "a.fq")
+    CLI.write_fastq(out["fq"], recs, np.random.default_rng(1))
+    out["fq64"] = str(d / "a64.fq")
+    CLI.write_fastq(out["fq64"], recs, np.random.default_rng(1), base=64)
+    out["gz"] = str(d / "a.fq.gz")
+    CLI.write_fastq(out["gz"], recs, np.random.default_rng(1), opener=gzip.open)
+    out["fa"] = str(d / "a.fa")
+    with open(out["fa"], "w") as f:               # multi-line FASTA, a blank record, trailing blanks, no final newline
+        for i, (n, cm, s) in enumerate(recs):
+            f.write(">%s\t%s\n" % (n, cm))
+            if i == 11:
+                f.write("\n")
+                continue
+            for j in range(0, len(s), 25):
+                f.write(s[j:j + 25] + ("\n" if i % 2 or j + 25 < len(s) else " \n"))
+        f.write(">last\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT")
+    out["odd"] = str(d / "odd.fq")
+    with open(out["odd"], "wb") as f:             # what a strict parser would reject and kseq takes in its stride
+        f.write(b"junk before the first record\n@r1 c1\nACGT\nACGT\n+r1\nIIII\nIIII\n"          # two-line sequence and quality
+                b"@r2\nAC@GT\n+\nIIII\n"                                                       # '@' inside a sequence line ends it
+                b"\n\n>f1\nacgtnACGT\n>f2 x y\n\n>f3\nAC-GT.AC\n"                               # FASTA records in a FASTQ file, an empty one
+                b"@r3\nACGTACGTAC\n+\nIIIIIIIIII@r4\nACGTA\n+\nIIIII\n"                         # no newline after a quality: its '@' is eaten
+                b"@r5\nACGTACGT\n+\nIII")                                                       # truncated quality: reading stops here
+    return out
+
+
+@pytest.mark.parametrize("args,key,kw", [
+    ([], "fq", {}), ([], "gz", {}), ([], "fa", {}), ([], "odd", {}),
+    (["-Y"], "fq", {"casava": True}), (["-B", "6"], "fq", {"barcode": 6}),
+    (["-B", "6", "-Y", "-q", "15"], "fq", {"barcode": 6, "casava": True, "trim_qual": 15}),
+    (["-I", "-q", "20"], "fq64", {"il13": True, "trim_qual": 20}), (["-q", "25"], "fq", {"trim_qual": 25}),
+    (["-c"], "fq", {"comp": False}), (["-Y", "-q", "30"], "fa", {"casava": True, "trim_qual": 30}),
+], ids=lambda x: "_".join(x) if isinstance(x, list) else None)
+def test_parsing_filters_trimming_and_encoding(files, args, key, kw):
+    path = files[key]
+    raw = gzip.open(path, "rb").read() if key == "gz" else open(path, "rb").read()
+    assert tool_lines(args, path) == expected_lines(raw, **kw)
+
+
+def test_golden_reads_parse_like_the_test_library():
+    """and the same against tests/nabwa_testlib.py's reader, which the parity tests feed the GPU from"""
+    fq = os.path.join(T.GOLDEN, "reads_se.fq")
+    reads = T.read_fastq(fq)
+    seq, rseq, off, _ = T.encode_reads(reads, trim_qual=20)
+    want = []
+    for i in range(len(reads)):
+        a, b = seq[off[i]:off[i + 1]].tobytes(), rseq[off[i]:off[i + 1]].tobytes()
+        want.append("%d %016x" % (len(a), fnv(fnv(FNV0, a), b)))
+    assert tool_lines(["-q", "20"], fq)[:-1] == want
