@@ -51,56 +51,107 @@ struct Fastx {
 	int have = 0, at = 0, pending = 0;
 	bool eof = false;
 	std::string name, comment, seq, qual;
+	unsigned char cls[256];            /* sequence bytes: 0 = base character (isgraph), 1 = skipped, 2 = ends the sequence ('>' '+' '@') */
 
 	bool open(const char *fn)
 	{
 		fp = strcmp(fn, "-") == 0 ? gzdopen(fileno(stdin), "r") : gzopen(fn, "r");
-		buf.resize(1 << 20);
+		if (fp) gzbuffer(fp, 1 << 20);
+		const char *bs = getenv("NABWA_ALN_BUF");             /* (tests: a few bytes, so that every scan meets the end of the buffer) */
+		buf.resize(bs && atoi(bs) > 0 ? (size_t)atoi(bs) : (size_t)4 << 20);
+		for (int c = 0; c < 256; ++c) cls[c] = isgraph(c) ? 0 : 1;
+		cls['>'] = cls['+'] = cls['@'] = 2;
 		return fp != nullptr;
 	}
 	void close() { if (fp) gzclose(fp); fp = nullptr; }
-	int ch()
+	/* true when buf[at .. have) holds at least one byte */
+	bool more()
 	{
-		if (at >= have) {
-			if (eof) return -1;
-			have = gzread(fp, buf.data(), (unsigned)buf.size()); at = 0;
-			if (have <= 0) { eof = true; have = 0; return -1; }
-		}
-		return buf[at++];
+		if (at < have) return true;
+		if (eof) return false;
+		have = gzread(fp, buf.data(), (unsigned)buf.size()); at = 0;
+		if (have <= 0) { eof = true; have = 0; return false; }
+		return true;
 	}
-	/* length of the sequence, -1 at the end of the input, -2 for a truncated quality string */
+	/* length of the sequence, -1 at the end of the input, -2 for a truncated quality string.  The scans below run over
+	 * what is in the buffer and append whole runs; they consume exactly the bytes the character-at-a-time description
+	 * above consumes (tests/test_aln_parser.py holds that description as code). */
 	int next()
 	{
-		int c;
+		int c = -1;
 		if (!pending) {
-			do c = ch(); while (c != -1 && c != '>' && c != '@');
-			if (c == -1) return -1;
+			for (;;) {
+				if (!more()) return -1;
+				const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+				while (p < e && *p != '>' && *p != '@') ++p;
+				at = (int)(p - buf.data());
+				if (p < e) { ++at; break; }
+			}
 		}
 		pending = 0;
 		name.clear(); comment.clear(); seq.clear(); qual.clear();
-		while ((c = ch()) != -1 && !isspace(c)) name.push_back((char)c);
+		for (c = -1;;) {                                     /* name: up to the first white space */
+			if (!more()) break;
+			const unsigned char *p = buf.data() + at, *e = buf.data() + have, *q = p;
+			while (q < e && !isspace(*q)) ++q;
+			name.append((const char*)p, (size_t)(q - p));
+			at = (int)(q - buf.data());
+			if (q < e) { c = *q; ++at; break; }
+		}
 		if (c == -1 && name.empty()) return -1;
-		if (c != '\n' && c != -1) while ((c = ch()) != -1 && c != '\n') comment.push_back((char)c);
-		while ((c = ch()) != -1 && c != '>' && c != '+' && c != '@') if (isgraph(c)) seq.push_back((char)c);
+		if (c != '\n' && c != -1)                            /* comment: the rest of the line */
+			for (;;) {
+				if (!more()) break;
+				const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+				const unsigned char *q = (const unsigned char*)memchr(p, '\n', (size_t)(e - p));
+				comment.append((const char*)p, (size_t)((q ? q : e) - p));
+				at = (int)((q ? q + 1 : e) - buf.data());
+				if (q) break;
+			}
+		for (c = -1;;) {                                     /* sequence: runs of base characters up to '>', '+' or '@' */
+			if (!more()) break;
+			const unsigned char *e = buf.data() + have, *q = buf.data() + at;
+			while (q < e) {
+				const unsigned char k = cls[*q];
+				if (k == 0) { const unsigned char *r = q; do ++q; while (q < e && cls[*q] == 0); seq.append((const char*)r, (size_t)(q - r)); }
+				else if (k == 1) ++q;
+				else { c = *q; break; }
+			}
+			at = (int)(q - buf.data());
+			if (c != -1) { ++at; break; }
+		}
 		if (c == '>' || c == '@') pending = c;
 		if (c != '+') return (int)seq.size();
-		do c = ch(); while (c != -1 && c != '\n');
-		if (c == -1) return -2;
-		while ((c = ch()) != -1 && qual.size() < seq.size()) if (c >= 33 && c <= 127) qual.push_back((char)c);
+		for (;;) {                                           /* the rest of the '+' line */
+			if (!more()) return -2;
+			const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+			const unsigned char *q = (const unsigned char*)memchr(p, '\n', (size_t)(e - p));
+			at = (int)((q ? q + 1 : e) - buf.data());
+			if (q) break;
+		}
+		for (;;) {                                           /* quality: characters 33..127 until there is one per base */
+			if (qual.size() >= seq.size()) { if (more()) ++at; break; }       /* ... and the character after them goes too */
+			if (!more()) break;
+			const unsigned char *e = buf.data() + have, *q = buf.data() + at;
+			size_t need = seq.size() - qual.size();
+			while (q < e && need) {
+				const unsigned char *r = q;
+				while (q < e && (size_t)(q - r) < need && *q >= 33 && *q <= 127) ++q;
+				qual.append((const char*)r, (size_t)(q - r)); need -= (size_t)(q - r);
+				if (need && q < e) ++q;                      /* a character that is not a quality (line break): skipped */
+			}
+			at = (int)(q - buf.data());
+		}
 		if (qual.size() != seq.size()) return -2;
 		return (int)seq.size();
 	}
 };
 
-static uint8_t nt4(unsigned char c)         /* nst_nt4_table (bntseq.c:39-56); its 5 for '-' is "not a base" like 4 everywhere on this path */
+static uint8_t NT4[256];               /* nst_nt4_table (bntseq.c:39-56); its 5 for '-' is "not a base" like 4 everywhere on this path */
+static void nt4_init()
 {
-	switch (c) {
-	case 'A': case 'a': return 0;
-	case 'C': case 'c': return 1;
-	case 'G': case 'g': return 2;
-	case 'T': case 't': return 3;
-	default: return 4;
-	}
+	memset(NT4, 4, sizeof NT4);
+	NT4['A'] = NT4['a'] = 0; NT4['C'] = NT4['c'] = 1; NT4['G'] = NT4['g'] = 2; NT4['T'] = NT4['t'] = 3;
 }
 
 struct Batch {                      /* what one GPU call (or a few) consumes */
@@ -149,10 +200,13 @@ struct Source {                     /* bwa_read_seq (bwaseqio.c:172-252) minus t
 		const bool comp = mode & NABWA_MODE_COMPREAD;
 		const size_t at = b->seq.size();
 		b->seq.resize(at + len); b->rseq.resize(at + len);
+		uint8_t *const ps = b->seq.data() + at, *const pr = b->rseq.data() + at;
+		const unsigned char *const last = (const unsigned char*)s + len - 1;
+		const uint8_t flip = comp ? 3 : 0;
 		for (int i = 0; i < len; ++i) {                                  /* seq: the read reversed; rseq: its reverse complement */
-			const uint8_t c = nt4((unsigned char)s[len - 1 - i]);
-			b->seq[at + i] = c;
-			b->rseq[at + i] = comp && c < 4 ? 3 - c : c;
+			const uint8_t c = NT4[last[-i]];
+			ps[i] = c;
+			pr[i] = c < 4 ? c ^ flip : c;                                /* 3 - c == c ^ 3 for 0..3 */
 		}
 		const int idx = b->n();
 		if (idx % REF_CHUNK == 0) b->chunk_max_len.push_back(0);
@@ -243,6 +297,7 @@ int main(int argc, char *argv[])
 {
 	nabwa_gap_opt_t opt;
 	nabwa_gap_init_opt(&opt);
+	nt4_init();
 	int c, opte = -1;
 	const char *ofile = nullptr;
 	Resume resume;

@@ -111,8 +111,10 @@ def expected_lines(data, trim_qual=0, barcode=0, casava=False, il13=False, comp=
     return lines
 
 
-def tool_lines(args, path):
+def tool_lines(args, path, buf=None):
     env = dict(os.environ, NABWA_ALN_PARSE_ONLY="2")
+    if buf:
+        env["NABWA_ALN_BUF"] = str(buf)
     r = subprocess.run([TOOL] + args + ["unused_prefix", path], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     return r.stdout.split("\n")[:-1]
@@ -164,6 +166,17 @@ def test_parsing_filters_trimming_and_encoding(files, args, key, kw):
     path = files[key]
     raw = gzip.open(path, "rb").read() if key == "gz" else open(path, "rb").read()
     assert tool_lines(args, path) == expected_lines(raw, **kw)
+
+
+@pytest.mark.parametrize("buf", [1, 2, 7, 64, 1000])
+def test_every_scan_survives_the_end_of_the_buffer(files, buf):
+    """the parser works on whatever the read buffer holds and appends whole runs: with buffers of a few bytes every run,
+    header, line end and quality string is cut somewhere"""
+    for key, args, kw in (("odd", [], {}), ("fa", ["-Y"], {"casava": True}), ("fq", ["-B", "6", "-q", "15"], {"barcode": 6, "trim_qual": 15}),
+                          ("gz", [], {})):
+        path = files[key]
+        raw = gzip.open(path, "rb").read() if key == "gz" else open(path, "rb").read()
+        assert tool_lines(args, path, buf) == expected_lines(raw, **kw), (key, buf)
 
 
 def test_golden_reads_parse_like_the_test_library():
