@@ -21,9 +21,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -47,30 +53,64 @@
 // until there are as many as bases, and one more character is consumed.
 struct Fastx {
 	gzFile fp = nullptr;
-	std::vector<unsigned char> buf;
-	int have = 0, at = 0, pending = 0;
-	bool eof = false;
+	std::vector<unsigned char> own;    /* gzip / stdin: the read buffer */
+	const unsigned char *data = nullptr;   /* what the scans run over: `own`, or the whole file when it is plain and mapped */
+	size_t have = 0, at = 0, file_size = 0;
+	int pending = 0;
+	bool eof = false, mapped = false, hit_limit = false;
 	std::string name, comment, seq, qual;
 	unsigned char cls[256];            /* sequence bytes: 0 = base character (isgraph), 1 = skipped, 2 = ends the sequence ('>' '+' '@') */
 
+	void tables()
+	{
+		for (int c = 0; c < 256; ++c) cls[c] = isgraph(c) ? 0 : 1;
+		cls['>'] = cls['+'] = cls['@'] = 2;
+	}
 	bool open(const char *fn)
 	{
+		tables();
+		if (strcmp(fn, "-") != 0 && !getenv("NABWA_ALN_BUF")) {          /* a plain regular file is mapped: no copies, and its parse can be split */
+			const int fd = ::open(fn, O_RDONLY);
+			struct stat st;
+			if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 2) {
+				unsigned char magic[2] = { 0, 0 };
+				if (pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+					void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+					if (m != MAP_FAILED) {
+						(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+						data = (const unsigned char*)m; have = file_size = (size_t)st.st_size; at = 0; eof = true; mapped = true;
+						::close(fd);
+						return true;
+					}
+				}
+			}
+			if (fd >= 0) ::close(fd);
+		}
 		fp = strcmp(fn, "-") == 0 ? gzdopen(fileno(stdin), "r") : gzopen(fn, "r");
 		if (fp) gzbuffer(fp, 1 << 20);
 		const char *bs = getenv("NABWA_ALN_BUF");             /* (tests: a few bytes, so that every scan meets the end of the buffer) */
-		buf.resize(bs && atoi(bs) > 0 ? (size_t)atoi(bs) : (size_t)4 << 20);
-		for (int c = 0; c < 256; ++c) cls[c] = isgraph(c) ? 0 : 1;
-		cls['>'] = cls['+'] = cls['@'] = 2;
+		own.resize(bs && atoi(bs) > 0 ? (size_t)atoi(bs) : (size_t)4 << 20);
+		data = own.data();
 		return fp != nullptr;
 	}
-	void close() { if (fp) gzclose(fp); fp = nullptr; }
-	/* true when buf[at .. have) holds at least one byte */
+	/* a second reader on the same mapped file: bytes [from, limit) */
+	void view(const Fastx &whole, size_t from, size_t limit)
+	{
+		tables();
+		data = whole.data; file_size = whole.file_size; have = limit; at = from; eof = true; mapped = true; pending = 0; hit_limit = false;
+	}
+	void close() { if (fp) gzclose(fp); fp = nullptr; if (mapped && data && have == file_size && !own.size()) { /* the mapping lives until exit */ } }
+	/* where the next record starts: the header character of a FASTA record may already have been taken */
+	size_t logical_pos() const { return at - (pending ? 1 : 0); }
+	/* true when data[at .. have) holds at least one byte */
 	bool more()
 	{
 		if (at < have) return true;
+		if (mapped) { if (have < file_size) hit_limit = true; return false; }
 		if (eof) return false;
-		have = gzread(fp, buf.data(), (unsigned)buf.size()); at = 0;
-		if (have <= 0) { eof = true; have = 0; return false; }
+		const int got = gzread(fp, own.data(), (unsigned)own.size());
+		at = 0; have = got > 0 ? (size_t)got : 0;
+		if (got <= 0) { eof = true; return false; }
 		return true;
 	}
 	/* length of the sequence, -1 at the end of the input, -2 for a truncated quality string.  The scans below run over
@@ -82,9 +122,9 @@ struct Fastx {
 		if (!pending) {
 			for (;;) {
 				if (!more()) return -1;
-				const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+				const unsigned char *p = data + at, *e = data + have;
 				while (p < e && *p != '>' && *p != '@') ++p;
-				at = (int)(p - buf.data());
+				at = (size_t)(p - data);
 				if (p < e) { ++at; break; }
 			}
 		}
@@ -92,47 +132,47 @@ struct Fastx {
 		name.clear(); comment.clear(); seq.clear(); qual.clear();
 		for (c = -1;;) {                                     /* name: up to the first white space */
 			if (!more()) break;
-			const unsigned char *p = buf.data() + at, *e = buf.data() + have, *q = p;
+			const unsigned char *p = data + at, *e = data + have, *q = p;
 			while (q < e && !isspace(*q)) ++q;
 			name.append((const char*)p, (size_t)(q - p));
-			at = (int)(q - buf.data());
+			at = (size_t)(q - data);
 			if (q < e) { c = *q; ++at; break; }
 		}
 		if (c == -1 && name.empty()) return -1;
 		if (c != '\n' && c != -1)                            /* comment: the rest of the line */
 			for (;;) {
 				if (!more()) break;
-				const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+				const unsigned char *p = data + at, *e = data + have;
 				const unsigned char *q = (const unsigned char*)memchr(p, '\n', (size_t)(e - p));
 				comment.append((const char*)p, (size_t)((q ? q : e) - p));
-				at = (int)((q ? q + 1 : e) - buf.data());
+				at = (size_t)((q ? q + 1 : e) - data);
 				if (q) break;
 			}
 		for (c = -1;;) {                                     /* sequence: runs of base characters up to '>', '+' or '@' */
 			if (!more()) break;
-			const unsigned char *e = buf.data() + have, *q = buf.data() + at;
+			const unsigned char *e = data + have, *q = data + at;
 			while (q < e) {
 				const unsigned char k = cls[*q];
 				if (k == 0) { const unsigned char *r = q; do ++q; while (q < e && cls[*q] == 0); seq.append((const char*)r, (size_t)(q - r)); }
 				else if (k == 1) ++q;
 				else { c = *q; break; }
 			}
-			at = (int)(q - buf.data());
+			at = (size_t)(q - data);
 			if (c != -1) { ++at; break; }
 		}
 		if (c == '>' || c == '@') pending = c;
 		if (c != '+') return (int)seq.size();
 		for (;;) {                                           /* the rest of the '+' line */
 			if (!more()) return -2;
-			const unsigned char *p = buf.data() + at, *e = buf.data() + have;
+			const unsigned char *p = data + at, *e = data + have;
 			const unsigned char *q = (const unsigned char*)memchr(p, '\n', (size_t)(e - p));
-			at = (int)((q ? q + 1 : e) - buf.data());
+			at = (size_t)((q ? q + 1 : e) - data);
 			if (q) break;
 		}
 		for (;;) {                                           /* quality: characters 33..127 until there is one per base */
 			if (qual.size() >= seq.size()) { if (more()) ++at; break; }       /* ... and the character after them goes too */
 			if (!more()) break;
-			const unsigned char *e = buf.data() + have, *q = buf.data() + at;
+			const unsigned char *e = data + have, *q = data + at;
 			size_t need = seq.size() - qual.size();
 			while (q < e && need) {
 				const unsigned char *r = q;
@@ -140,7 +180,7 @@ struct Fastx {
 				qual.append((const char*)r, (size_t)(q - r)); need -= (size_t)(q - r);
 				if (need && q < e) ++q;                      /* a character that is not a quality (line break): skipped */
 			}
-			at = (int)(q - buf.data());
+			at = (size_t)(q - data);
 		}
 		if (qual.size() != seq.size()) return -2;
 		return (int)seq.size();
@@ -215,6 +255,147 @@ struct Source {                     /* bwa_read_seq (bwaseqio.c:172-252) minus t
 		return true;
 	}
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// From records to GPU batches.  Fragments of parsed reads (from one sequential parser, or from several parsers working on
+// pieces of a mapped file) are appended to the batch under construction; a batch is handed on when it holds batch_reads
+// reads (a multiple of the reference's chunk) or, for long reads, 1 Gi bases at a chunk boundary.
+struct Assembler {
+	long batch_reads;
+	std::function<void(std::unique_ptr<Batch>)> emit;
+	std::unique_ptr<Batch> cur{new Batch};
+
+	void add(const Batch &f)
+	{
+		for (int i = 0; i < f.n(); ) {
+			Batch &b = *cur;
+			// as many reads of the fragment as the batch under construction still takes, bases copied in one piece
+			int k = f.n() - i;
+			if ((long)k > batch_reads - b.n()) k = (int)(batch_reads - b.n());
+			const int to_chunk_end = REF_CHUNK - b.n() % REF_CHUNK;           /* the 1 Gi-base rule is looked at on chunk boundaries */
+			if (k > to_chunk_end) k = to_chunk_end;
+			const size_t o = (size_t)f.off[i], bytes = (size_t)(f.off[i + k] - f.off[i]), at = b.seq.size();
+			b.seq.insert(b.seq.end(), f.seq.begin() + o, f.seq.begin() + o + bytes);
+			b.rseq.insert(b.rseq.end(), f.rseq.begin() + o, f.rseq.begin() + o + bytes);
+			if (b.n() % REF_CHUNK == 0) b.chunk_max_len.push_back(0);
+			int mx = b.chunk_max_len.back();
+			for (int j = 0; j < k; ++j) {
+				const int len = (int)(f.off[i + j + 1] - f.off[i + j]);
+				if (len > mx) mx = len;
+				b.off.push_back((int64_t)at + (f.off[i + j + 1] - f.off[i]));
+			}
+			b.chunk_max_len.back() = mx;
+			i += k;
+			if (b.n() >= batch_reads || (b.seq.size() >= (1ull << 30) && b.n() % REF_CHUNK == 0)) flush();
+		}
+	}
+	void flush()
+	{
+		if (!cur->n()) return;
+		const size_t cap = cur->seq.size() + cur->seq.size() / 8;              /* the next batch will be about as large: no regrowth copies */
+		emit(std::move(cur));
+		cur.reset(new Batch);
+		cur->seq.reserve(cap); cur->rseq.reserve(cap);
+	}
+};
+
+/* Where a record may start at or after `from` (and before `end`): after a line break, '>' (a FASTA header wherever it
+ * stands), or '@' whose line after next begins with '+' (the four-line FASTQ shape; a quality line may begin with '@' too,
+ * and then the line after next is a sequence).  A guess -- the caller checks it against the parse that arrives there. */
+static size_t guess_record_start(const unsigned char *d, size_t from, size_t end)
+{
+	for (size_t p = from; p < end; ) {
+		const unsigned char *nl = (const unsigned char*)memchr(d + p, '\n', end - p);
+		if (!nl) break;
+		p = (size_t)(nl - d) + 1;
+		if (p >= end) break;
+		if (d[p] == '>') return p;
+		if (d[p] == '@') {
+			const unsigned char *l1 = (const unsigned char*)memchr(d + p, '\n', end - p);
+			if (!l1) break;
+			const unsigned char *l2 = (const unsigned char*)memchr(l1 + 1, '\n', (size_t)(d + end - (l1 + 1)));
+			if (!l2) break;
+			if (l2 + 1 < d + end && l2[1] == '+') return p;
+		}
+	}
+	return end;
+}
+
+/* Everything the input still holds, as batches through `as`.  A mapped file is parsed a window at a time by several
+ * parsers, each starting at a guessed record start; parser j's reads are taken when parser j-1 (whose own start was right)
+ * stopped exactly where j began -- then j's parse is what the single sequential parse would have produced from there.  At
+ * the first piece that does not line up, the rest of the window is dropped and the next window starts where the last
+ * good parser stopped, which is a record boundary of the sequential parse by construction. */
+static double dbg_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+static void read_everything(Source &src, Assembler &as)
+{
+	int n_thr = getenv("NABWA_ALN_THREADS") ? atoi(getenv("NABWA_ALN_THREADS")) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+	if (!src.fx.mapped || n_thr < 2) {
+		Batch frag;
+		for (;;) {
+			frag = Batch();
+			while (frag.n() < 65536 && src.one(&frag)) {}
+			if (frag.n() == 0) break;
+			as.add(frag);
+			if (frag.n() < 65536) break;
+		}
+		as.flush();
+		return;
+	}
+	const size_t window = (getenv("NABWA_ALN_WINDOW") ? (size_t)atol(getenv("NABWA_ALN_WINDOW")) : (size_t)64 << 20);
+	const unsigned char *d = src.fx.data; const size_t size = src.fx.file_size;
+	size_t pos = src.fx.logical_pos();
+	bool input_ended = false;
+	struct Piece { Source s; Batch b; size_t stop_at = 0; bool ended = false; };
+	std::vector<Piece> piece;
+	while (pos < size && !input_ended) {
+		const double t_start = dbg_now();
+		const size_t wend = pos + window < size ? pos + window : size;
+		std::vector<size_t> cut{pos};
+		for (int k = 1; k < n_thr; ++k) {
+			const size_t c = guess_record_start(d, pos + (wend - pos) / n_thr * k, wend);
+			if (c > cut.back() && c < wend) cut.push_back(c);
+		}
+		cut.push_back(wend == size ? size : guess_record_start(d, wend, size));
+		const int m = (int)cut.size() - 1;
+		if ((int)piece.size() < m) piece.resize(m);
+		std::vector<std::thread> th;
+		for (int j = 0; j < m; ++j) {
+			Piece &q = piece[j];
+			q.b.off.assign(1, 0); q.b.seq.clear(); q.b.rseq.clear(); q.b.chunk_max_len.clear();     /* the buffers of the window before are used again */
+			q.stop_at = 0; q.ended = false; q.s.n_trimmed = q.s.n_tot = 0;
+			q.s.mode = src.mode; q.s.trim_qual = src.trim_qual;
+			const size_t limit = cut[j + 1] + ((size_t)64 << 20) < size ? cut[j + 1] + ((size_t)64 << 20) : size;   /* a parser on a wrong start does not run to the end of the file */
+			q.s.fx.view(src.fx, cut[j], limit);
+			auto work = [&q, stop = cut[j + 1]]() {
+				while (q.s.fx.logical_pos() < stop) if (!q.s.one(&q.b)) { q.ended = true; break; }
+				q.stop_at = q.s.fx.logical_pos();
+			};
+			if (m == 1) work(); else th.emplace_back(work);
+		}
+		for (auto &x : th) x.join();
+		const double t_parsed = dbg_now();
+		size_t good_to = pos;
+		for (int j = 0; j < m; ++j) {
+			Piece &q = piece[j];
+			if (q.s.fx.hit_limit) {          /* ran into its look-ahead limit: parse this stretch again without one, alone */
+				q.b = Batch(); q.ended = false; q.s.n_trimmed = q.s.n_tot = 0;
+				q.s.fx.view(src.fx, cut[j], size);
+				while (q.s.fx.logical_pos() < cut[j + 1]) if (!q.s.one(&q.b)) { q.ended = true; break; }
+				q.stop_at = q.s.fx.logical_pos();
+			}
+			as.add(q.b);
+			src.n_trimmed += q.s.n_trimmed; src.n_tot += q.s.n_tot;
+			good_to = q.stop_at;
+			if (q.ended) { input_ended = true; break; }            /* end of the input, or a truncated quality string: reading stops for good */
+			if (q.stop_at != cut[j + 1]) break;                   /* the next piece did not start on a record of this parse */
+		}
+		if (getenv("NABWA_ALN_DEBUG")) fprintf(stderr, "[nabwa_aln] window at %zu: %d pieces, accepted up to %zu of %zu; parse %.3f s, assemble %.3f s\n", pos, m, good_to, cut[m], t_parsed - t_start, dbg_now() - t_parsed);
+		pos = good_to;
+	}
+	as.flush();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 struct Resume { int skip = 0; long at = 0; bool found = false; };
@@ -343,18 +524,21 @@ int main(int argc, char *argv[])
 		if (!src.fx.open(reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
 		auto fnv = [](uint64_t h, const uint8_t *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; };
 		uint64_t all = 1469598103934665603ull; long n_reads = 0, n_bases = 0;
-		for (;;) {
-			Batch b;
-			while (b.n() < REF_CHUNK && src.one(&b)) {}
-			if (b.n() == 0) break;
+		Assembler as;
+		as.batch_reads = REF_CHUNK;
+		as.emit = [&](std::unique_ptr<Batch> bp) {
+			const Batch &b = *bp;
 			for (int i = 0; i < b.n(); ++i) {
 				const size_t o = (size_t)b.off[i], len = (size_t)(b.off[i + 1] - b.off[i]);
+				n_bases += (long)len;
+				if (!per_read) continue;                                  /* =1: counts only (timing the parser) */
 				uint64_t h = fnv(fnv(1469598103934665603ull, b.seq.data() + o, len), b.rseq.data() + o, len);
-				if (per_read) printf("%zu %016llx\n", len, (unsigned long long)h);
-				all = fnv(all, (const uint8_t*)&h, 8); n_bases += (long)len;
+				printf("%zu %016llx\n", len, (unsigned long long)h);
+				all = fnv(all, (const uint8_t*)&h, 8);
 			}
 			n_reads += b.n();
-		}
+		};
+		read_everything(src, as);
 		printf("reads %ld bases %ld fnv %016llx\n", n_reads, n_bases, (unsigned long long)all);
 		return 0;
 	}
@@ -393,18 +577,18 @@ int main(int argc, char *argv[])
 	std::mutex mu; std::condition_variable cv;
 	std::deque<std::unique_ptr<Batch>> ready; bool done = false;
 	std::thread reader([&]() {
-		for (bool eof = false; !eof; ) {
-			std::unique_ptr<Batch> b(new Batch);
-			while (b->n() < batch_reads) {
-				if (!src.one(b.get())) { eof = true; break; }
-				if (b->seq.size() >= (1ull << 30) && b->n() % REF_CHUNK == 0) break;   /* long reads: bound the bases of a batch as well */
-			}
+		Assembler as;
+		as.batch_reads = batch_reads;
+		as.emit = [&](std::unique_ptr<Batch> b) {
 			std::unique_lock<std::mutex> lk(mu);
 			cv.wait(lk, [&] { return ready.size() < 2; });
-			if (b->n()) ready.push_back(std::move(b));
-			if (eof) done = true;
+			ready.push_back(std::move(b));
 			cv.notify_all();
-		}
+		};
+		read_everything(src, as);
+		std::unique_lock<std::mutex> lk(mu);
+		done = true;
+		cv.notify_all();
 	});
 
 	long tot = 0; int status = 0;

@@ -111,10 +111,14 @@ def expected_lines(data, trim_qual=0, barcode=0, casava=False, il13=False, comp=
     return lines
 
 
-def tool_lines(args, path, buf=None):
+def tool_lines(args, path, buf=None, window=None, threads=None):
     env = dict(os.environ, NABWA_ALN_PARSE_ONLY="2")
     if buf:
         env["NABWA_ALN_BUF"] = str(buf)
+    if window:
+        env["NABWA_ALN_WINDOW"] = str(window)
+    if threads:
+        env["NABWA_ALN_THREADS"] = str(threads)
     r = subprocess.run([TOOL] + args + ["unused_prefix", path], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     return r.stdout.split("\n")[:-1]
@@ -177,6 +181,39 @@ def test_every_scan_survives_the_end_of_the_buffer(files, buf):
         path = files[key]
         raw = gzip.open(path, "rb").read() if key == "gz" else open(path, "rb").read()
         assert tool_lines(args, path, buf) == expected_lines(raw, **kw), (key, buf)
+
+
+@pytest.mark.parametrize("window,threads", [(200, 2), (333, 3), (1000, 8), (5000, 5), (1 << 20, 1), (1 << 20, 7)])
+def test_pieces_of_a_mapped_file_give_the_sequential_parse(files, window, threads):
+    """a plain file is mapped and parsed in pieces that start at GUESSED record starts (aln_main.cpp: read_everything);
+    a piece counts only if the parse before it stopped exactly there.  Tiny windows put guesses everywhere: into
+    multi-line records, onto quality lines that begin with '@', into FASTA records inside a FASTQ file, behind the
+    truncated record that ends the input."""
+    for key, args, kw in (("odd", [], {}), ("fa", [], {}), ("fa", ["-Y", "-q", "30"], {"casava": True, "trim_qual": 30}),
+                          ("fq", [], {}), ("fq", ["-B", "6", "-Y", "-q", "15"], {"barcode": 6, "casava": True, "trim_qual": 15})):
+        path = files[key]
+        raw = open(path, "rb").read()
+        assert tool_lines(args, path, window=window, threads=threads) == expected_lines(raw, **kw), (key, window, threads)
+
+
+def test_quality_lines_that_look_like_headers(tmp_path):
+    """four-line FASTQ whose quality strings begin with '@' and '+' and '>' -- the shapes the boundary guess has to survive"""
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "tricky.fq")
+    with open(path, "wb") as f:
+        for i in range(3000):
+            L = int(rng.integers(30, 90))
+            s = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L, p=[.24, .24, .24, .24, .04]))
+            q = bytearray(int(x) for x in rng.integers(35, 74, L))
+            q[0] = b"@+>I"[i % 4]
+            if i % 5 == 0:
+                q[1] = 64                                  # "@@..."
+            f.write(b"@t%d %d:N\n" % (i, i % 3) + s + b"\n+" + (b"t%d" % i if i % 2 else b"") + b"\n" + bytes(q) + b"\n")
+    raw = open(path, "rb").read()
+    want = expected_lines(raw, trim_qual=20)
+    assert want[-1].startswith("reads 3000 ")
+    for window, threads in ((400, 4), (4096, 8), (1 << 16, 3), (None, None)):
+        assert tool_lines(["-q", "20"], path, window=window, threads=threads) == want, (window, threads)
 
 
 def test_golden_reads_parse_like_the_test_library():
