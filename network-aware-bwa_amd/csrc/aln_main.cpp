@@ -12,7 +12,7 @@
 // (bwtaln.c:104-105).  We keep the chunk boundaries as bookkeeping, give the GPU runs of consecutive chunks whose clamp
 // comes out the same (normally: everything that was read), and split only where it differs.
 //
-// Not taken over: -b/-0/-1/-2 (BAM input is outside this path) are refused.  One deliberate difference:
+// BAM input (-b, with -0/-1/-2) is read through zlib as the reference does (bamlite.h:7-11).  One deliberate difference:
 // resuming into an existing -f file (attempt_recovery, bwtaln.c:259-296) continues the record stream; the reference
 // writes a second copy of the 64-byte header at the resume point (bwtaln.c:387 is unconditional), which makes the
 // resumed file unreadable.  A resumed file here equals the file of an uninterrupted run.
@@ -201,14 +201,104 @@ struct Batch {                      /* what one GPU call (or a few) consumes */
 	int n() const { return (int)off.size() - 1; }
 };
 
+/* BAM records as bwa_read_bam takes them (bwaseqio.c:125-168 over bamlite.c:73-155): any gzip container (BGZF is a
+ * series of gzip members; the reference opens BAM with gzopen as well, bamlite.h:7-11), header skipped, then per record the
+ * flag, the 4-bit bases and the qualities.  `which`: 1 = first reads of pairs, 2 = second reads, 4 = unpaired (bwtaln.c:167-172). */
+struct BamReader {
+	gzFile fp = nullptr;
+	int which = 7;
+	std::vector<unsigned char> rec;
+
+	bool get(void *dst, size_t n) { return n == 0 || gzread(fp, dst, (unsigned)n) == (int)n; }
+	bool skip(size_t n) { unsigned char tmp[4096]; while (n) { const size_t k = n < sizeof tmp ? n : sizeof tmp; if (!get(tmp, k)) return false; n -= k; } return true; }
+	bool open(const char *fn)
+	{
+		fp = strcmp(fn, "-") == 0 ? gzdopen(fileno(stdin), "r") : gzopen(fn, "r");
+		if (!fp) return false;
+		gzbuffer(fp, 1 << 20);
+		char magic[4]; int32_t l_text = 0, n_ref = 0;
+		if (!get(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { fprintf(stderr, "[nabwa_aln] invalid BAM binary header (this is not a BAM file).\n"); return false; }
+		if (!get(&l_text, 4) || l_text < 0 || !skip((size_t)l_text) || !get(&n_ref, 4) || n_ref < 0) return false;
+		for (int32_t i = 0; i < n_ref; ++i) { int32_t l_name = 0; if (!get(&l_name, 4) || l_name < 0 || !skip((size_t)l_name + 4)) return false; }
+		return true;
+	}
+	void close() { if (fp) gzclose(fp); fp = nullptr; }
+	/* the next record that passes the selection: flag, number of bases, pointers to 4-bit bases and qualities; false at the end */
+	bool next(unsigned *flag, int *l_seq, const unsigned char **bases, const unsigned char **qual)
+	{
+		for (;;) {
+			int32_t block = 0; uint32_t x[8];
+			if (!get(&block, 4) || block < 32 || !get(x, 32)) return false;
+			rec.resize((size_t)block - 32 + 1);
+			if (!get(rec.data(), (size_t)block - 32)) return false;
+			const unsigned l_qname = x[2] & 0xffu, n_cigar = x[3] & 0xffffu; *flag = x[3] >> 16; *l_seq = (int)x[4];
+			const size_t need = (size_t)l_qname + 4u * n_cigar + ((size_t)*l_seq + 1) / 2 + (size_t)*l_seq;
+			if (*l_seq < 0 || need > (size_t)block - 32) return false;
+			const bool paired = *flag & 1u;
+			if (!(((which & 1) && paired && (*flag & 64u)) || ((which & 2) && paired && (*flag & 128u)) || ((which & 4) && !paired))) continue;
+			*bases = rec.data() + l_qname + 4u * n_cigar; *qual = *bases + ((size_t)*l_seq + 1) / 2;
+			return true;
+		}
+	}
+};
+
 struct Source {                     /* bwa_read_seq (bwaseqio.c:172-252) minus the bwa_seq_t records */
 	Fastx fx;
 	int mode, trim_qual;
 	long n_trimmed = 0, n_tot = 0;
 
+	BamReader *bam = nullptr;           /* -b: records come from here instead of fx */
+
+	/* bwa_trim_read (bwaseqio.c:110-123) on ASCII qualities q[0..full) with the given offset: the length that is kept */
+	static int trimmed_len(const unsigned char *q, int full, int trim_qual, int shift)
+	{
+		int sum = 0, best = 0, best_l = full - 1;
+		for (int l = full - 1; l >= MIN_RDLEN - 1; --l) {
+			sum += trim_qual - ((int)q[l] - shift);
+			if (sum < 0) break;
+			if (sum > best) { best = sum; best_l = l; }
+		}
+		return best_l + 1;
+	}
+	void append(Batch *b, const uint8_t *fwd, int len)   /* fwd: codes of the read as sequenced; stored reversed / reverse-complemented */
+	{
+		const size_t at = b->seq.size();
+		b->seq.resize(at + len); b->rseq.resize(at + len);
+		uint8_t *const ps = b->seq.data() + at, *const pr = b->rseq.data() + at;
+		const uint8_t flip = (mode & NABWA_MODE_COMPREAD) ? 3 : 0;
+		for (int i = 0; i < len; ++i) { const uint8_t c = fwd[len - 1 - i]; ps[i] = c; pr[i] = c < 4 ? c ^ flip : c; }
+		if (b->n() % REF_CHUNK == 0) b->chunk_max_len.push_back(0);
+		if (len > b->chunk_max_len.back()) b->chunk_max_len.back() = len;
+		b->off.push_back((int64_t)(at + len));
+	}
+	/* bwa_read_bam (bwaseqio.c:125-168): no barcode, no Casava filter, empty reads are kept */
+	bool one_bam(Batch *b)
+	{
+		static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };
+		unsigned flag; int l; const unsigned char *s4, *q;
+		if (!bam->next(&flag, &l, &s4, &q)) return false;
+		if (!b) return true;
+		if (l > 65535) { fprintf(stderr, "[nabwa_aln] a read is longer than 65535 bases\n"); exit(1); }
+		std::vector<uint8_t> code(l ? l : 1), qa(l ? l : 1);
+		for (int i = 0; i < l; ++i) {
+			code[i] = nt16_nt4[s4[i >> 1] >> 4 * (1 - (i & 1)) & 0xf];
+			qa[i] = (uint8_t)((int)q[i] + 33 < 126 ? q[i] + 33 : 126);
+		}
+		if (flag & 16u) {                                           /* stored reverse-complemented: back to the read as sequenced */
+			std::reverse(code.begin(), code.begin() + l); std::reverse(qa.begin(), qa.begin() + l);
+			for (int i = 0; i < l; ++i) if (code[i] < 4) code[i] = 3 - code[i];
+		}
+		int len = l;
+		if (trim_qual >= 1) { len = trimmed_len(qa.data(), l, trim_qual, 33); n_trimmed += l - len; }
+		n_tot += l;
+		append(b, code.data(), len);
+		return true;
+	}
+
 	/* reads the next record that survives the filters; appends it to b unless b is null (skipping) */
 	bool one(Batch *b)
 	{
+		if (bam) return one_bam(b);
 		const int l_bc = (int)((unsigned)mode >> 24);
 		for (;;) {
 			if (fx.next() < 0) return false;
@@ -455,9 +545,25 @@ static const Opt OPTS[] = {
 	{ 'N', nullptr, NABWA_MODE_NONSTOP, 0, nullptr, "do not stop at the best score: every hit within the allowed differences" },
 	{ 'I', nullptr, MODE_IL13, 0, nullptr, "qualities are Illumina 1.3+ (offset 64)" },
 	{ 'Y', nullptr, MODE_CFY, 0, nullptr, "drop reads whose Casava comment says 'filtered'" },
-	{ 'b', nullptr, 0x20, 0, nullptr, nullptr }, { '0', nullptr, 0x40, 0, nullptr, nullptr },      /* BAM input: accepted by the parser, refused below */
-	{ '1', nullptr, 0x80, 0, nullptr, nullptr }, { '2', nullptr, 0x100, 0, nullptr, nullptr },
+	{ 'b', nullptr, 0x20, 0, nullptr, "the input is BAM (BGZF or plain gzip)" },
+	{ '0', nullptr, 0x40, 0, nullptr, "with -b: unpaired reads only" },
+	{ '1', nullptr, 0x80, 0, nullptr, "with -b: first reads of pairs only" },
+	{ '2', nullptr, 0x100, 0, nullptr, "with -b: second reads of pairs only" },
 };
+
+/* bwa_open_reads (bwtaln.c:164-176): BAM with the read selection of -0 -1 -2 (none given: all), or FASTA/FASTQ */
+static bool open_source(Source &src, BamReader &bam, const nabwa_gap_opt_t &opt, const char *fn)
+{
+	src.mode = opt.mode; src.trim_qual = opt.trim_qual;
+	if (opt.mode & 0x20) {
+		int which = ((opt.mode & 0x40) ? 4 : 0) | ((opt.mode & 0x80) ? 1 : 0) | ((opt.mode & 0x100) ? 2 : 0);
+		bam.which = which ? which : 7;
+		if (!bam.open(fn)) return false;
+		src.bam = &bam;
+		return true;
+	}
+	return src.fx.open(fn);
+}
 
 static int usage(const nabwa_gap_opt_t *o)
 {
@@ -469,7 +575,7 @@ static int usage(const nabwa_gap_opt_t *o)
 		else if (d.letter == 'n') snprintf(dflt, sizeof dflt, " [%.2f]", o->fnr);
 		fprintf(stderr, "         -%c %-5s %s%s\n", d.letter, d.arg ? d.arg : "", d.help, dflt);
 	}
-	fprintf(stderr, "         (-b -0 -1 -2: BAM input is not available in this tool)\n\n");
+	fprintf(stderr, "\n");
 	fprintf(stderr, "Environment: NABWA_DEVICE (GPU ordinal, 0), NABWA_ALN_BATCH (reads per GPU batch, 4194304)\n\n");
 	return 1;
 }
@@ -504,7 +610,6 @@ int main(int argc, char *argv[])
 	}
 	if (opte > 0) { opt.max_gape = opte; opt.mode &= ~NABWA_MODE_GAPE; }
 	if (optind + 2 > argc) return usage(&opt);
-	if (opt.mode & MODE_BAM_ANY) { fprintf(stderr, "[nabwa_aln] BAM input (-b -0 -1 -2) is not available in this tool\n"); return 1; }
 	if ((int)((unsigned)opt.mode >> 24) > MAX_BCLEN) { fprintf(stderr, "[nabwa_aln] the maximum barcode length is %d.\n", MAX_BCLEN); return 1; }
 	if (opt.fnr > 0.0f)
 		for (int i = 17, k = 0; i <= 250; ++i) {
@@ -519,9 +624,8 @@ int main(int argc, char *argv[])
 	// tests check this file's share of the work against an independent restatement, and times the parser.
 	if (getenv("NABWA_ALN_PARSE_ONLY")) {
 		const bool per_read = atoi(getenv("NABWA_ALN_PARSE_ONLY")) >= 2;
-		Source src;
-		src.mode = opt.mode; src.trim_qual = opt.trim_qual;
-		if (!src.fx.open(reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
+		Source src; BamReader bam;
+		if (!open_source(src, bam, opt, reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
 		auto fnv = [](uint64_t h, const uint8_t *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; };
 		uint64_t all = 1469598103934665603ull; long n_reads = 0, n_bases = 0;
 		Assembler as;
@@ -543,6 +647,10 @@ int main(int argc, char *argv[])
 		return 0;
 	}
 
+	// ---- the reads: nothing is written before they can be opened
+	Source src; BamReader bam;
+	if (!open_source(src, bam, opt, reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
+
 	// ---- the index: no GPU, no output
 	nabwa_index_t *ix = nullptr;
 	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;
@@ -561,9 +669,6 @@ int main(int argc, char *argv[])
 	}
 	if (!resume.found && fwrite(&opt, sizeof(opt), 1, out) != 1) { perror("[nabwa_aln] write"); return 2; }
 
-	Source src;
-	src.mode = opt.mode; src.trim_qual = opt.trim_qual;
-	if (!src.fx.open(reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
 	if (resume.skip) {
 		fprintf(stderr, "[nabwa_aln] skipping %d sequences.\n", resume.skip);
 		for (int i = 0; i < resume.skip; ++i)
@@ -644,7 +749,7 @@ int main(int argc, char *argv[])
 	}
 	reader.join();
 	if (src.n_tot && opt.trim_qual >= 1) fprintf(stderr, "[nabwa_aln] %.1f%% bases are trimmed.\n", 100.0 * src.n_trimmed / src.n_tot);
-	src.fx.close();
+	src.fx.close(); bam.close();
 	nabwa_index_destroy(ix);
 	if (fflush(out) != 0) status = status ? status : 2;
 	if (out != stdout) fclose(out);

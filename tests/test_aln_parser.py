@@ -216,6 +216,71 @@ def test_quality_lines_that_look_like_headers(tmp_path):
         assert tool_lines(["-q", "20"], path, window=window, threads=threads) == want, (window, threads)
 
 
+def expected_bam_lines(recs, which=7, trim_qual=0):
+    """bwa_read_bam (bwaseqio.c:125-168) restated on the records a BAM was written from"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    lines, n_bases, total = [], 0, FNV0
+    for name, flag, seq, qual in recs:
+        paired = flag & 1
+        if not ((which & 1 and paired and flag & 64) or (which & 2 and paired and flag & 128) or (which & 4 and not paired)):
+            continue
+        c = [code.get(ch, 4) for ch in seq]
+        q = [min(x + 33, 126) for x in qual]
+        if flag & 16:
+            c = [3 - x if x < 4 else x for x in reversed(c)]
+            q = list(reversed(q))
+        ln = len(c)
+        if trim_qual >= 1:
+            s, best, best_l = 0, 0, ln - 1
+            for l in range(ln - 1, 33, -1):
+                s += trim_qual - (q[l] - 33)
+                if s < 0:
+                    break
+                if s > best:
+                    best, best_l = s, l
+            ln = best_l + 1
+        ln = max(ln, 0)
+        rev = bytes(reversed(c[:ln]))
+        rc = bytes(3 - x if x < 4 else x for x in rev)
+        h = fnv(fnv(FNV0, rev), rc)
+        lines.append("%d %016x" % (ln, h))
+        total = fnv(total, h.to_bytes(8, "little"))
+        n_bases += ln
+    lines.append("reads %d bases %d fnv %016x" % (len(lines), n_bases, total))
+    return lines
+
+
+@pytest.mark.parametrize("args,which,trim", [(["-b"], 7, 0), (["-b", "-0"], 4, 0), (["-b", "-1", "-q", "15"], 1, 15), (["-b", "-2"], 2, 0),
+                                             (["-b", "-1", "-2", "-q", "30"], 3, 30)], ids=lambda x: "_".join(x) if isinstance(x, list) else None)
+def test_bam_records_selection_strand_and_trimming(tmp_path, args, which, trim):
+    recs = CLI.bam_records(np.random.default_rng(8))
+    for members in (1, 5):
+        path = str(tmp_path / ("r%d.bam" % members))
+        CLI.write_bam(path, recs, members)
+        assert tool_lines(args, path) == expected_bam_lines(recs, which, trim), members
+
+
+@pytest.mark.skipif(not os.path.exists(CLI.REFBIN), reason="compiled reference not built")
+def test_the_bam_restatement_against_the_compiled_reference(tmp_path):
+    """pins expected_bam_lines' reading of bwa_read_bam to the reference itself, on the CPU: the reference's .sai for a BAM equals
+    its .sai for the FASTQ that holds the reads as the restatement says the BAM path sees them (turned back, qualities as
+    capped ASCII) -- with and without trimming.  (Empty reads left out: the FASTQ path drops them, the BAM path keeps them.)"""
+    recs = [r for r in CLI.bam_records(np.random.default_rng(8), 300) if len(r[2])]
+    bam, fq = str(tmp_path / "r.bam"), str(tmp_path / "r.fq")
+    CLI.write_bam(bam, recs, 3)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    with open(fq, "w") as f:
+        for name, flag, seq, qual in recs:
+            q = [min(x + 33, 126) for x in qual]
+            if flag & 16:
+                seq, q = "".join(comp[c] for c in reversed(seq)), list(reversed(q))
+            f.write("@%s\n%s\n+\n%s\n" % (name, seq, "".join(chr(x) for x in q)))
+    for extra in ([], ["-q", "15"], ["-q", "30", "-n", "2"]):
+        a = CLI.run_ref(["-b"] + extra + [T.TOY, bam])
+        b = CLI.run_ref(extra + [T.TOY, fq])
+        assert len(a) > 64 + 4 * len(recs) and a[64:] == b[64:], extra
+
+
 def test_golden_reads_parse_like_the_test_library():
     """and the same against tests/nabwa_testlib.py's reader, which the parity tests feed the GPU from"""
     fq = os.path.join(T.GOLDEN, "reads_se.fq")

@@ -160,6 +160,66 @@ def test_chunks_with_different_gap_open_clamps(tmp_path):
     assert got == want
 
 
+def write_bam(path, recs, members=1):
+    """an unaligned BAM (one @RG-less header, no references) of (name, flag, sequence, phred list) records, as a gzip stream of
+    `members` members (BGZF is a series of gzip members; the reference reads BAM through gzopen, bamlite.h:7-11)"""
+    import struct
+    nt16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.0\tSO:unsorted\n"
+    body = [b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chrT\x00" + struct.pack("<i", 1000)]
+    for name, flag, seq, qual in recs:
+        qn = name.encode() + b"\x00"
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, c in enumerate(seq):
+            packed[i >> 1] |= nt16[c] << (4 if i % 2 == 0 else 0)
+        core = struct.pack("<iiIIiiii", -1, -1, (4680 << 16) | (0 << 8) | len(qn), (flag << 16) | 0, len(seq), -1, -1, 0)
+        data = qn + bytes(packed) + bytes(qual) + b"XYZ\x00" * (len(name) % 2)       # sometimes a tag-like tail
+        body.append(struct.pack("<i", len(core) + len(data)) + core + data)
+    blob = b"".join(body)
+    with open(path, "wb") as f:
+        step = (len(blob) + members - 1) // members
+        for i in range(0, len(blob), step):
+            f.write(gzip.compress(blob[i:i + step]))
+
+
+def bam_records(rng, n=500):
+    genome = "".join(s for _, s in T.read_fasta(T.TOY + ".fa")).replace("N", "A")
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(0, 3)) * 0 + int(rng.choice([0, 36, 50, 76, 100, 101]))
+        p = int(rng.integers(0, len(genome) - 120))
+        s = list(genome[p:p + L])
+        for j in range(L):
+            if rng.random() < 0.01:
+                s[j] = "ACGTN"[int(rng.integers(5))]
+        flag = [4, 4 | 16, 1 | 64 | 4, 1 | 128 | 4, 1 | 64 | 16, 1 | 128][i % 6]
+        if flag & 16:
+            s = [comp[c] for c in reversed(s)]                       # stored the way an aligner stores a reverse-strand read
+        q = [int(x) for x in rng.integers(2, 41, L)]
+        for j in range(L - int(rng.integers(0, L // 2 + 1)), L):
+            q[j] = int(rng.integers(2, 12))
+        if i % 50 == 0:
+            q = [255] * L                                            # qualities absent
+        recs.append(("b%04d" % i, flag, "".join(s), q))
+    return recs
+
+
+@pytest.mark.skipif(not os.path.exists(REFBIN), reason="compiled reference did not travel")
+def test_bam_input_equals_the_compiled_reference(tmp_path):
+    """-b with the read selections -0 -1 -2 and trimming: reverse-strand records are turned back, empty reads stay in"""
+    recs = bam_records(np.random.default_rng(8))
+    one, many = str(tmp_path / "r.bam"), str(tmp_path / "r_members.bam")
+    write_bam(one, recs)
+    write_bam(many, recs, members=7)
+    for args, path in ((["-b"], one), (["-b"], many), (["-b", "-0"], one), (["-b", "-1", "-q", "15"], many), (["-b", "-2"], one),
+                       (["-b", "-1", "-2"], one), (["-b", "-0", "-q", "25", "-n", "3"], one)):
+        want = run_ref(args + [T.TOY, path])
+        rc, got, err = run_tool(args + [T.TOY, path])
+        assert rc == 0, err
+        assert got == want, args
+
+
 def test_resume_into_an_interrupted_file_and_final_rename(tmp_path):
     fq = os.path.join(T.GOLDEN, "reads_se.fq")
     with open(os.path.join(T.GOLDEN, "se_k1R5.sai"), "rb") as f:
@@ -184,8 +244,8 @@ def test_resume_into_an_interrupted_file_and_final_rename(tmp_path):
 
 def test_refusals(tmp_path):
     fq = os.path.join(T.GOLDEN, "reads_se.fq")
-    rc, out, err = run_tool(["-b", T.TOY, fq])
-    assert rc == 1 and out == b"" and "BAM input" in err
+    rc, out, err = run_tool(["-b", T.TOY, fq])                 # -b on something that is not BAM
+    assert rc == 2 and out == b"" and "not a BAM file" in err
     rc, out, err = run_tool([T.TOY])
     assert rc == 1 and "Usage" in err
     rc, out, err = run_tool([str(tmp_path / "no_such_index"), fq])
