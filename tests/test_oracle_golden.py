@@ -92,6 +92,23 @@ def test_global_dp(lib, vec):
         assert list(cig[:ncig.value]) == list(want), t
 
 
+def test_global_dp_on_the_references_own_demo(lib):
+    """the one known answer the reference ships for this path: the global alignment of its stdaln demo
+    (stdaln.c:1048,1056-1058, built with -DSTDALN_MAIN, under aln_param_blast = {5, 2, 2, aln_sm_blast, 5, 50},
+    stdaln.c:214-226) prints `>1,34 1,32 1D16M1D16M`"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+    def enc(s):
+        return np.array([code.get(c.upper(), 4) for c in s], np.uint8)
+    sm = np.array([1, -3, -3, -3, -2, -3, 1, -3, -3, -2, -3, -3, 1, -3, -2, -3, -3, -3, 1, -2, -2, -2, -2, -2, -2], np.int32)
+    r, q = enc("CGTGCGATGCactgCATACGGCTCGCCTAGATCA"), enc("AAGGGATGCTCTGCATCGgCTCGGCTAGCTGT")
+    assert (len(r), len(q)) == (34, 32)
+    cig = (C.c_uint32 * 64)()
+    ncig = C.c_int()
+    lib.orc_global(T.ptr(r), len(r), T.ptr(q), len(q), 5, 2, 2, T.ptr(sm), 5, 50, cig, C.byref(ncig))
+    assert "".join("%d%s" % (c >> 4, "MID"[c & 15]) for c in cig[:ncig.value]) == "1D16M1D16M"
+
+
 @pytest.mark.parametrize("name", ["default", "adna", "q20"])
 def test_sam_parity(lib, ix, name):
     """aln2seq (RNG in record order) -> SA lookup -> mapQ -> gap refinement -> MD/NM/XA, against samse output."""
