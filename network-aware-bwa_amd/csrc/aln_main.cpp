@@ -30,7 +30,9 @@
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
+#include <chrono>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -576,7 +578,7 @@ static int usage(const nabwa_gap_opt_t *o)
 		fprintf(stderr, "         -%c %-5s %s%s\n", d.letter, d.arg ? d.arg : "", d.help, dflt);
 	}
 	fprintf(stderr, "\n");
-	fprintf(stderr, "Environment: NABWA_DEVICE (GPU ordinal, 0), NABWA_ALN_BATCH (reads per GPU batch, 4194304)\n\n");
+	fprintf(stderr, "Environment: NABWA_DEVICES (GPUs to use, e.g. 0,1,2,3; default NABWA_DEVICE or 0), NABWA_ALN_BATCH (reads per GPU batch, 4194304),\n             NABWA_ALN_THREADS (parser threads for plain input, 8)\n\n");
 	return 1;
 }
 
@@ -651,14 +653,27 @@ int main(int argc, char *argv[])
 	Source src; BamReader bam;
 	if (!open_source(src, bam, opt, reads)) { fprintf(stderr, "[nabwa_aln] fail to open file '%s'. Abort!\n", reads); return 2; }
 
-	// ---- the index: no GPU, no output
-	nabwa_index_t *ix = nullptr;
-	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;
+	// ---- the index, one replica per GPU of NABWA_DEVICES ("0,1,2,3"; default: NABWA_DEVICE or 0): no GPU, no output
+	std::vector<int> devices;
+	if (getenv("NABWA_DEVICES")) {
+		for (const char *q = getenv("NABWA_DEVICES"); *q; ) { char *e; const long d = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)d); q = *e == ',' ? e + 1 : e; }
+	}
+	if (devices.empty()) devices.push_back(getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0);
 	const std::string sa_path = std::string(prefix) + ".sa", rsa_path = std::string(prefix) + ".rsa";
 	const int with_sa = access(sa_path.c_str(), R_OK) == 0 && access(rsa_path.c_str(), R_OK) == 0;   /* optional: lets the library build its text-mode companions */
-	if (nabwa_index_load(prefix, device, with_sa, 0, &ix) != NABWA_OK) {
-		fprintf(stderr, "[nabwa_aln] cannot set up the index on GPU %d: %s\n", device, nabwa_last_error());
-		return 2;
+	std::vector<nabwa_index_t*> ixs(devices.size(), nullptr);
+	{
+		std::vector<std::string> err(devices.size());
+		std::vector<std::thread> th;
+		for (size_t g = 0; g < devices.size(); ++g)
+			th.emplace_back([&, g]() { if (nabwa_index_load(prefix, devices[g], with_sa, 0, &ixs[g]) != NABWA_OK) { err[g] = nabwa_last_error(); ixs[g] = nullptr; } });
+		for (auto &x : th) x.join();
+		for (size_t g = 0; g < devices.size(); ++g)
+			if (!ixs[g]) {
+				fprintf(stderr, "[nabwa_aln] cannot set up the index on GPU %d: %s\n", devices[g], err[g].c_str());
+				for (nabwa_index_t *p : ixs) if (p) nabwa_index_destroy(p);
+				return 2;
+			}
 	}
 
 	FILE *out = stdout;
@@ -696,61 +711,108 @@ int main(int argc, char *argv[])
 		cv.notify_all();
 	});
 
+	// ---- one worker per GPU takes the batches as they come; the records leave in batch order (the .sai is positional)
 	long tot = 0; int status = 0;
-	std::vector<int32_t> n_aln, max_entries;
-	std::vector<nabwa_aln1_t> rows;
-	std::vector<char> obuf;
-	for (;;) {
-		std::unique_ptr<Batch> b;
-		{
-			std::unique_lock<std::mutex> lk(mu);
-			cv.wait(lk, [&] { return !ready.empty() || done; });
-			if (ready.empty()) break;
-			b = std::move(ready.front()); ready.pop_front();
-			cv.notify_all();
-		}
-		if (status) continue;                                             /* drain the reader after a failure */
-		// runs of chunks with the same max_gapo clamp -> one GPU call each
-		const int n_chunks = (int)b->chunk_max_len.size();
+	/* a batch through one GPU: runs of chunks with the same max_gapo clamp -> one call each; the record stream (n_aln, then the
+	 * rows; bwtaln.c:242-246) of the whole batch into obuf */
+	auto search_batch = [&](nabwa_index_t *ix, const Batch &b, std::vector<char> &obuf) -> bool {
+		std::vector<int32_t> n_aln, max_entries;
+		std::vector<nabwa_aln1_t> rows;
+		obuf.clear();
+		const int n_chunks = (int)b.chunk_max_len.size();
 		auto clamp_of = [&](int ch) {
-			const int md = opt.fnr > 0.0f ? nabwa_cal_maxdiff(b->chunk_max_len[ch], 0.02, opt.fnr) : opt.max_diff;
+			const int md = opt.fnr > 0.0f ? nabwa_cal_maxdiff(b.chunk_max_len[ch], 0.02, opt.fnr) : opt.max_diff;
 			return md < opt.max_gapo ? md : opt.max_gapo;
 		};
-		for (int c0 = 0; c0 < n_chunks && !status; ) {
+		for (int c0 = 0; c0 < n_chunks; ) {
 			int c1 = c0 + 1;
 			while (c1 < n_chunks && clamp_of(c1) == clamp_of(c0)) ++c1;
-			const int r0 = c0 * REF_CHUNK, r1 = c1 * REF_CHUNK < b->n() ? c1 * REF_CHUNK : b->n(), n = r1 - r0;
+			const int r0 = c0 * REF_CHUNK, r1 = c1 * REF_CHUNK < b.n() ? c1 * REF_CHUNK : b.n(), n = r1 - r0;
 			std::vector<int64_t> off(n + 1);
-			const int64_t base = b->off[r0];
-			for (int i = 0; i <= n; ++i) off[i] = b->off[r0 + i] - base;
+			const int64_t base = b.off[r0];
+			for (int i = 0; i <= n; ++i) off[i] = b.off[r0 + i] - base;
 			n_aln.resize(n); max_entries.resize(n);
 			int64_t cap = (int64_t)n + n / 4 + 1024, n_rows = 0;
 			int rc;
 			for (;;) {
 				rows.resize(cap);
-				rc = nabwa_cal_sa_reg_gap(ix, &opt, n, off.data(), b->seq.data() + base, b->rseq.data() + base, 0,
+				rc = nabwa_cal_sa_reg_gap(ix, &opt, n, off.data(), b.seq.data() + base, b.rseq.data() + base, 0,
 										  n_aln.data(), rows.data(), cap, &n_rows, max_entries.data());
 				if (rc != NABWA_ECAP) break;
 				cap = 0; for (int i = 0; i < n; ++i) cap += n_aln[i];
 			}
-			if (rc != NABWA_OK) { fprintf(stderr, "[nabwa_aln] GPU search failed: %s\n", nabwa_last_error()); status = 2; break; }
-			// the record stream: n_aln, then the rows (bwtaln.c:242-246)
-			obuf.resize((size_t)n * 4 + (size_t)n_rows * sizeof(nabwa_aln1_t));
-			char *w = obuf.data(); const nabwa_aln1_t *r = rows.data();
+			if (rc != NABWA_OK) { fprintf(stderr, "[nabwa_aln] GPU search failed: %s\n", nabwa_last_error()); return false; }
+			const size_t at = obuf.size();
+			obuf.resize(at + (size_t)n * 4 + (size_t)n_rows * sizeof(nabwa_aln1_t));
+			char *w = obuf.data() + at; const nabwa_aln1_t *r = rows.data();
 			for (int i = 0; i < n; ++i) {
 				memcpy(w, &n_aln[i], 4); w += 4;
 				memcpy(w, r, (size_t)n_aln[i] * sizeof(nabwa_aln1_t)); w += (size_t)n_aln[i] * sizeof(nabwa_aln1_t); r += n_aln[i];
 			}
-			if (fwrite(obuf.data(), 1, obuf.size(), out) != obuf.size()) { perror("[nabwa_aln] write"); status = 2; break; }
-			tot += n;
-			fprintf(stderr, "[nabwa_aln] %ld sequences have been processed.\n", tot);
 			c0 = c1;
 		}
+		return true;
+	};
+	struct Done { std::vector<char> bytes; int n_reads = 0; bool ok = false; };
+	std::mutex omu; std::condition_variable ocv;
+	std::map<long, Done> finished;            /* batch number -> its records, until the writer gets to it */
+	long next_in = 0, next_out = 0; bool failed = false;
+	std::vector<std::thread> workers;
+	for (size_t g = 0; g < ixs.size(); ++g)
+		workers.emplace_back([&, g]() {
+			for (;;) {
+				std::unique_ptr<Batch> b; long no;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [&] { return !ready.empty() || done; });
+					if (ready.empty()) return;
+					b = std::move(ready.front()); ready.pop_front(); no = next_in++;
+					cv.notify_all();
+				}
+				Done d; d.n_reads = b->n();
+				{	/* not more than two finished batches per GPU wait for the writer */
+					std::unique_lock<std::mutex> lk(omu);
+					ocv.wait(lk, [&] { return failed || no - next_out < 2 * (long)ixs.size() + 2; });
+					if (failed) continue;                                 /* drain the reader after a failure */
+				}
+				d.ok = search_batch(ixs[g], *b, d.bytes);
+				std::unique_lock<std::mutex> lk(omu);
+				if (!d.ok) failed = true;
+				finished.emplace(no, std::move(d));
+				ocv.notify_all();
+			}
+		});
+	{	/* the writer: this thread */
+		size_t alive = workers.size();
+		(void)alive;
+		for (;;) {
+			Done d;
+			{
+				std::unique_lock<std::mutex> lk(omu);
+				bool readers_done = false;
+				ocv.wait_for(lk, std::chrono::milliseconds(50), [&] { return finished.count(next_out) != 0 || failed; });
+				if (finished.count(next_out) == 0) {
+					if (failed) { status = 2; break; }
+					lk.unlock();
+					{ std::unique_lock<std::mutex> lk2(mu); readers_done = done && ready.empty() && next_in == next_out; }
+					if (readers_done) break;
+					continue;
+				}
+				d = std::move(finished[next_out]); finished.erase(next_out); ++next_out;
+				ocv.notify_all();
+			}
+			if (!d.ok) { status = 2; break; }
+			if (fwrite(d.bytes.data(), 1, d.bytes.size(), out) != d.bytes.size()) { perror("[nabwa_aln] write"); status = 2; std::unique_lock<std::mutex> lk(omu); failed = true; ocv.notify_all(); break; }
+			tot += d.n_reads;
+			fprintf(stderr, "[nabwa_aln] %ld sequences have been processed.\n", tot);
+		}
+		{ std::unique_lock<std::mutex> lk(omu); if (status) failed = true; ocv.notify_all(); }
 	}
+	for (auto &w : workers) w.join();
 	reader.join();
 	if (src.n_tot && opt.trim_qual >= 1) fprintf(stderr, "[nabwa_aln] %.1f%% bases are trimmed.\n", 100.0 * src.n_trimmed / src.n_tot);
 	src.fx.close(); bam.close();
-	nabwa_index_destroy(ix);
+	for (nabwa_index_t *p : ixs) nabwa_index_destroy(p);
 	if (fflush(out) != 0) status = status ? status : 2;
 	if (out != stdout) fclose(out);
 	if (status) return status;

@@ -157,6 +157,11 @@ def test_chunks_with_different_gap_open_clamps(tmp_path):
     rc, got, err = run_tool(args[:-1] + [T.TOY, fa], env={"NABWA_ALN_BATCH": str(0x40000)})
     assert rc == 0, err
     assert got == want
+    # and with two index replicas (NABWA_DEVICES: one worker per entry; here both on GPU 0) taking the batches as they come:
+    # the records still leave in input order
+    rc, got, err = run_tool(args[:-1] + [T.TOY, fa], env={"NABWA_ALN_BATCH": str(0x40000), "NABWA_DEVICES": "0,0"})
+    assert rc == 0, err
+    assert got == want
 
 
 def write_bam(path, recs, members=1):
