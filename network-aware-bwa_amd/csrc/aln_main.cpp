@@ -783,8 +783,6 @@ int main(int argc, char *argv[])
 			}
 		});
 	{	/* the writer: this thread */
-		size_t alive = workers.size();
-		(void)alive;
 		for (;;) {
 			Done d;
 			{
