@@ -281,6 +281,24 @@ def test_the_bam_restatement_against_the_compiled_reference(tmp_path):
         assert len(a) > 64 + 4 * len(recs) and a[64:] == b[64:], extra
 
 
+def test_reads_from_standard_input(files, tmp_path):
+    """'-' as the file name: FASTQ (plain and gzip) and BAM arrive through a pipe"""
+    env = dict(os.environ, NABWA_ALN_PARSE_ONLY="2")
+    for key in ("fq", "gz"):
+        raw = gzip.open(files[key], "rb").read() if key == "gz" else open(files[key], "rb").read()
+        with open(files[key], "rb") as f:
+            r = subprocess.run([TOOL, "-q", "15", "unused_prefix", "-"], stdin=f, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.split("\n")[:-1] == expected_lines(raw, trim_qual=15), key
+    recs = CLI.bam_records(np.random.default_rng(8), 120)
+    bam = str(tmp_path / "p.bam")
+    CLI.write_bam(bam, recs, 2)
+    with open(bam, "rb") as f:
+        r = subprocess.run([TOOL, "-b", "-1", "unused_prefix", "-"], stdin=f, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:-1] == expected_bam_lines(recs, 1, 0)
+
+
 def test_golden_reads_parse_like_the_test_library():
     """and the same against tests/nabwa_testlib.py's reader, which the parity tests feed the GPU from"""
     fq = os.path.join(T.GOLDEN, "reads_se.fq")
