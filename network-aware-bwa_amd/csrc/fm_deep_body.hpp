@@ -1,0 +1,466 @@
+// fm_deep_body.hpp -- kernel D: bwt_match_gap (bwtgap.c:104-266) for the DEEP searches, one search per wavefront.
+//
+// Why.  One read per lane (kernel S, fm_search.hip) is right while searches are short: 260 k of them hide each other's
+// latency.  A deep search (ancient-DNA options, reads with many differences: 10^5 .. 10^7 pops) is a dependent chain of
+// pops on ONE lane at 2-3 us each, needs an arena of up to max_entries + 1 entries of its own, and the launch waits for
+// the longest of them (round 1: 31 s for one read, 0.001 of the roofline).  Kernel D gives such a search a whole wave:
+//
+//   * The per-score LIFO stacks (bwtgap.c:46-79) are kept as they are in the reference -- one array per score -- but
+//     paged: 4 KB pages of 256 entries from ONE device-wide pool, linked per score level.  A search holds the pages its
+//     live entries need, nothing is sized for the worst case per lane, and nothing is re-run in growing tiers.
+//   * A ROUND pops the top W <= 64 entries of the lowest non-empty score s at once, one per lane (lane 0 = the top).
+//     Each lane runs its entry's CHAIN: pre-checks, hit test / exact tail, expansion; the matching child (same score,
+//     pushed last, hence the very next pop of the reference) continues the chain in registers; every other child has a
+//     score > s and is STAGED in the lane's own buffer.  Between two hits the reference's loop body is a pure function
+//     of the popped entry, so the W chains are independent -- this is where the parallelism comes from.
+//   * COMMIT restores the reference's order exactly: the reference would have run chain 0 to its end, then chain 1, ...
+//     so the staged children go to their score levels lane by lane (a prefix sum over the lanes gives every lane its
+//     slots; within a lane in chain order).  A chain that ends in a hit (the search state changes: max_diff, the width
+//     bounds through gap_shadow, best_score) or that fills its staging buffer invalidates the lanes above it: they are
+//     dropped (their entries are still on the stack) and popped again in the next round.
+//   * The live-entry count before every pop (bwtgap.c:139-140: statistic and cut-off) is exact: a lane tracks the count
+//     relative to its first pop and its peak, the prefix sum of the lanes' net changes gives the absolute values; when
+//     the cut-off falls inside a round, the lanes before it are committed and the search goes on one pop per round
+//     ("careful") until the cut-off is reached at a round's start.
+//
+// The same source is compiled for gfx950 (fm_deep.hip) and, with NABWA_EMU, as a CPU emulation of one wave
+// (tests/emu/, test infrastructure): see wave_spmd.hpp.
+#pragma once
+#include "fm_search.hpp"
+#include "wave_spmd.hpp"
+
+#define DEEP_PAGE_SH 8u
+#define DEEP_PAGE    (1u << DEEP_PAGE_SH)    /* entries per page */
+#define DEEP_NIL     0xffffffffu
+#define DEEP_NEWP    16u                       /* pages one commit can need at most (64 lanes x stage_k <= 48 entries) */
+#define DEEP_STAGE_MAX 48u
+#define DST_M 0
+#define DST_I 1
+#define DST_D 2
+#define DF_NONE 0
+#define DF_HIT  1
+#define DF_CONT 2
+#define DCL_MM 0u      /* child classes = the three scores a chain at score s pushes to: s + s_mm, s + s_gapo, s + s_gape */
+#define DCL_GO 1u
+#define DCL_GE 2u
+#define NABWA_ST_POOL   3   /* kernel D: the page pool ran dry under this read -- run it again in the guaranteed pass */
+#define NABWA_ST_HITCAP 4   /* more hit rows than the result rows given */
+
+struct DeepParams {
+	SearchParams S;                  // index, reads, width records, options, outputs (n_aln / max_ent / status / aln by work item or res_slot)
+	uint4 *pages;                    // the pool: n_pages x 256 entries x 16 B
+	uint32_t *page_prev;             // per page: the page below it in its level's stack
+	uint32_t n_pages;
+	unsigned int *page_bump;         // pages handed out so far (a wave keeps what it took and re-uses it for its next reads)
+	uint32_t *own;                   // per wave 2 x own_cap ids: the pages it holds, and those of them that are free
+	uint32_t own_cap;
+	uint4 *stage;                    // per wave [64][stage_k]: the children of the running round
+	uint32_t stage_k;
+	uint32_t NS;                     // score levels (LDS: 2 x NS + DEEP_NEWP words per wave)
+	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
+	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures
+};
+
+struct DeepLane { uint32_t k, l; int i, a, mm, go, ge, state, ldp; };
+
+#ifdef NABWA_EMU
+#define DEEP_FN static
+#else
+#define DEEP_FN __device__ __forceinline__
+#endif
+
+DEEP_FN uint4 deep_pack(uint32_t k, uint32_t l, int i, int ldp, int mm, int go, int ge, int state, int a, uint32_t cls)
+{
+	return make_uint4(k, l, (uint32_t)i | (uint32_t)ldp << 16,
+					  (uint32_t)mm | (uint32_t)go << 8 | (uint32_t)ge << 16 | (uint32_t)state << 24 | (uint32_t)a << 26 | cls << 27);
+}
+
+DEEP_FN void deep_unpack(const uint4 &r, DeepLane &e)
+{
+	e.k = r.x; e.l = r.y; e.i = (int)(r.z & 0xffffu); e.ldp = (int)(r.z >> 16);
+	e.mm = (int)(r.w & 0xffu); e.go = (int)(r.w >> 8 & 0xffu); e.ge = (int)(r.w >> 16 & 0xffu);
+	e.state = (int)(r.w >> 24 & 3u); e.a = (int)(r.w >> 26 & 1u);
+}
+
+DEEP_FN int deep_ctz64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+
+// One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
+DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
+#ifndef NABWA_EMU
+							, const int ln
+#endif
+							)
+{
+	const SearchParams &S = P.S;
+	uint32_t *const s_cnt = lds, *const s_top = lds + P.NS, *const s_newp = lds + 2 * P.NS;
+	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
+	uint4 *const stage = P.stage + (size_t)wave * 64 * P.stage_k;
+	const uint32_t K = P.stage_k;
+	uint32_t n_own = 0, n_free = 0;
+	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
+	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
+
+	LANE(uint32_t, tu);       // scratch for broadcasts
+	LANE(DeepLane, e);
+	LANE(bool, act);
+	LANE(int, flag);
+	LANE(uint32_t, np);       // children staged
+	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // of them, per (canonical) class
+	LANE(int, rel);           // live entries relative to the count before this lane's first pop
+	LANE(int, peak);          // the largest value `rel` had right before a pop
+	LANE(uint32_t, d); LANE(uint32_t, off);
+	LANE(int, nst);
+
+	// n_new pages into s_newp[]: from this wave's free ones first, then from the pool
+	auto alloc_pages = [&](uint32_t n_new) -> bool {
+		const uint32_t take = n_new < n_free ? n_new : n_free;
+		LANES { if ((uint32_t)ln < take) s_newp[ln] = freep[n_free - 1u - (uint32_t)ln]; }
+		n_free -= take;
+		const uint32_t rest = n_new - take;
+		if (rest) {
+			LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(P.page_bump, rest); }
+			const uint32_t base = WBCAST(tu, 0);
+			if ((uint64_t)base + rest > P.n_pages || n_own + rest > P.own_cap) return false;
+			LANES { if ((uint32_t)ln < rest) { s_newp[take + (uint32_t)ln] = base + (uint32_t)ln; own[n_own + (uint32_t)ln] = base + (uint32_t)ln; } }
+			n_own += rest;
+		}
+		WAVE_SYNC();
+		return true;
+	};
+
+	for (;;) {
+		LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(S.work_counter, 1u); }
+		const uint32_t idx = WBCAST(tu, 0);
+		if (idx >= (uint32_t)S.n) break;
+		const uint32_t rid = S.ids ? (uint32_t)S.ids[idx] : idx;
+		const uint32_t item = S.res_slot ? (uint32_t)S.res_slot[rid] : idx;
+		const int len = S.rd_len[rid];
+		const size_t sq_off = (size_t)S.poff[rid];
+		const int MD = (int)S.rd_maxdiff[rid], MG = (int)S.rd_maxgapo[rid];
+		uint8_t *const rec = S.wdata + (size_t)rid * S.wstride;
+		uint4 *const out = S.aln + (size_t)item * S.aln_cap;
+		int n_aln = 0, max_ent = 0, status = NABWA_ST_OK;
+
+		if (len > 0 && (int)S.rd_nN[rid] <= MD) {          // too many N: no search (bwtgap.c:118-123)
+			const bool seeded = len > S.seed_len;
+			int max_diff = MD, best_cnt = 0, n_entries = 0;
+			int best_score = (MD + 1) * S.s_mm + (MG + 1) * S.s_gapo + (S.max_gape + 1) * S.s_gape;
+			LANES { for (uint32_t t = (uint32_t)ln; t < P.NS; t += 64u) { s_cnt[t] = 0; s_top[t] = DEEP_NIL; } }
+			LANES { for (uint32_t t = (uint32_t)ln; t < n_own; t += 64u) freep[t] = own[t]; }      // every page this wave holds is free again
+			n_free = n_own;
+			WAVE_SYNC();
+			bool done = false, careful = P.careful_all != 0;
+			uint32_t cur = 0;                                 // no level below `cur` holds an entry
+			// roots (bwtgap.c:127-128): strand 0 is pushed first, strand 1 second, so strand 1 is popped first
+			if (!alloc_pages(1)) { status = NABWA_ST_POOL; done = true; ++st_pool; }
+			else {
+				const uint32_t p0 = s_newp[0];
+				ONE_LANE {
+					P.pages[(size_t)p0 * DEEP_PAGE + 0] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 0, 0u);
+					P.pages[(size_t)p0 * DEEP_PAGE + 1] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 1, 0u);
+					P.page_prev[p0] = DEEP_NIL; s_cnt[0] = 2; s_top[0] = p0;
+				}
+				WAVE_SYNC();
+				n_entries = 2;
+			}
+
+			while (!done) {
+				// ---------------------------------------------------------------- start of a round = the reference's loop head
+				if (n_entries == 0) break;
+				if (max_ent < n_entries) max_ent = n_entries;                     // bwtgap.c:139
+				if (n_entries > S.max_entries) break;                             // bwtgap.c:140
+				bool found = false;
+				for (uint32_t base = cur; base < P.NS && !found; base += 64u) {
+					const uint64_t mk = WBALLOT(base + (uint32_t)ln < P.NS && s_cnt[base + (uint32_t)ln] != 0u);
+					if (mk) { cur = base + (uint32_t)deep_ctz64(mk); found = true; }
+				}
+				if (!found) break;     // only children that were counted but never stored are left: the reference pops one of them and stops (bwtgap.c:144)
+				const int s = (int)cur;
+				if (!nonstop && n_aln > 0 && s > best_score + S.s_mm) break;      // bwtgap.c:144
+				const uint32_t cs = s_cnt[s];
+				uint32_t W = careful ? 1u : (uint32_t)P.max_lanes;
+				if (W > cs) W = cs;
+				const int T0 = s + S.s_mm, T1 = s + S.s_gapo, T2 = s + S.s_gape;
+				const uint32_t can1 = T1 == T0 ? 0u : 1u, can2 = T2 == T0 ? 0u : (T2 == T1 ? can1 : 2u);
+				const uint32_t topq = (cs - 1u) >> DEEP_PAGE_SH, top_pg = s_top[s];
+				uint32_t prev_pg = DEEP_NIL;
+				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = P.page_prev[top_pg];
+				LANES {
+					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(np) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
+					if (L(act)) {
+						const uint32_t p = cs - 1u - (uint32_t)ln;
+						const uint32_t pg = (p >> DEEP_PAGE_SH) == topq ? top_pg : prev_pg;
+						deep_unpack(P.pages[(size_t)pg * DEEP_PAGE + (p & (DEEP_PAGE - 1u))], L(e));
+					}
+				}
+				++st_rounds; st_run += W; if (careful) ++st_careful;
+
+				// ---------------------------------------------------------------- the chains
+				while (WBALLOT(L(act)) != 0ull) {
+					++st_steps;
+					LANES { if (L(act)) {
+						DeepLane &E = L(e);
+						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
+						if (L(rel) > L(peak)) L(peak) = L(rel);
+						L(rel) -= 1;
+						const int m = max_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
+						const uint8_t *const bb = rec + S.woff_bid + (uint32_t)E.a * S.WLB;
+						bool go_on = m >= 0;
+						if (go_on && E.i > 0 && m < (int)(bb[E.i - 1] & 127u)) go_on = false;      // bwtgap.c:156
+						if (!go_on) L(act) = false;
+						else {
+							const bool q1 = E.a == 0;                                         // the index searched: bwts[1 - a] (bwtgap.c:149)
+							DevBwt B;
+							B.bk = q1 ? S.bwt[1].bk : S.bwt[0].bk; B.primary = q1 ? S.bwt[1].primary : S.bwt[0].primary;
+							B.seq_len = q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len;
+							B.L2[0] = 0; B.L2[1] = q1 ? S.bwt[1].L2[1] : S.bwt[0].L2[1]; B.L2[2] = q1 ? S.bwt[1].L2[2] : S.bwt[0].L2[2]; B.L2[3] = q1 ? S.bwt[1].L2[3] : S.bwt[0].L2[3];
+							const uint8_t *const str = (E.a ? S.rseq : S.seq) + sq_off;
+							bool hit = false;
+							if (E.i == 0) hit = true;
+							else if (m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape)) {
+								// nothing may differ any more: bwt_match_exact_alt (bwt.c:237-252) over str[i-1 .. 0]
+								uint32_t k = E.k, l = E.l; int i = E.i; bool ok = true;
+								while (i > 0) {
+									const uint32_t c = str[i - 1];
+									if (c > 3u) { ok = false; break; }
+									Occ4 ck, cl;
+									nabwa_occ4_pair(B, k - 1u, l, ck, cl);
+									k = B.L2[c] + ck.c[c] + 1u; l = B.L2[c] + cl.c[c];
+									if (k > l) { ok = false; break; }
+									--i;
+								}
+								if (ok) { hit = true; E.k = k; E.l = l; } else L(act) = false;
+							}
+							if (hit) { L(flag) = DF_HIT; L(act) = false; }
+							else if (L(act)) {
+								// ---- expansion (bwtgap.c:201-260)
+								const int i = E.i - 1;
+								Occ4 ck, cl;
+								nabwa_occ4_pair(B, E.k - 1u, E.l, ck, cl);
+								const uint32_t occ = E.l - E.k + 1u;
+								bool allow_diff = true, allow_M = true;
+								if (i > 0) {
+									const uint32_t B1 = bb[i - 1], B0 = bb[i];
+									const int b1 = (int)(B1 & 127u), b0 = (int)(B0 & 127u);
+									if (b1 > m - 1) allow_diff = false;
+									else if (b1 == m - 1 && b0 == m - 1 && (B0 & 128u)) allow_M = false;
+									const int ii = i - (len - S.seed_len);
+									if (seeded && ii > 0) {
+										const uint8_t *const sb = rec + S.woff_sbid + (uint32_t)E.a * S.SLB;
+										const uint32_t S1 = sb[ii - 1], S0 = sb[ii];
+										const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
+										const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
+										if (s1 > m_seed - 1) allow_diff = false;
+										else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
+									}
+								}
+								uint4 *const stg = stage + (size_t)ln * K;
+								// a child of class cls: counted always, staged unless it can never be popped (after the first hit the
+								// loop ends at the first pop above best_score + s_mm, bwtgap.c:144)
+								auto child = [&](uint32_t cls, uint32_t nk, uint32_t nl, int ni, int nmm, int ngo, int nge, int nstate) {
+									L(rel) += 1;
+									const int sc = cls == DCL_MM ? T0 : (cls == DCL_GO ? T1 : T2);
+									if (!nonstop && n_aln > 0 && sc > best_score + S.s_mm) return;
+									stg[L(np)] = deep_pack(nk, nl, ni, ni, nmm, ngo, nge, nstate, E.a, cls);
+									L(np) += 1;
+									const uint32_t cn = cls == DCL_MM ? 0u : (cls == DCL_GO ? can1 : can2);
+									if (cn == 0u) L(cc0) += 1; else if (cn == 1u) L(cc1) += 1; else L(cc2) += 1;
+								};
+								int tmp = E.go + E.ge;
+								if (loggap) { const uint32_t v = (uint32_t)(E.ge + E.go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
+								if (allow_diff && i >= S.indel_end_skip + tmp && len - i >= S.indel_end_skip + tmp) {
+									if (E.state == DST_M) {                                      // gap open: the insertion, then the deletions
+										if (E.go < MG) {
+											child(DCL_GO, E.k, E.l, i, E.mm, E.go + 1, E.ge, DST_I);
+											for (int j = 0; j < 4; ++j) {
+												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
+												if (nk <= nl) child(DCL_GO, nk, nl, i + 1, E.mm, E.go + 1, E.ge, DST_D);
+											}
+										}
+									} else if (E.state == DST_I) {
+										if (E.ge < S.max_gape) child(DCL_GE, E.k, E.l, i, E.mm, E.go, E.ge + 1, DST_I);
+									} else if (E.ge < S.max_gape) {
+										if (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ) {
+											for (int j = 0; j < 4; ++j) {
+												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
+												if (nk <= nl) child(DCL_GE, nk, nl, i + 1, E.mm, E.go, E.ge + 1, DST_D);
+											}
+										}
+									}
+								}
+								const uint32_t c = str[i];
+								bool match = false; uint32_t mk_ = 0, ml_ = 0;
+								if (allow_diff && allow_M) {
+									for (int j = 1; j <= 4; ++j) {
+										const uint32_t x = (c + (uint32_t)j) & 3u;
+										const bool is_mm = j != 4 || c > 3u;
+										const uint32_t nk = B.L2[x] + ck.c[x] + 1u, nl = B.L2[x] + cl.c[x];
+										if (nk <= nl) {
+											if (is_mm) child(DCL_MM, nk, nl, i, E.mm + 1, E.go, E.ge, DST_M);
+											else { match = true; mk_ = nk; ml_ = nl; }
+										}
+									}
+								} else if (c < 4u) {
+									const uint32_t nk = B.L2[c] + ck.c[c] + 1u, nl = B.L2[c] + cl.c[c];
+									if (nk <= nl) { match = true; mk_ = nk; ml_ = nl; }
+								}
+								// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
+								if (match) { L(rel) += 1; E.k = mk_; E.l = ml_; E.i = i; E.ldp = 0; E.state = DST_M; }
+								else L(act) = false;
+								if (L(act) && (careful || L(np) + 9u > K)) { L(flag) = DF_CONT; L(act) = false; }
+							}
+						}
+					} }
+					// a chain that ended in a hit or ran out of staging room: the lanes above it will be dropped
+					const uint64_t sm = WBALLOT(L(flag) != DF_NONE);
+					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) L(act) = false; } }
+				}
+
+				// ---------------------------------------------------------------- commit, in the reference's order
+				const uint64_t stopm = WBALLOT(L(flag) != DF_NONE && (uint32_t)ln < W);
+				int jl = stopm ? deep_ctz64(stopm) : (int)W - 1;            // the last lane whose chain counts
+				uint32_t tot = 0;
+				LANES { L(d) = ln <= jl ? (uint32_t)L(rel) : 0u; }
+				WEXSCAN_U32(L(off), L(d), tot);
+				LANES { L(nst) = n_entries + (int)L(off); }                  // live entries before this lane's first pop
+				const uint64_t over = WBALLOT(ln <= jl && (int64_t)L(nst) + L(peak) > (int64_t)S.max_entries);
+				if (over) { careful = true; jl = deep_ctz64(over) - 1; }   // the cut-off (bwtgap.c:140) falls into that lane's chain
+				if (jl < 0) continue;
+				{
+					int64_t mx = 0;
+					WMAX_I64(mx, ln <= jl ? (int64_t)L(nst) + L(peak) : (int64_t)0);
+					if (mx > max_ent) max_ent = (int)mx;
+				}
+				LANES { L(tu) = (uint32_t)(L(nst) + L(rel)); }
+				n_entries = (int)WBCAST(tu, jl);
+				st_commit += (unsigned)(jl + 1);
+				// the popped entries leave level s
+				const uint32_t newc = cs - (uint32_t)(jl + 1);
+				ONE_LANE { s_cnt[s] = newc; }
+				if (newc == 0u || ((newc - 1u) >> DEEP_PAGE_SH) != topq) {      // its top page is empty now
+					if (newc && prev_pg == DEEP_NIL) prev_pg = P.page_prev[top_pg];
+					ONE_LANE { freep[n_free] = top_pg; s_top[s] = newc ? prev_pg : DEEP_NIL; }
+					++n_free;
+				}
+				WAVE_SYNC();
+				bool pool_fail = false;
+				// the staged children go to their levels: lane by lane, within a lane in chain order
+				for (uint32_t c = 0; c < 3u && !pool_fail; ++c) {
+					if ((c == 1u && can1 != 1u) || (c == 2u && can2 != 2u)) continue;
+					LANES { L(d) = ln <= jl ? (c == 0u ? L(cc0) : (c == 1u ? L(cc1) : L(cc2))) : 0u; }
+					WEXSCAN_U32(L(off), L(d), tot);
+					if (tot == 0u) continue;
+					const int Tc = c == 0u ? T0 : (c == 1u ? T1 : T2);
+					if ((uint32_t)Tc >= P.NS) { pool_fail = true; break; }   // (cannot happen: the host sizes NS by the largest score an entry can have)
+					const uint32_t cT = s_cnt[Tc], old_top = s_top[Tc];
+					const uint32_t q_new = cT ? ((cT - 1u) >> DEEP_PAGE_SH) + 1u : 0u, q_last = (cT + tot - 1u) >> DEEP_PAGE_SH;
+					const uint32_t n_new = q_last + 1u > q_new ? q_last + 1u - q_new : 0u;
+					if (n_new && !alloc_pages(n_new)) { pool_fail = true; break; }
+					ONE_LANE {
+						for (uint32_t t = 0; t < n_new; ++t) P.page_prev[s_newp[t]] = t ? s_newp[t - 1u] : old_top;
+						s_cnt[Tc] = cT + tot;
+						if (n_new) s_top[Tc] = s_newp[n_new - 1u];
+					}
+					LANES { if (ln <= jl) {
+						uint32_t w = cT + L(off);
+						const uint4 *const stg = stage + (size_t)ln * K;
+						for (uint32_t r = 0; r < L(np); ++r) {
+							uint4 v = stg[r];
+							const uint32_t cls = v.w >> 27 & 3u;
+							const uint32_t cn = cls == DCL_MM ? 0u : (cls == DCL_GO ? can1 : can2);
+							if (cn != c) continue;
+							v.w &= ~(3u << 27);
+							const uint32_t q = w >> DEEP_PAGE_SH;
+							const uint32_t pg = q < q_new ? old_top : s_newp[q - q_new];
+							P.pages[(size_t)pg * DEEP_PAGE + (w & (DEEP_PAGE - 1u))] = v;
+							++w;
+						}
+					} }
+					WAVE_SYNC();
+				}
+				const int fl = WBCAST(flag, jl);
+				if (!pool_fail && !over && fl == DF_CONT) {
+					// the chain of lane jl goes on in the next round: its current entry is the newest of level s again
+					const uint32_t cT = s_cnt[s], old_top = s_top[s];
+					const bool need = (cT & (DEEP_PAGE - 1u)) == 0u;
+					if (need && !alloc_pages(1)) pool_fail = true;
+					else {
+						const uint32_t pg = need ? s_newp[0] : old_top;
+						ONE_LANE { if (need) { P.page_prev[pg] = old_top; s_top[s] = pg; } s_cnt[s] = cT + 1u; }
+						LANES { if (ln == jl) P.pages[(size_t)pg * DEEP_PAGE + (cT & (DEEP_PAGE - 1u))] =
+							deep_pack(L(e).k, L(e).l, L(e).i, L(e).ldp, L(e).mm, L(e).go, L(e).ge, L(e).state, L(e).a, 0u); }
+						WAVE_SYNC();
+					}
+				}
+				if (pool_fail) { status = NABWA_ST_POOL; ++st_pool; break; }
+				if (!over && fl == DF_HIT) {
+					// ---- hit bookkeeping (bwtgap.c:166-199), the wave together
+					LANES { L(tu) = L(e).k; } const uint32_t hk = WBCAST(tu, jl);
+					LANES { L(tu) = L(e).l; } const uint32_t hl = WBCAST(tu, jl);
+					LANES { L(tu) = (uint32_t)L(e).mm | (uint32_t)L(e).go << 8 | (uint32_t)L(e).ge << 16 | (uint32_t)L(e).a << 24; } const uint32_t hinfo = WBCAST(tu, jl);
+					LANES { L(tu) = (uint32_t)L(e).ldp; } const int h_ldp = (int)WBCAST(tu, jl);
+					const int h_mm = (int)(hinfo & 0xffu), h_go = (int)(hinfo >> 8 & 0xffu), h_ge = (int)(hinfo >> 16 & 0xffu), h_a = (int)(hinfo >> 24 & 1u);
+					const int score = s;
+					bool do_add = true;
+					if (n_aln == 0) {
+						best_score = score;
+						const int best_diff = h_mm + h_go + (gape_mode ? h_ge : 0);
+						if (!nonstop) max_diff = best_diff + 1 > MD ? MD : best_diff + 1;
+					}
+					if (score == best_score) best_cnt += (int)(hl - hk + 1u);
+					else if (best_cnt > S.max_top2) { done = true; do_add = false; }
+					if (do_add && h_go) {       // a gap in a tandem repeat finds the same interval again (bwtgap.c:179-183)
+						const uint64_t dup = WBALLOT([&]() -> bool { bool f = false; for (int j = ln; j < n_aln; j += 64) { const uint4 h = out[j]; if (h.y == hk && h.z == hl) f = true; } return f; }());
+						if (dup) do_add = false;
+					}
+					if (do_add) {
+						if (n_aln == S.aln_cap) { status = NABWA_ST_HITCAP; done = true; }
+						else {
+							// gap_shadow (bwtgap.c:81-91) on this strand's widths, positions < last_diff_pos, 64 at a time; then the
+							// "w[t-1] == w[t]" bits of the bound bytes of positions 1 .. last_diff_pos are refreshed
+							const uint32_t x = hl - hk + 1u, mx = h_a ? S.bwt[0].seq_len : S.bwt[1].seq_len;
+							uint32_t *const wp = (uint32_t*)rec + (uint32_t)h_a * S.WL; uint8_t *const bp = rec + S.woff_bid + (uint32_t)h_a * S.WLB;
+							uint32_t jj = 0;
+							for (int t0 = 0; t0 < h_ldp; t0 += 64) {
+								const uint64_t eqm = WBALLOT(t0 + ln < h_ldp && wp[t0 + ln] == x);
+								LANES {
+									const int t = t0 + ln;
+									if (t < h_ldp) {
+										const uint32_t wv = wp[t];
+										if (wv > x) wp[t] = wv - x;
+										else if (wv == x) {
+											const uint32_t rank = (uint32_t)__popcll((unsigned long long)(eqm & ((2ull << ln) - 1ull)));
+											wp[t] = mx - (jj + rank); bp[t] = (uint8_t)((bp[t] & 128u) | 1u);
+										}
+									}
+								}
+								jj += (uint32_t)__popcll((unsigned long long)eqm);
+							}
+							WAVE_SYNC();
+							for (int t0 = 1; t0 <= h_ldp && h_ldp > 0; t0 += 64) {
+								LANES {
+									const int t = t0 + ln;
+									if (t <= h_ldp) bp[t] = (uint8_t)((bp[t] & 127u) | (wp[t] == wp[t - 1] ? 128u : 0u));
+								}
+							}
+							ONE_LANE { out[n_aln] = make_uint4(hinfo, hk, hl, (uint32_t)score); }
+							++n_aln;
+							WAVE_SYNC();
+						}
+					}
+				}
+			}
+		}
+		ONE_LANE { S.n_aln[item] = n_aln; S.max_ent[item] = max_ent; S.status[item] = (uint8_t)status; }
+	}
+	if (P.stats) {
+		ONE_LANE {
+#ifdef NABWA_EMU
+			P.stats[0] += st_rounds; P.stats[1] += st_run; P.stats[2] += st_commit; P.stats[3] += st_steps; P.stats[4] += st_careful; P.stats[5] += st_pool;
+#else
+			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
+			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
+#endif
+		}
+	}
+}

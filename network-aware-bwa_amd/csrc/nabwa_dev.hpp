@@ -19,7 +19,11 @@
 // The reference keeps 128 rows in 48 bytes (bwt.h:35,61-68, bwtmisc.c:125-152), which straddles
 // 64-byte lines; the re-pack is done on the device at load time (fm_index.hip).
 #pragma once
+#ifdef NABWA_EMU
+#include "emu_hip.hpp"   /* tests/emu/: the few vector types and bit intrinsics, for the CPU wave emulation of kernel D (wave_spmd.hpp) */
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #define NABWA_INTV 192u

@@ -1,0 +1,164 @@
+// tests/emu/deep_emu.cpp -- TEST INFRASTRUCTURE ONLY: kernel D (network-aware-bwa_amd/csrc/fm_deep_body.hpp) compiled by g++ as a
+// sequential emulation of one wavefront (NABWA_EMU, wave_spmd.hpp), so that its speculative rounds and ordered commits
+// can be checked against the oracle here, under AddressSanitizer, without a GPU.  Nothing in libnabwa.so links this.
+//
+// Around the kernel body this file holds plain CPU stand-ins for what other GPU kernels produce for it: the 64-byte
+// bucket array (repack_kernel, fm_index.hip) and the per-read width records (fm_width_kernel, fm_search.hip).
+#define NABWA_EMU 1
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../network-aware-bwa_amd/csrc/fm_deep_body.hpp"
+
+namespace {
+
+uint32_t ref_base(const uint32_t *w, uint32_t j)          // base j of the reference's .bwt word stream (bwt.h:61-66)
+{
+	const uint32_t *p = w + (size_t)(j >> 7) * 12 + 4;
+	return p[(j & 127u) >> 4] >> ((~j & 15u) << 1) & 3u;
+}
+
+struct EmuBwt { std::vector<uint4> bk; DevBwt B; };
+
+void build(EmuBwt &X, const uint32_t *words)
+{
+	memset(&X.B, 0, sizeof(X.B));
+	X.B.primary = words[0]; X.B.L2[0] = 0; X.B.L2[1] = words[1]; X.B.L2[2] = words[2]; X.B.L2[3] = words[3]; X.B.seq_len = words[4];
+	const uint32_t *w = words + 5, n = X.B.seq_len;
+	const uint32_t nb = (uint32_t)(((uint64_t)n + NABWA_INTV - 1) / NABWA_INTV);
+	X.bk.assign((size_t)nb * 4, make_uint4(0, 0, 0, 0));
+	uint32_t cnt[4] = { 0, 0, 0, 0 };
+	for (uint32_t b = 0; b < nb; ++b) {
+		uint64_t lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+		const uint32_t c0[4] = { cnt[0], cnt[1], cnt[2], cnt[3] };
+		for (uint32_t r = 0; r < NABWA_INTV; ++r) {
+			const uint32_t j = b * NABWA_INTV + r;
+			if (j >= n) break;
+			const uint32_t c = ref_base(w, j);
+			++cnt[c];
+			lo[r >> 6] |= (uint64_t)(c & 1u) << (r & 63u); hi[r >> 6] |= (uint64_t)(c >> 1) << (r & 63u);
+		}
+		uint4 *o = &X.bk[(size_t)b * 4];
+		o[0] = make_uint4(c0[0], c0[1], c0[2], c0[3]);
+		for (int g = 0; g < 3; ++g) o[1 + g] = make_uint4((uint32_t)lo[g], (uint32_t)(lo[g] >> 32), (uint32_t)hi[g], (uint32_t)(hi[g] >> 32));
+	}
+	X.B.bk = X.bk.data(); X.B.n_buckets = nb;
+}
+
+// bwt_cal_width (bwtaln.c:52-76) into the record layout kernel W writes: widths, bound bytes min(bid,127) | (w[p-1]==w[p]) << 7
+void cal_width(const DevBwt &B, int len, const uint8_t *str, uint32_t *wd, uint8_t *bd)
+{
+	uint32_t k = 0, l = B.seq_len, pw = 0; int bid = 0;
+	for (int i = 0; i < len; ++i) {
+		const uint32_t c = str[i];
+		if (c < 4) {
+			Occ4 ck, cl;
+			nabwa_occ4_pair(B, k - 1u, l, ck, cl);
+			k = B.L2[c] + ck.c[c] + 1u; l = B.L2[c] + cl.c[c];
+		}
+		if (k > l || c > 3) { k = 0; l = B.seq_len; ++bid; }
+		const uint32_t wv = l - k + 1u;
+		wd[i] = wv; bd[i] = (uint8_t)((bid > 127 ? 127 : bid) | ((i > 0 && wv == pw) ? 128 : 0));
+		pw = wv;
+	}
+	++bid;
+	wd[len] = 0; bd[len] = (uint8_t)((bid > 127 ? 127 : bid) | ((len > 0 && 0u == pw) ? 128 : 0));
+}
+
+int cal_maxdiff(int l, double err, double thres)       // bwa_cal_maxdiff (bwtaln.c:37-49)
+{
+	double elambda = exp(-l * err), sum = elambda, y = 1.0;
+	uint32_t x = 1;
+	for (int k = 1; k < 1000; ++k) {
+		y *= l * err; x *= (uint32_t)k;
+		sum += elambda * y / (int32_t)x;
+		if (1.0 - sum < thres) return k;
+	}
+	return 2;
+}
+
+uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries; float fnr; int max_diff, max_gapo, max_gape, max_seed_diff, seed_len, n_threads, max_top2, trim_qual; };
+
+// knobs: [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap
+// stats (may be NULL): 6 words, see DeepParams.  Returns 0.
+extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const emu_opt *opt, int n, const int64_t *off,
+							   const uint8_t *seq, const uint8_t *rseq, int per_read, const int *knobs,
+							   int32_t *n_aln, uint32_t *rows /* n x aln_cap x 4 */, int32_t *max_ent, uint8_t *status,
+							   unsigned long long *stats)
+{
+	EmuBwt X[2];
+	build(X[0], bwt0); build(X[1], bwt1);
+	int max_len = 0;
+	for (int i = 0; i < n; ++i) if (off[i + 1] - off[i] > max_len) max_len = (int)(off[i + 1] - off[i]);
+	DeepParams P;
+	memset(&P, 0, sizeof(P));
+	SearchParams &S = P.S;
+	S.bwt[0] = X[0].B; S.bwt[1] = X[1].B;
+	// reads, padded to 16-byte starts as pad_reads_kernel lays them out
+	std::vector<int64_t> poff(n + 1, 0);
+	for (int i = 0; i < n; ++i) poff[i + 1] = poff[i] + (off[i + 1] - off[i] + 15) / 16 * 16;
+	std::vector<uint8_t> ps(poff[n] + 64, 4), pr(poff[n] + 64, 4);
+	std::vector<int32_t> rd_len(n);
+	std::vector<uint8_t> md(n), mg(n), nN(n);
+	const int md_batch = opt->fnr > 0.0f ? cal_maxdiff(max_len, 0.02, opt->fnr) : opt->max_diff;
+	uint32_t NS = 1;
+	for (int i = 0; i < n; ++i) {
+		const int L = (int)(off[i + 1] - off[i]);
+		memcpy(&ps[poff[i]], seq + off[i], L); memcpy(&pr[poff[i]], rseq + off[i], L);
+		rd_len[i] = L;
+		const int d = opt->fnr > 0.0f ? cal_maxdiff(L, 0.02, opt->fnr) : opt->max_diff;
+		const int sizing = per_read ? d : md_batch;
+		int g = opt->max_gapo; if (sizing < g) g = sizing;
+		md[i] = (uint8_t)d; mg[i] = (uint8_t)g;
+		const uint32_t ns = (uint32_t)((d + 2) * opt->s_mm + (g + 1) * opt->s_gapo + (opt->max_gape + 1) * opt->s_gape + 1);
+		if (ns > NS) NS = ns;
+		int c = 0; for (int j = 0; j < L; ++j) if (seq[off[i] + j] > 3) ++c;
+		nN[i] = (uint8_t)(c > 255 ? 255 : c);
+	}
+	S.seq = ps.data(); S.rseq = pr.data(); S.poff = poff.data(); S.rd_len = rd_len.data(); S.rd_maxdiff = md.data(); S.rd_maxgapo = mg.data();
+	S.rd_nN = nN.data(); S.n = n;
+	S.s_mm = opt->s_mm; S.s_gapo = opt->s_gapo; S.s_gape = opt->s_gape; S.mode = opt->mode; S.indel_end_skip = opt->indel_end_skip;
+	S.max_del_occ = opt->max_del_occ; S.max_entries = opt->max_entries; S.max_gape = opt->max_gape; S.max_seed_diff = opt->max_seed_diff;
+	S.seed_len = opt->seed_len; S.max_top2 = opt->max_top2;
+	// width records (layout of nabwa_api.hip: layout())
+	S.WL = align_up((uint32_t)max_len + 1, 16); S.WLB = S.WL + 16; S.SLB = align_up((uint32_t)(opt->seed_len > 65535 ? 0 : opt->seed_len) + 1, 16) + 16;
+	S.woff_bid = 2 * S.WL * 4; S.woff_sbid = S.woff_bid + 2 * S.WLB; S.wstride = align_up(S.woff_sbid + 2 * S.SLB, 64);
+	std::vector<uint8_t> wdata((size_t)(n ? n : 1) * S.wstride, 0);
+	std::vector<uint32_t> tmpw(max_len + 2);
+	for (int i = 0; i < n; ++i) {
+		uint8_t *rec = &wdata[(size_t)i * S.wstride];
+		const int L = rd_len[i];
+		if (L <= 0) continue;
+		for (int x = 0; x < 2; ++x) {
+			const uint8_t *str = (x ? pr.data() : ps.data()) + poff[i];
+			cal_width(X[x].B, L, str, (uint32_t*)rec + x * S.WL, rec + S.woff_bid + x * S.WLB);
+			if (L > opt->seed_len) cal_width(X[x].B, opt->seed_len, str + (L - opt->seed_len), tmpw.data(), rec + S.woff_sbid + x * S.SLB);
+		}
+	}
+	S.wdata = wdata.data();
+	const int aln_cap = knobs[6];
+	S.n_aln = n_aln; S.max_ent = max_ent; S.status = status; S.aln = (uint4*)rows; S.aln_cap = aln_cap;
+	unsigned int counter = 0, bump = 0;
+	S.work_counter = &counter;
+	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)knobs[2];
+	P.max_lanes = knobs[0]; P.careful_all = knobs[1]; P.NS = NS; P.stats = stats;
+	const int per_wave = knobs[5];
+	const int n_waves = per_wave > 0 ? (n + per_wave - 1) / per_wave : 1;
+	std::vector<uint4> pages((size_t)P.n_pages * DEEP_PAGE);
+	std::vector<uint32_t> prev(P.n_pages, 0), own((size_t)n_waves * 2 * P.own_cap, 0);
+	std::vector<uint4> stage((size_t)n_waves * 64 * P.stage_k);
+	std::vector<uint32_t> lds(2 * NS + DEEP_NEWP);
+	P.pages = pages.data(); P.page_prev = prev.data(); P.page_bump = &bump; P.own = own.data(); P.stage = stage.data();
+	for (int w = 0; w < n_waves; ++w) {
+		S.n = per_wave > 0 ? ((w + 1) * per_wave < n ? (w + 1) * per_wave : n) : n;
+		deep_wave_body(P, lds.data(), (uint32_t)w);
+		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
+	}
+	return 0;
+}
