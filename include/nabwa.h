@@ -22,7 +22,9 @@ extern "C" {
 #define NABWA_EINVAL   -2   /* bad argument or unsupported option block */
 #define NABWA_EIO      -3   /* index file missing / malformed */
 #define NABWA_ENOMEM   -4
-#define NABWA_ECAP     -5   /* caller-provided output capacity too small */
+#define NABWA_ECAP     -5   /* caller-provided output capacity too small (n_aln[] / *n_rows say how much is needed) */
+#define NABWA_EHITS    -6   /* some reads have more hit rows than the device-side result rows (env NABWA_ALNCAP2, default 1024):
+                             their n_aln is 0, every other read is resolved and can be fetched */
 
 /* gap_opt_t -- identical layout to the reference's (bwtaln.h:143-153, 64 bytes); it is the
  * block `bwa worker` receives over the wire (bam2bam.c:1260-1263). */
@@ -91,12 +93,14 @@ int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, con
 					   const uint8_t *seq, const uint8_t *rseq, int per_read, nabwa_batch_t **out);
 /* enqueue the FM search of the whole batch on the batch's HIP stream (asynchronous) */
 int nabwa_batch_run(nabwa_batch_t *b);
-/* wait for completion; returns the number of reads that needed the large-arena second pass */
+/* wait for completion; *n_second_pass = the number of reads the first pass handed on to kernel D (deep searches) */
 int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass);
 /* HIP-event time of the most recent run of the dominant kernel (fm_search, first pass), ms */
 float nabwa_batch_last_kernel_ms(nabwa_batch_t *b);
 /* same for the width kernel (fm_width) that precedes it */
 float nabwa_batch_last_width_ms(nabwa_batch_t *b);
+/* same for kernel D (fm_deep: the reads the first pass handed on, one search per wavefront); 0 when it did not run */
+float nabwa_batch_last_deep_ms(nabwa_batch_t *b);
 /* untimed instrumented run: Occ-bucket touches the reference algorithm performs on this batch
  * (1 per bwt_occ/bwt_occ4 body, 1 per same-block bwt_2occ/bwt_2occ4), split into
  * those of bwt_match_gap (search kernel) and of the bwt_cal_width passes (width kernel) */

@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABWA_LIB", os.path.join(_HERE, "libnabwa.so"))   # NABWA_LIB: A/B builds
 
-OK, ENODEV, EINVAL, EIO, ENOMEM, ECAP = 0, -1, -2, -3, -4, -5
+OK, ENODEV, EINVAL, EIO, ENOMEM, ECAP, EHITS = 0, -1, -2, -3, -4, -5, -6
 
 ALN_DT = np.dtype([("info", "<u4"), ("k", "<u4"), ("l", "<u4"), ("score", "<i4")])  # bwt_aln1_t, bwtaln.h:41-45
 
@@ -224,6 +224,8 @@ def lib():
     L.nabwa_batch_last_kernel_ms.argtypes = [_P]
     L.nabwa_batch_last_width_ms.restype = C.c_float
     L.nabwa_batch_last_width_ms.argtypes = [_P]
+    L.nabwa_batch_last_deep_ms.restype = C.c_float
+    L.nabwa_batch_last_deep_ms.argtypes = [_P]
     L.nabwa_batch_fetch.argtypes = [_P, _P, _P, C.c_int64, _P, _P]
     L.nabwa_batch_checksum.argtypes = [_P, _P, _P]
     L.nabwa_batch_count_touches.argtypes = [_P, _P, _P]
@@ -444,6 +446,10 @@ class Batch:
 
     def last_width_ms(self):
         return float(lib().nabwa_batch_last_width_ms(self._h))
+
+    def last_deep_ms(self):
+        """HIP-event time of kernel D (the deep searches the first pass handed on) in the most recent run; 0 if it did not run"""
+        return float(lib().nabwa_batch_last_deep_ms(self._h))
 
     def checksum(self):
         s = C.c_uint64()

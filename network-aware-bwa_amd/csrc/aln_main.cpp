@@ -733,13 +733,13 @@ int main(int argc, char *argv[])
 			for (int i = 0; i <= n; ++i) off[i] = b.off[r0 + i] - base;
 			n_aln.resize(n); max_entries.resize(n);
 			int64_t cap = (int64_t)n + n / 4 + 1024, n_rows = 0;
-			int rc;
-			for (;;) {
+			int rc = NABWA_OK;
+			for (int attempt = 0; attempt < 2; ++attempt) {      /* the second attempt has the row count the first one reported */
 				rows.resize(cap);
 				rc = nabwa_cal_sa_reg_gap(ix, &opt, n, off.data(), b.seq.data() + base, b.rseq.data() + base, 0,
 										  n_aln.data(), rows.data(), cap, &n_rows, max_entries.data());
-				if (rc != NABWA_ECAP) break;
-				cap = 0; for (int i = 0; i < n; ++i) cap += n_aln[i];
+				if (rc != NABWA_ECAP || n_rows <= cap) break;
+				cap = n_rows;
 			}
 			if (rc != NABWA_OK) { fprintf(stderr, "[nabwa_aln] GPU search failed: %s\n", nabwa_last_error()); return false; }
 			const size_t at = obuf.size();

@@ -33,14 +33,23 @@ extern "C" int nabwa_bwa_cal_sa_reg_gap(nabwa_index_t *ix, int n_seqs, nabwa_bwa
 		if (L) { memcpy(&s[off[i]], seqs[i].seq, L); memcpy(&r[off[i]], seqs[i].rseq, L); }
 	}
 	std::vector<int32_t> n_aln(n_seqs ? n_seqs : 1), maxe(n_seqs ? n_seqs : 1);
+	/* one search, two fetches: the first tells the number of rows, the second brings them (a fetch does not search again) */
+	nabwa_batch_t *bt = 0;
+	int rc = nabwa_batch_create(ix, opt, n_seqs, off.data(), s.data(), r.data(), /*per_read*/0, &bt);
+	if (rc != NABWA_OK) return rc;
+	rc = nabwa_batch_run(bt);
+	if (rc == NABWA_OK) rc = nabwa_batch_sync(bt, 0);
 	int64_t rows = 0;
-	int rc = nabwa_cal_sa_reg_gap(ix, opt, n_seqs, off.data(), s.data(), r.data(), /*per_read*/0, n_aln.data(), 0, 0, &rows, maxe.data());
-	if (rc != NABWA_OK && rc != NABWA_ECAP) return rc;
-	std::vector<nabwa_aln1_t> aln(rows ? rows : 1);
-	if (rows) {
-		rc = nabwa_cal_sa_reg_gap(ix, opt, n_seqs, off.data(), s.data(), r.data(), 0, n_aln.data(), aln.data(), rows, &rows, maxe.data());
-		if (rc != NABWA_OK) return rc;
+	std::vector<nabwa_aln1_t> aln(1);
+	if (rc == NABWA_OK) {
+		rc = nabwa_batch_fetch(bt, n_aln.data(), 0, 0, &rows, maxe.data());
+		if (rc == NABWA_ECAP && rows > 0) {
+			aln.resize((size_t)rows);
+			rc = nabwa_batch_fetch(bt, n_aln.data(), aln.data(), rows, &rows, maxe.data());
+		}
 	}
+	nabwa_batch_destroy(bt);
+	if (rc != NABWA_OK) return rc;
 	int64_t a0 = 0;
 	for (int i = 0; i < n_seqs; ++i) {
 		nabwa_bwa_seq_t *p = seqs + i;

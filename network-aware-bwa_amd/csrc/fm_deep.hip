@@ -1,0 +1,28 @@
+// fm_deep.hip -- kernel D for gfx950: bwt_match_gap (bwtgap.c:104-266) for the deep searches, one search per wavefront.
+// The kernel body lives in fm_deep_body.hpp (design notes there); this file is its __global__ entry and launcher.
+// Block = ONE wave (64 threads): everything the wave shares (per-score counts and top pages) is its block's LDS, and
+// __syncthreads() is the wave's own memory fence.  Persistent grid: n_waves blocks draw reads from a counter.
+#include "fm_deep_body.hpp"
+
+#ifndef NABWA_DEEP_WAVES
+#define NABWA_DEEP_WAVES 4    // waves per SIMD the register budget is bounded for (128 VGPRs): 16 searches per CU
+#endif
+
+extern __shared__ uint32_t s_deep[];
+
+__global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
+{
+	deep_wave_body(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
+}
+
+extern "C" void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s)
+{
+	const size_t lds = (size_t)(2u * P->NS + DEEP_NEWP) * 4u;
+	hipLaunchKernelGGL(fm_deep_kernel, dim3(n_waves), dim3(64), lds, s, *P);
+}
+
+extern "C" int nabwa_deep_occupancy(int ns)
+{
+	int nb = 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_deep_kernel, 64, (size_t)(2u * (unsigned)ns + DEEP_NEWP) * 4u) == hipSuccess ? nb : 0;
+}

@@ -1,0 +1,34 @@
+// fm_deep.hpp -- parameter block of kernel D (fm_deep_body.hpp / fm_deep.hip), shared with the host API.
+#pragma once
+#include "fm_search.hpp"
+
+#define DEEP_PAGE_SH 8u
+#define DEEP_PAGE    (1u << DEEP_PAGE_SH)    /* entries per page */
+#define DEEP_NIL     0xffffffffu
+#define DEEP_NEWP    16u                       /* pages one commit can need at most (64 lanes x stage_k <= 48 entries) */
+#define DEEP_STAGE_MAX 48u
+#define DST_M 0
+#define DST_I 1
+#define DST_D 2
+#define DF_NONE 0
+#define DF_HIT  1
+#define DF_CONT 2
+#define DCL_MM 0u      /* child classes = the three scores a chain at score s pushes to: s + s_mm, s + s_gapo, s + s_gape */
+#define DCL_GO 1u
+#define DCL_GE 2u
+
+struct DeepParams {
+	SearchParams S;                  // index, reads, width records, options, outputs (n_aln / max_ent / status / aln by work item or res_slot)
+	uint4 *pages;                    // the pool: n_pages x 256 entries x 16 B
+	uint32_t *page_prev;             // per page: the page below it in its level's stack
+	uint32_t n_pages;
+	unsigned int *page_bump;         // pages handed out so far (a wave keeps what it took and re-uses it for its next reads)
+	uint32_t *own;                   // per wave 2 x own_cap ids: the pages it holds, and those of them that are free
+	uint32_t own_cap;
+	uint4 *stage;                    // per wave [64][stage_k]: the children of the running round
+	uint32_t stage_k;
+	uint32_t NS;                     // score levels (LDS: 2 x NS + DEEP_NEWP words per wave)
+	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
+	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures
+};
+

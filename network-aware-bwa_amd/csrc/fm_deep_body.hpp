@@ -26,47 +26,17 @@
 // The same source is compiled for gfx950 (fm_deep.hip) and, with NABWA_EMU, as a CPU emulation of one wave
 // (tests/emu/, test infrastructure): see wave_spmd.hpp.
 #pragma once
-#include "fm_search.hpp"
+#include "fm_deep.hpp"
 #include "wave_spmd.hpp"
-
-#define DEEP_PAGE_SH 8u
-#define DEEP_PAGE    (1u << DEEP_PAGE_SH)    /* entries per page */
-#define DEEP_NIL     0xffffffffu
-#define DEEP_NEWP    16u                       /* pages one commit can need at most (64 lanes x stage_k <= 48 entries) */
-#define DEEP_STAGE_MAX 48u
-#define DST_M 0
-#define DST_I 1
-#define DST_D 2
-#define DF_NONE 0
-#define DF_HIT  1
-#define DF_CONT 2
-#define DCL_MM 0u      /* child classes = the three scores a chain at score s pushes to: s + s_mm, s + s_gapo, s + s_gape */
-#define DCL_GO 1u
-#define DCL_GE 2u
-#define NABWA_ST_POOL   3   /* kernel D: the page pool ran dry under this read -- run it again in the guaranteed pass */
-#define NABWA_ST_HITCAP 4   /* more hit rows than the result rows given */
-
-struct DeepParams {
-	SearchParams S;                  // index, reads, width records, options, outputs (n_aln / max_ent / status / aln by work item or res_slot)
-	uint4 *pages;                    // the pool: n_pages x 256 entries x 16 B
-	uint32_t *page_prev;             // per page: the page below it in its level's stack
-	uint32_t n_pages;
-	unsigned int *page_bump;         // pages handed out so far (a wave keeps what it took and re-uses it for its next reads)
-	uint32_t *own;                   // per wave 2 x own_cap ids: the pages it holds, and those of them that are free
-	uint32_t own_cap;
-	uint4 *stage;                    // per wave [64][stage_k]: the children of the running round
-	uint32_t stage_k;
-	uint32_t NS;                     // score levels (LDS: 2 x NS + DEEP_NEWP words per wave)
-	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
-	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures
-};
 
 struct DeepLane { uint32_t k, l; int i, a, mm, go, ge, state, ldp; };
 
 #ifdef NABWA_EMU
 #define DEEP_FN static
+#define DEEP_ATOMIC_ADD_U64(p, v) (*(p) += (v))
 #else
 #define DEEP_FN __device__ __forceinline__
+#define DEEP_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 #endif
 
 DEEP_FN uint4 deep_pack(uint32_t k, uint32_t l, int i, int ldp, int mm, int go, int ge, int state, int a, uint32_t cls)
@@ -83,14 +53,17 @@ DEEP_FN void deep_unpack(const uint4 &r, DeepLane &e)
 }
 
 DEEP_FN int deep_ctz64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+// element c of a four-element array by selects: a dynamically indexed register array would live in scratch memory
+DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u ? a[0] : (c == 1u ? a[1] : (c == 2u ? a[2] : a[3])); }
 
 // One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
-DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
+DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #ifndef NABWA_EMU
 							, const int ln
 #endif
 							)
 {
+	const DeepParams P = P_;          /* (a by-value copy: the kernel argument stays in scalar registers / the kernarg segment) */
 	const SearchParams &S = P.S;
 	uint32_t *const s_cnt = lds, *const s_top = lds + P.NS, *const s_newp = lds + 2 * P.NS;
 	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
@@ -110,23 +83,27 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 	LANE(int, peak);          // the largest value `rel` had right before a pop
 	LANE(uint32_t, d); LANE(uint32_t, off);
 	LANE(int, nst);
+	LANE(uint32_t, tch);      // bucket touches of the reference algorithm in this lane's chain (instrumented runs only)
+	const bool counting = S.touch_counter != 0;
 
-	// n_new pages into s_newp[]: from this wave's free ones first, then from the pool
-	auto alloc_pages = [&](uint32_t n_new) -> bool {
-		const uint32_t take = n_new < n_free ? n_new : n_free;
-		LANES { if ((uint32_t)ln < take) s_newp[ln] = freep[n_free - 1u - (uint32_t)ln]; }
-		n_free -= take;
-		const uint32_t rest = n_new - take;
-		if (rest) {
-			LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(P.page_bump, rest); }
-			const uint32_t base = WBCAST(tu, 0);
-			if ((uint64_t)base + rest > P.n_pages || n_own + rest > P.own_cap) return false;
-			LANES { if ((uint32_t)ln < rest) { s_newp[take + (uint32_t)ln] = base + (uint32_t)ln; own[n_own + (uint32_t)ln] = base + (uint32_t)ln; } }
-			n_own += rest;
-		}
-		WAVE_SYNC();
-		return true;
-	};
+	// n_new pages into s_newp[]: from this wave's free ones first, then from the pool; ok_ = false when the pool is dry
+#define DEEP_ALLOC(n_new_, ok_) do { \
+		const uint32_t nn_ = (n_new_); \
+		const uint32_t take_ = nn_ < n_free ? nn_ : n_free; \
+		LANES { if ((uint32_t)ln < take_) s_newp[ln] = freep[n_free - 1u - (uint32_t)ln]; } \
+		n_free -= take_; \
+		const uint32_t rest_ = nn_ - take_; \
+		ok_ = true; \
+		if (rest_) { \
+			LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(P.page_bump, rest_); } \
+			const uint32_t base_ = WBCAST(tu, 0); \
+			if ((uint64_t)base_ + rest_ > P.n_pages || n_own + rest_ > P.own_cap) ok_ = false; \
+			else { \
+				LANES { if ((uint32_t)ln < rest_) { s_newp[take_ + (uint32_t)ln] = base_ + (uint32_t)ln; own[n_own + (uint32_t)ln] = base_ + (uint32_t)ln; } } \
+				n_own += rest_; \
+			} \
+		} \
+		WAVE_SYNC(); } while (0)
 
 	for (;;) {
 		LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(S.work_counter, 1u); }
@@ -140,6 +117,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 		uint8_t *const rec = S.wdata + (size_t)rid * S.wstride;
 		uint4 *const out = S.aln + (size_t)item * S.aln_cap;
 		int n_aln = 0, max_ent = 0, status = NABWA_ST_OK;
+		unsigned long long rd_touch = 0;
 
 		if (len > 0 && (int)S.rd_nN[rid] <= MD) {          // too many N: no search (bwtgap.c:118-123)
 			const bool seeded = len > S.seed_len;
@@ -152,7 +130,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 			bool done = false, careful = P.careful_all != 0;
 			uint32_t cur = 0;                                 // no level below `cur` holds an entry
 			// roots (bwtgap.c:127-128): strand 0 is pushed first, strand 1 second, so strand 1 is popped first
-			if (!alloc_pages(1)) { status = NABWA_ST_POOL; done = true; ++st_pool; }
+			bool got_page = false;
+			DEEP_ALLOC(1u, got_page);
+			if (!got_page) { status = NABWA_ST_POOL; done = true; ++st_pool; }
 			else {
 				const uint32_t p0 = s_newp[0];
 				ONE_LANE {
@@ -186,7 +166,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 				uint32_t prev_pg = DEEP_NIL;
 				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = P.page_prev[top_pg];
 				LANES {
-					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(np) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
+					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(np) = 0; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
 					if (L(act)) {
 						const uint32_t p = cs - 1u - (uint32_t)ln;
 						const uint32_t pg = (p >> DEEP_PAGE_SH) == topq ? top_pg : prev_pg;
@@ -225,7 +205,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 									if (c > 3u) { ok = false; break; }
 									Occ4 ck, cl;
 									nabwa_occ4_pair(B, k - 1u, l, ck, cl);
-									k = B.L2[c] + ck.c[c] + 1u; l = B.L2[c] + cl.c[c];
+									if (counting) L(tch) += ref_touches(B, k - 1u, l, false);
+									k = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u; l = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
 									if (k > l) { ok = false; break; }
 									--i;
 								}
@@ -237,6 +218,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 								const int i = E.i - 1;
 								Occ4 ck, cl;
 								nabwa_occ4_pair(B, E.k - 1u, E.l, ck, cl);
+								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, true);
 								const uint32_t occ = E.l - E.k + 1u;
 								bool allow_diff = true, allow_M = true;
 								if (i > 0) {
@@ -256,34 +238,38 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 								}
 								uint4 *const stg = stage + (size_t)ln * K;
 								// a child of class cls: counted always, staged unless it can never be popped (after the first hit the
-								// loop ends at the first pop above best_score + s_mm, bwtgap.c:144)
-								auto child = [&](uint32_t cls, uint32_t nk, uint32_t nl, int ni, int nmm, int ngo, int nge, int nstate) {
-									L(rel) += 1;
-									const int sc = cls == DCL_MM ? T0 : (cls == DCL_GO ? T1 : T2);
-									if (!nonstop && n_aln > 0 && sc > best_score + S.s_mm) return;
-									stg[L(np)] = deep_pack(nk, nl, ni, ni, nmm, ngo, nge, nstate, E.a, cls);
-									L(np) += 1;
-									const uint32_t cn = cls == DCL_MM ? 0u : (cls == DCL_GO ? can1 : can2);
-									if (cn == 0u) L(cc0) += 1; else if (cn == 1u) L(cc1) += 1; else L(cc2) += 1;
-								};
+								// loop ends at the first pop above best_score + s_mm, bwtgap.c:144).  (A macro, not a lambda: the closure
+								// of a by-reference lambda with this many captures is not dissolved by the compiler and drags every
+								// captured per-lane variable into scratch memory.)
+#define DEEP_CHILD(cls_, nk_, nl_, ni_, nmm_, ngo_, nge_, nstate_) do { \
+									L(rel) += 1; \
+									const int sc_ = (cls_) == DCL_MM ? T0 : ((cls_) == DCL_GO ? T1 : T2); \
+									if (nonstop || n_aln == 0 || sc_ <= best_score + S.s_mm) { \
+										stg[L(np)] = deep_pack((nk_), (nl_), (ni_), (ni_), (nmm_), (ngo_), (nge_), (nstate_), E.a, (cls_)); \
+										L(np) += 1; \
+										const uint32_t cn_ = (cls_) == DCL_MM ? 0u : ((cls_) == DCL_GO ? can1 : can2); \
+										if (cn_ == 0u) L(cc0) += 1; else if (cn_ == 1u) L(cc1) += 1; else L(cc2) += 1; \
+									} } while (0)
 								int tmp = E.go + E.ge;
 								if (loggap) { const uint32_t v = (uint32_t)(E.ge + E.go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
 								if (allow_diff && i >= S.indel_end_skip + tmp && len - i >= S.indel_end_skip + tmp) {
 									if (E.state == DST_M) {                                      // gap open: the insertion, then the deletions
 										if (E.go < MG) {
-											child(DCL_GO, E.k, E.l, i, E.mm, E.go + 1, E.ge, DST_I);
+											DEEP_CHILD(DCL_GO, E.k, E.l, i, E.mm, E.go + 1, E.ge, DST_I);
+#pragma unroll
 											for (int j = 0; j < 4; ++j) {
 												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
-												if (nk <= nl) child(DCL_GO, nk, nl, i + 1, E.mm, E.go + 1, E.ge, DST_D);
+												if (nk <= nl) DEEP_CHILD(DCL_GO, nk, nl, i + 1, E.mm, E.go + 1, E.ge, DST_D);
 											}
 										}
 									} else if (E.state == DST_I) {
-										if (E.ge < S.max_gape) child(DCL_GE, E.k, E.l, i, E.mm, E.go, E.ge + 1, DST_I);
+										if (E.ge < S.max_gape) DEEP_CHILD(DCL_GE, E.k, E.l, i, E.mm, E.go, E.ge + 1, DST_I);
 									} else if (E.ge < S.max_gape) {
 										if (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ) {
+#pragma unroll
 											for (int j = 0; j < 4; ++j) {
 												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
-												if (nk <= nl) child(DCL_GE, nk, nl, i + 1, E.mm, E.go, E.ge + 1, DST_D);
+												if (nk <= nl) DEEP_CHILD(DCL_GE, nk, nl, i + 1, E.mm, E.go, E.ge + 1, DST_D);
 											}
 										}
 									}
@@ -291,17 +277,18 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 								const uint32_t c = str[i];
 								bool match = false; uint32_t mk_ = 0, ml_ = 0;
 								if (allow_diff && allow_M) {
+#pragma unroll
 									for (int j = 1; j <= 4; ++j) {
 										const uint32_t x = (c + (uint32_t)j) & 3u;
 										const bool is_mm = j != 4 || c > 3u;
-										const uint32_t nk = B.L2[x] + ck.c[x] + 1u, nl = B.L2[x] + cl.c[x];
+										const uint32_t nk = deep_sel4(B.L2, x) + deep_sel4(ck.c, x) + 1u, nl = deep_sel4(B.L2, x) + deep_sel4(cl.c, x);
 										if (nk <= nl) {
-											if (is_mm) child(DCL_MM, nk, nl, i, E.mm + 1, E.go, E.ge, DST_M);
+											if (is_mm) DEEP_CHILD(DCL_MM, nk, nl, i, E.mm + 1, E.go, E.ge, DST_M);
 											else { match = true; mk_ = nk; ml_ = nl; }
 										}
 									}
 								} else if (c < 4u) {
-									const uint32_t nk = B.L2[c] + ck.c[c] + 1u, nl = B.L2[c] + cl.c[c];
+									const uint32_t nk = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u, nl = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
 									if (nk <= nl) { match = true; mk_ = nk; ml_ = nl; }
 								}
 								// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
@@ -334,6 +321,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 				LANES { L(tu) = (uint32_t)(L(nst) + L(rel)); }
 				n_entries = (int)WBCAST(tu, jl);
 				st_commit += (unsigned)(jl + 1);
+				if (counting) { uint32_t tt = 0; LANES { L(d) = ln <= jl ? L(tch) : 0u; } WEXSCAN_U32(L(off), L(d), tt); rd_touch += tt; }
 				// the popped entries leave level s
 				const uint32_t newc = cs - (uint32_t)(jl + 1);
 				ONE_LANE { s_cnt[s] = newc; }
@@ -355,7 +343,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 					const uint32_t cT = s_cnt[Tc], old_top = s_top[Tc];
 					const uint32_t q_new = cT ? ((cT - 1u) >> DEEP_PAGE_SH) + 1u : 0u, q_last = (cT + tot - 1u) >> DEEP_PAGE_SH;
 					const uint32_t n_new = q_last + 1u > q_new ? q_last + 1u - q_new : 0u;
-					if (n_new && !alloc_pages(n_new)) { pool_fail = true; break; }
+					if (n_new) { bool okp = false; DEEP_ALLOC(n_new, okp); if (!okp) { pool_fail = true; break; } }
 					ONE_LANE {
 						for (uint32_t t = 0; t < n_new; ++t) P.page_prev[s_newp[t]] = t ? s_newp[t - 1u] : old_top;
 						s_cnt[Tc] = cT + tot;
@@ -383,7 +371,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 					// the chain of lane jl goes on in the next round: its current entry is the newest of level s again
 					const uint32_t cT = s_cnt[s], old_top = s_top[s];
 					const bool need = (cT & (DEEP_PAGE - 1u)) == 0u;
-					if (need && !alloc_pages(1)) pool_fail = true;
+					bool okp = true;
+					if (need) DEEP_ALLOC(1u, okp);
+					if (!okp) pool_fail = true;
 					else {
 						const uint32_t pg = need ? s_newp[0] : old_top;
 						ONE_LANE { if (need) { P.page_prev[pg] = old_top; s_top[s] = pg; } s_cnt[s] = cT + 1u; }
@@ -410,8 +400,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 					if (score == best_score) best_cnt += (int)(hl - hk + 1u);
 					else if (best_cnt > S.max_top2) { done = true; do_add = false; }
 					if (do_add && h_go) {       // a gap in a tandem repeat finds the same interval again (bwtgap.c:179-183)
-						const uint64_t dup = WBALLOT([&]() -> bool { bool f = false; for (int j = ln; j < n_aln; j += 64) { const uint4 h = out[j]; if (h.y == hk && h.z == hl) f = true; } return f; }());
-						if (dup) do_add = false;
+						LANES { L(tu) = 0u; for (int j = ln; j < n_aln; j += 64) { const uint4 h = out[j]; if (h.y == hk && h.z == hl) L(tu) = 1u; } }
+						if (WBALLOT(L(tu) != 0u)) do_add = false;
 					}
 					if (do_add) {
 						if (n_aln == S.aln_cap) { status = NABWA_ST_HITCAP; done = true; }
@@ -452,6 +442,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P, uint32_t *lds, uint32_t wave
 			}
 		}
 		ONE_LANE { S.n_aln[item] = n_aln; S.max_ent[item] = max_ent; S.status[item] = (uint8_t)status; }
+		if (counting && status == NABWA_ST_OK) { ONE_LANE { DEEP_ATOMIC_ADD_U64(S.touch_counter, rd_touch); } }
 	}
 	if (P.stats) {
 		ONE_LANE {

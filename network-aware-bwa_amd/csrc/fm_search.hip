@@ -64,19 +64,6 @@
 #define NABWA_RUN_MAX 4   // levels one text-form trip may walk (every lane of the wave waits for the longest walk)
 #endif
 
-// bucket touches the REFERENCE algorithm performs for one (k-1, l) query: one per
-// bwt_occ / bwt_occ4 body execution, one for a same-128-row-block pair (bwt.c:92-216)
-__device__ __forceinline__ uint32_t ref_touches(const DevBwt &B, uint32_t kq, uint32_t lq, bool four)
-{
-	const uint32_t NEG = 0xffffffffu;
-	const uint32_t bk = (kq == NEG || (!four && kq == B.seq_len)) ? 0u : 1u;
-	const uint32_t bl = (lq == NEG || (!four && lq == B.seq_len)) ? 0u : 1u;
-	if (kq == lq) return bk;
-	const uint32_t _k = kq - (kq >= B.primary ? 1u : 0u), _l = lq - (lq >= B.primary ? 1u : 0u);
-	if (!(_l >> 7 != _k >> 7 || kq == NEG || lq == NEG)) return 1u;
-	return bk + bl;
-}
-
 // 16-byte register windows are kept as two separate 64-bit scalars and indexed with a select and a
 // shift: a dynamically indexed uint4 (or a struct of two halves) makes hipcc keep the value in
 // scratch and load one piece back.
@@ -1146,21 +1133,19 @@ extern "C" void nabwa_launch_padded_len(int n, const int64_t *off, int64_t *plen
 	hipLaunchKernelGGL(padded_len_kernel, dim3(n / 256 + 1), dim3(256), 0, s, n, off, plen);
 }
 
-// ids of the reads whose first pass was abandoned (arena or hit list outgrown)
 __global__ __launch_bounds__(256) void collect_kernel(int n, const uint8_t *__restrict__ status, int32_t *__restrict__ ids,
-												  unsigned int *__restrict__ count)
+												  unsigned int *__restrict__ count, int which)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n && status[i] == NABWA_ST_OVERFLOW) ids[atomicAdd(count, 1u)] = i;
+	if (i < n && status[i] == which) ids[atomicAdd(count, 1u)] = i;
 }
 
-extern "C" void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, hipStream_t s)
+// ids of the reads whose status is `which` (NABWA_ST_OVERFLOW after kernel S, NABWA_ST_POOL / NABWA_ST_HITCAP after kernel D)
+extern "C" void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which, hipStream_t s)
 {
 	if (n <= 0) return;
-	hipLaunchKernelGGL(collect_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, status, ids, count);
+	hipLaunchKernelGGL(collect_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, status, ids, count, which);
 }
-
-#define NABWA_ST_WIDE 2   // result lives in the wide pass's buffers at wide_idx[read]
 
 __global__ __launch_bounds__(256) void scatter_wide_kernel(int n2, const int32_t *__restrict__ ids, const int32_t *__restrict__ n_aln2,
 													   const int32_t *__restrict__ max_ent2, const uint8_t *__restrict__ status2,
@@ -1171,7 +1156,7 @@ __global__ __launch_bounds__(256) void scatter_wide_kernel(int n2, const int32_t
 	if (q >= n2) return;
 	const int rid = ids[q], j = wide_idx[rid];       /* j: the read's row in the wide result arrays (assign_slots_kernel) */
 	if (status2[j] == NABWA_ST_OK) { n_aln[rid] = n_aln2[j]; max_ent[rid] = max_ent2[j]; status[rid] = NABWA_ST_WIDE; }
-	else { n_aln[rid] = 0; max_ent[rid] = max_ent2[j]; status[rid] = NABWA_ST_OVERFLOW; }
+	else { n_aln[rid] = 0; max_ent[rid] = max_ent2[j]; status[rid] = status2[j]; }     /* NABWA_ST_POOL / NABWA_ST_HITCAP: the host decides */
 }
 
 // the reads that go to the wide passes get a row each in the wide result arrays; it stays theirs over the tiers

@@ -5,7 +5,10 @@
 
 #define NABWA_SEARCH_BLOCK 256
 #define NABWA_ST_OK        0
-#define NABWA_ST_OVERFLOW  1   // arena or hit list outgrown in the first pass: re-run in the wide pass
+#define NABWA_ST_OVERFLOW  1   // arena or hit list outgrown in the first pass (kernel S): the read goes to kernel D
+#define NABWA_ST_WIDE      2   // resolved by kernel D: the result lives in the wide result arrays at wide_idx[read]
+#define NABWA_ST_POOL      3   // kernel D: the page pool ran dry under this read -- it is run again in the guaranteed pass
+#define NABWA_ST_HITCAP    4   // kernel D: more hit rows than the wide result rows (NABWA_ALNCAP2)
 
 struct SearchParams {
 	DevBwt bwt[2];

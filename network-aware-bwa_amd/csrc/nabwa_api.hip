@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../include/nabwa.h"
 #include "fm_search.hpp"
+#include "fm_deep.hpp"
 #include "nabwa_internal.hpp"
 
 extern "C" {
@@ -29,7 +30,9 @@ int nabwa_width_occupancy(void);
 void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
 						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
-void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, hipStream_t s);
+void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which, hipStream_t s);
+void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s);
+int nabwa_deep_occupancy(int ns);
 void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s);
 void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
 							   const uint8_t *status2, int32_t *n_aln, int32_t *max_ent, uint8_t *status,
@@ -418,6 +421,10 @@ struct nabwa_batch {
 	int n2, aln_cap2; uint8_t *d_scratch2; size_t scratch2_bytes; int32_t *d_naln2, *d_maxent2; uint8_t *d_status2; uint4 *d_aln2;
 	int unresolved;
 	unsigned long long *d_sum;
+	// kernel D (deep searches): page pool, per-wave page lists and staging, counters; allocated on demand, kept for the next run
+	uint4 *d_pages; uint32_t *d_page_prev, *d_deep_own; uint4 *d_deep_stage; unsigned long long *d_deep_ctr;
+	size_t deep_pages, deep_own_words, deep_stage_ent;
+	hipEvent_t evd0, evd1; float last_ms_deep; int deep_ran, deep_only;
 };
 
 static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
@@ -427,7 +434,7 @@ static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int se
 	// per-read width record
 	P.WL = align_up((uint32_t)max_len + 1, 16);
 	P.WLB = P.WL + 16;
-	P.SLB = align_up((uint32_t)seed_len + 1, 16) + 16;
+	P.SLB = align_up((uint32_t)(max_len > seed_len ? seed_len : 0) + 1, 16) + 16;      /* seed bounds exist only for reads longer than the seed (bwtaln.c:126-130) */
 	P.woff_bid = 2 * P.WL * 4;
 	P.woff_sbid = P.woff_bid + 2 * P.WLB;
 	P.wstride = align_up(P.woff_sbid + 2 * P.SLB, 64);
@@ -446,12 +453,14 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 	(void)hipSetDevice(b->ix->device);
 	void *ptrs[] = { b->d_pack, b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
-					 b->d_status2, b->d_aln2, b->d_sum };
+					 b->d_status2, b->d_aln2, b->d_sum, b->d_pages, b->d_page_prev, b->d_deep_own, b->d_deep_stage, b->d_deep_ctr };
 	if (b->stream) (void)hipStreamSynchronize(b->stream);      /* the buffers go back to the pool, not to the driver: nothing may still use them */
 	for (void *p : ptrs) if (p) (void)pool_free(b->ix, p);
 	if (b->ev0) (void)hipEventDestroy(b->ev0);
 	if (b->ev1) (void)hipEventDestroy(b->ev1);
 	if (b->evw) (void)hipEventDestroy(b->evw);
+	if (b->evd0) (void)hipEventDestroy(b->evd0);
+	if (b->evd1) (void)hipEventDestroy(b->evd1);
 	if (b->stream) (void)hipStreamDestroy(b->stream);
 	delete b;
 }
@@ -512,8 +521,8 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 		const int md_sizing = md_of[per_read ? L : max_len];
 		int g = opt->max_gapo; if (md_sizing < g) g = md_sizing;
 		const int d = md_of[L];
-		/* first-pass arena entries keep n_mm / n_gapo in 4 bits and n_gape in 5 (fm_search.hip) */
-		if (d < 0 || d > 14 || g < 0 || g > 15) return fail(NABWA_EINVAL, "max_diff > 14 or max_gapo > 15 (unsupported)");
+		/* kernel D's entries keep n_mm / n_gapo / n_gape in 8 bits each, the bound bytes of kernel W hold min(bid, 127) */
+		if (d < 0 || d > 126 || g < 0 || g > 255) return fail(NABWA_EINVAL, "max_diff > 126 or max_gapo > 255 (unsupported)");
 		md_tab[L] = (uint8_t)d; mg_tab[L] = (uint8_t)g;
 		if (d > mdx) mdx = d;
 		if (g > mgx) mgx = g;
@@ -536,18 +545,24 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 				}
 		if (NS1 > NS) NS1 = NS;
 	}
-	if (NS > 128 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 31)
-		return fail(NABWA_EINVAL, "option block needs more than 128 score levels (unsupported)");
+	/* the reference packs the score into 11 bits (bwtgap.c:58) */
+	if (NS > 2048 || opt->s_mm < 0 || opt->s_gapo < 0 || opt->s_gape < 0 || opt->max_gape < 0 || opt->max_gape > 255)
+		return fail(NABWA_EINVAL, "option block needs more than 2048 score levels (the reference's own limit)");
+	/* first-pass (kernel S) arena entries keep n_mm / n_gapo in 4 bits and n_gape in 5, and it tracks 64 score levels:
+	 * option blocks beyond that go to kernel D whole */
+	const bool deep_only = mdx > 14 || mgx > 15 || opt->max_gape > 31 || NS1 > 64;
 	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
 
 	const double tc1 = now();
 	nabwa_batch *b = new nabwa_batch();
 	memset(b, 0, sizeof(*b));
-	b->ix = ix; b->opt = *opt; b->n = n;
+	b->ix = ix; b->opt = *opt; b->n = n; b->deep_only = deep_only ? 1 : 0;
 	BCHK(hipStreamCreate(&b->stream));
 	BCHK(hipEventCreate(&b->ev0));
 	BCHK(hipEventCreate(&b->ev1));
 	BCHK(hipEventCreate(&b->evw));
+	BCHK(hipEventCreate(&b->evd0));
+	BCHK(hipEventCreate(&b->evd1));
 	// reads: upload as given, then re-lay out on the device with 16-byte aligned starts
 	const size_t nb = (size_t)off[n] > 0 ? (size_t)off[n] : 1, pnb = (size_t)padded_total + 64;
 	if ((uint64_t)pnb >= (1ull << 32)) { nabwa_batch_destroy(b); return fail(NABWA_EINVAL, "batch holds 4 Gi padded bases or more: split it (lane state keeps a 32-bit read offset)"); }
@@ -599,7 +614,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	int cap1 = env_int("NABWA_CAP1", 4096);
 	if (cap1 < 16) cap1 = 16;
 	if (cap1 > 65534) cap1 = 65534;
-	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, NS1);
+	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, deep_only ? 1u : NS1);
 	b->NS_wide = NS;
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
@@ -611,7 +626,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 
 	hipDeviceProp_t prop;
 	BCHK(hipGetDeviceProperties(&prop, ix->device));
-	int occ = nabwa_search_occupancy(0, (int)NS1);
+	int occ = nabwa_search_occupancy(0, deep_only ? 1 : (int)NS1);
 	if (occ < 1) occ = 1;
 	const int occ_env = env_int("NABWA_BLOCKS_PER_CU", 0);
 	if (occ_env > 0) occ = occ_env;
@@ -660,13 +675,13 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	}
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
 	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls + 10 : 0;
-	if (b->P.NS <= 64) nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
-	else {      /* the first-pass kernel tracks at most 64 score levels: such option blocks go through the second pass whole */
+	if (!b->deep_only) nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
+	else {      /* option blocks the first-pass kernel's compact entries cannot hold: every read goes to kernel D */
 		HIPCHK(hipMemsetAsync(b->d_status, NABWA_ST_OVERFLOW, b->n, b->stream));
 		HIPCHK(hipMemsetAsync(b->d_naln, 0, (size_t)b->n * 4, b->stream));
 	}
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
-	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
+	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->stream);
 	HIPCHK(hipGetLastError());
 	return NABWA_OK;
 }
@@ -684,110 +699,175 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	HIPCHK(hipEventElapsedTime(&b->last_ms_w, b->evw, b->ev0));
 	if (n_second_pass) *n_second_pass = (int)novf;
 	if (novf == 0) return NABWA_OK;
-	// ---- the flagged reads again, from scratch, in tiers of growing arenas and shrinking lane counts (all tiers share one
-	// scratch allocation of NABWA_WIDE_GB; a tier gets as many lanes as arenas of its size fit into it):
-	//   A  the first-pass kernel once more with the largest arena its 16-bit links address (65534 pushes);
-	//   B  the WIDE kernel (slot reuse, 32-bit links, results in the wide arrays) with 2^17, then 2^19 live entries
-	//      (each only while more reads are left than the last tier has lanes for);
-	//   C  the WIDE kernel with max_entries + 16 live entries -- the reference's own bound (bwtgap.c:140).
-	// With default options almost nothing gets here.  With the options ancient-DNA pipelines use (-n 0.01 -o 2 -l 16500, the
-	// seed off) a third of the reads outgrow the first pass and a few per cent hold > 65536 live entries.
+	// ---- the flagged reads go to kernel D (fm_deep_body.hpp): one search per wavefront, arenas paged out of one pool.
+	// (Round 1 re-ran them from scratch on one lane each in tiers of growing per-lane arenas: 22 k reads/s on the
+	// ancient-DNA workload, the launch as long as its longest search.)  Optionally the first-pass kernel runs once more
+	// before that with the largest arena its 16-bit links address (NABWA_TIER_A=1).
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	const uint64_t cap_full = (uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 16;
-	size_t budget = (size_t)env_int("NABWA_WIDE_GB", 64) << 30;
-	{
-		size_t fr = 0, tot = 0;
-		HIPCHK(hipMemGetInfo(&fr, &tot));
-		size_t avail = fr + b->scratch2_bytes;
-		{ std::lock_guard<std::mutex> lk(b->ix->pool->mu); avail += b->ix->pool->idle_bytes; }
-		avail = avail > ((size_t)4 << 30) ? avail - ((size_t)4 << 30) : 0;
-		if (budget > avail) budget = avail;
-	}
-	struct Tier { uint64_t cap; bool wide; };
-	std::vector<Tier> tiers;
-	if (env_int("NABWA_TIER_A", 1) && b->P.NS <= 64 && b->P.cap < 65534) tiers.push_back({ 65534, false });
-	const uint64_t cap_b = (uint64_t)env_int("NABWA_TIER_B_CAP", 1 << 17);          /* (tests shrink it to reach tier C) */
-	if (env_int("NABWA_TIER_B", 1) && cap_full > cap_b && cap_b >= 16) tiers.push_back({ cap_b, true });
-	if (env_int("NABWA_TIER_B", 1) && cap_full > (1u << 19) && cap_b < (1u << 19)) tiers.push_back({ 1u << 19, true });
-	tiers.push_back({ cap_full, true });
-	/* an intermediate wide tier is skipped when the full-size tier has lanes for what is left (two reads per lane): the
-	 * largest searches are dependent chains of tens of seconds, and the sooner they start in the arena that can hold them
-	 * the sooner the launch ends; the intermediate tiers only exist to keep that last tier from becoming work-bound */
-	long lanes_full = 0;
-	{
-		SearchParams QL = b->P;
-		layout(QL, (uint32_t)cap_full, true, b->max_len, b->opt.seed_len, b->NS_wide);
-		lanes_full = (long)(budget / QL.lane_stride) / NABWA_SEARCH_BLOCK * NABWA_SEARCH_BLOCK;
-		if (lanes_full < NABWA_SEARCH_BLOCK) lanes_full = NABWA_SEARCH_BLOCK;
-	}
-	const bool may_skip = env_int("NABWA_TIER_SKIP", 1) != 0;
 	unsigned int cur = novf;
-	bool slots = false;
-	for (size_t ti = 0; ti < tiers.size() && cur; ++ti) {
-		const Tier T = tiers[ti];
-		if (T.wide && ti + 1 < tiers.size() && may_skip && (long)cur <= 2 * lanes_full) continue;
+	b->deep_ran = 0; b->last_ms_deep = 0.f;
+	// the kernel-W records of the listed reads again: a search edits them in place (gap_shadow)
+	auto rebuild_widths = [&](const SearchParams &Q, unsigned int cnt) {
+		SearchParams QW = Q; QW.touch_counter = 0; QW.rd_cls = 0; QW.n_sync = 0; QW.w_sync = 0;
+		QW.n_aln = b->d_naln; QW.max_ent = b->d_maxent; QW.status = b->d_status; QW.aln = b->d_aln; QW.aln_cap = b->P.aln_cap;
+		long bw2 = (2 * (long)cnt + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
+		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
+		nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
+	};
+	auto recollect = [&](int which, unsigned int *left) -> int {
+		HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
+		nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, which, b->stream);
+		HIPCHK(hipMemcpyAsync(left, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
+		HIPCHK(hipStreamSynchronize(b->stream));
+		return NABWA_OK;
+	};
+	if (env_int("NABWA_TIER_A", 0) && b->P.cap < 65534 && b->deep_only == 0) {
 		const double tt0 = now();
 		SearchParams Q = b->P;
-		layout(Q, (uint32_t)T.cap, T.wide, b->max_len, b->opt.seed_len, T.wide ? b->NS_wide : b->P.NS);
+		layout(Q, 65534u, false, b->max_len, b->opt.seed_len, b->P.NS);
 		long blocks = ((long)cur + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
-		long fit = (long)(budget / ((size_t)NABWA_SEARCH_BLOCK * Q.lane_stride));
-		if (T.wide && ti + 1 == tiers.size() && getenv("NABWA_WIDE_BLOCKS")) fit = env_int("NABWA_WIDE_BLOCKS", 2);
-		if (fit < 1) fit = 1;
-		if (blocks > fit) blocks = fit;
-		if (blocks > 4096) blocks = 4096;
+		size_t budget = (size_t)env_int("NABWA_WIDE_GB", 32) << 30;
+		const long fit = (long)(budget / ((size_t)NABWA_SEARCH_BLOCK * Q.lane_stride));
+		if (blocks > fit) blocks = fit < 1 ? 1 : fit;
 		const size_t need = (size_t)blocks * NABWA_SEARCH_BLOCK * Q.lane_stride;
 		if (b->scratch2_bytes < need) {
 			if (b->d_scratch2) { HIPCHK(pool_free(b->ix, b->d_scratch2)); b->d_scratch2 = 0; b->scratch2_bytes = 0; }
 			HIPCHK(pool_malloc(b->ix, (void**)&b->d_scratch2, need));
 			b->scratch2_bytes = need;
 		}
-		if (T.wide && !slots) {       /* rows of the wide result arrays for the reads that are left now */
-			if (b->n2 < (int)cur) {
-				void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
-				for (void *p : old) if (p) (void)pool_free(b->ix, p);
-				b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
-				b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
-				HIPCHK(pool_malloc(b->ix, (void**)&b->d_naln2, (size_t)cur * 4)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_maxent2, (size_t)cur * 4));
-				HIPCHK(pool_malloc(b->ix, (void**)&b->d_status2, cur)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_aln2, (size_t)cur * b->aln_cap2 * 16));
-				b->n2 = (int)cur;
-			}
-			nabwa_launch_assign_slots((int)cur, b->d_ovf_ids, b->d_wide_idx, b->stream);
-			slots = true;
-		}
 		Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)cur; Q.n_sync = 0; Q.w_sync = 0;
-		Q.wide_inline = env_int("NABWA_WIDE_INLINE", 1);
-		if (T.wide) { Q.res_slot = b->d_wide_idx; Q.n_aln = b->d_naln2; Q.max_ent = b->d_maxent2; Q.status = b->d_status2; Q.aln = b->d_aln2; Q.aln_cap = b->aln_cap2; }
+		rebuild_widths(Q, cur);
 		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-		{	// the pass before edited these reads' width records in place (gap_shadow): rebuild them
-			SearchParams QW = Q; QW.touch_counter = 0; QW.rd_cls = 0;
-			QW.n_aln = b->d_naln; QW.max_ent = b->d_maxent; QW.status = b->d_status; QW.aln = b->d_aln; QW.aln_cap = b->P.aln_cap;
-			long bw2 = (2 * (long)cur + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
-			if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
-			nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
-		}
-		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-		nabwa_launch_fm_search(&Q, (int)blocks, T.wide ? 1 : 0, b->stream);
-		if (T.wide) nabwa_launch_scatter_wide((int)cur, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
-											  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
+		nabwa_launch_fm_search(&Q, (int)blocks, 0, b->stream);
 		HIPCHK(hipGetLastError());
-		// what is still flagged goes on to the next tier; after the last one it is reported (hit list > NABWA_ALNCAP2), never dropped
-		HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
-		nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, b->stream);
 		unsigned int left = 0;
-		HIPCHK(hipMemcpyAsync(&left, b->d_novf, 4, hipMemcpyDeviceToHost, b->stream));
-		HIPCHK(hipStreamSynchronize(b->stream));
-		if (timing) fprintf(stderr, "[nabwa] tier %s, arena of %llu entries: %u reads on %ld blocks, %u left, %.3f s\n",
-							T.wide ? "wide" : "first-pass kernel", (unsigned long long)T.cap, cur, blocks, left, now() - tt0);
+		int r = recollect(NABWA_ST_OVERFLOW, &left);
+		if (r != NABWA_OK) return r;
+		if (timing) fprintf(stderr, "[nabwa] first-pass kernel again, arena of 65534 entries: %u reads on %ld blocks, %u left, %.3f s\n", cur, blocks, left, now() - tt0);
 		cur = left;
 	}
-	b->unresolved = (int)cur;
-	if (cur) return fail(NABWA_ECAP, "reads with more hits than NABWA_ALNCAP2 rows");
+	if (cur) {
+		/* a chain's matching child must be the only child of its own score (fm_deep_body.hpp) */
+		if (b->opt.s_mm < 1 || b->opt.s_gapo < 1 || b->opt.s_gape < 1) return fail(NABWA_EINVAL, "deep searches need s_mm, s_gapo, s_gape >= 1");
+		const double tt0 = now();
+		hipDeviceProp_t prop;
+		HIPCHK(hipGetDeviceProperties(&prop, b->ix->device));
+		const uint32_t NS = b->NS_wide;
+		// rows of the wide result arrays for the reads that are left
+		if (b->n2 < (int)cur || b->aln_cap2 != env_int("NABWA_ALNCAP2", 1024)) {
+			void *old[] = { b->d_naln2, b->d_maxent2, b->d_status2, b->d_aln2 };
+			for (void *p : old) if (p) (void)pool_free(b->ix, p);
+			b->d_naln2 = b->d_maxent2 = 0; b->d_status2 = 0; b->d_aln2 = 0;
+			b->aln_cap2 = env_int("NABWA_ALNCAP2", 1024);
+			if (b->aln_cap2 < 1) b->aln_cap2 = 1;
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_naln2, (size_t)cur * 4)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_maxent2, (size_t)cur * 4));
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_status2, cur)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_aln2, (size_t)cur * b->aln_cap2 * 16));
+			b->n2 = (int)cur;
+		}
+		nabwa_launch_assign_slots((int)cur, b->d_ovf_ids, b->d_wide_idx, b->stream);
+		// working memory of kernel D
+		uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 32);
+		if (K < 9u) K = 9u;
+		if (K > DEEP_STAGE_MAX) K = DEEP_STAGE_MAX;
+		int occ = nabwa_deep_occupancy((int)NS);
+		if (occ < 1) occ = 1;
+		if (env_int("NABWA_DEEP_WAVES_PER_CU", 0) > 0) occ = env_int("NABWA_DEEP_WAVES_PER_CU", 0);
+		long n_waves = (long)prop.multiProcessorCount * occ;
+		if (n_waves > (long)cur) n_waves = (long)cur;
+		size_t budget = (size_t)env_int("NABWA_DEEP_GB", 32) << 30;
+		{
+			size_t fr = 0, tot = 0;
+			HIPCHK(hipMemGetInfo(&fr, &tot));
+			size_t avail = fr + b->deep_pages * ((size_t)DEEP_PAGE * 16 + 4);
+			{ std::lock_guard<std::mutex> lk(b->ix->pool->mu); avail += b->ix->pool->idle_bytes; }
+			avail = avail > ((size_t)6 << 30) ? avail - ((size_t)6 << 30) : ((size_t)64 << 20);
+			if (budget > avail) budget = avail;
+		}
+		if (getenv("NABWA_DEEP_PAGES")) budget = (size_t)env_int("NABWA_DEEP_PAGES", 64) * ((size_t)DEEP_PAGE * 16 + 4);     /* (tests: a pool that runs dry) */
+		size_t n_pages = budget / ((size_t)DEEP_PAGE * 16 + 4);
+		if (n_pages > 0xfffffff0ull) n_pages = 0xfffffff0ull;
+		if (n_pages < 2) n_pages = 2;
+		// pages one search can hold at most: its live entries are bounded by the cut-off (bwtgap.c:140) plus one round's
+		// children, and every score level may have a partly filled page
+		uint64_t cap_pages = ((uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 64ull * K + 2) / DEEP_PAGE + NS + 4;
+		if (cap_pages > n_pages) cap_pages = n_pages;
+		if (b->deep_pages < n_pages) {
+			if (b->d_pages) { HIPCHK(pool_free(b->ix, b->d_pages)); HIPCHK(pool_free(b->ix, b->d_page_prev)); b->d_pages = 0; b->d_page_prev = 0; b->deep_pages = 0; }
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_pages, n_pages * DEEP_PAGE * 16)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_page_prev, n_pages * 4));
+			b->deep_pages = n_pages;
+		}
+		const size_t own_words = (size_t)n_waves * 2 * cap_pages, stage_ent = (size_t)n_waves * 64 * K;
+		if (b->deep_own_words < own_words) {
+			if (b->d_deep_own) HIPCHK(pool_free(b->ix, b->d_deep_own));
+			b->d_deep_own = 0; b->deep_own_words = 0;
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_own, own_words * 4)); b->deep_own_words = own_words;
+		}
+		if (b->deep_stage_ent < stage_ent) {
+			if (b->d_deep_stage) HIPCHK(pool_free(b->ix, b->d_deep_stage));
+			b->d_deep_stage = 0; b->deep_stage_ent = 0;
+			HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_stage, stage_ent * 16)); b->deep_stage_ent = stage_ent;
+		}
+		if (!b->d_deep_ctr) HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_ctr, 128));
+		DeepParams D;
+		memset(&D, 0, sizeof(D));
+		D.S = b->P;
+		D.S.ids = b->d_ovf_ids; D.S.n_sync = 0; D.S.w_sync = 0; D.S.res_slot = b->d_wide_idx;
+		D.S.n_aln = b->d_naln2; D.S.max_ent = b->d_maxent2; D.S.status = b->d_status2; D.S.aln = b->d_aln2; D.S.aln_cap = b->aln_cap2;
+		D.pages = b->d_pages; D.page_prev = b->d_page_prev; D.n_pages = (uint32_t)n_pages;
+		D.page_bump = (unsigned int*)(b->d_deep_ctr + 8);
+		D.own = b->d_deep_own; D.stage = b->d_deep_stage; D.stage_k = K; D.NS = NS;
+		D.careful_all = env_int("NABWA_DEEP_CAREFUL", 0); D.max_lanes = env_int("NABWA_DEEP_LANES", 64);
+		if (D.max_lanes < 1) D.max_lanes = 1;
+		if (D.max_lanes > 64) D.max_lanes = 64;
+		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
+		// pass 1: as many waves as fit the CUs, pages on demand; pass 2 (only if the pool ran dry under some reads): as many
+		// waves as the pool can serve in the worst case
+		unsigned int todo = cur, n_pool = 0;
+		for (int pass = 0; pass < 2 && todo; ++pass) {
+			long waves = n_waves, own_cap = (long)cap_pages;
+			if (pass == 1) {
+				waves = (long)(n_pages / cap_pages);
+				if (waves < 1) waves = 1;
+				if (waves > n_waves) waves = n_waves;
+			}
+			if (waves > (long)todo) waves = (long)todo;
+			D.S.n = (int)todo; D.own_cap = (uint32_t)own_cap;
+			rebuild_widths(D.S, todo);
+			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
+			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 128, b->stream));
+			D.S.work_counter = b->d_counter;
+			if (pass == 0) HIPCHK(hipEventRecord(b->evd0, b->stream));
+			nabwa_launch_fm_deep(&D, (int)waves, b->stream);
+			if (pass == 0) HIPCHK(hipEventRecord(b->evd1, b->stream));
+			nabwa_launch_scatter_wide((int)todo, b->d_ovf_ids, b->d_naln2, b->d_maxent2, b->d_status2,
+									  b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, b->stream);
+			HIPCHK(hipGetLastError());
+			int r = recollect(NABWA_ST_POOL, &n_pool);
+			if (r != NABWA_OK) return r;
+			if (timing) {
+				unsigned long long st[16];
+				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 128, hipMemcpyDeviceToHost));
+				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu\n",
+						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4]);
+			}
+			todo = n_pool;
+		}
+		b->deep_ran = 1;
+		HIPCHK(hipEventElapsedTime(&b->last_ms_deep, b->evd0, b->evd1));
+		if (todo) { b->unresolved = (int)todo; return fail(NABWA_ENOMEM, "kernel D: the page pool cannot hold one worst-case search (raise NABWA_DEEP_GB or lower max_entries)"); }
+		unsigned int n_hit = 0;
+		int r = recollect(NABWA_ST_HITCAP, &n_hit);
+		if (r != NABWA_OK) return r;
+		b->unresolved = (int)n_hit;
+		if (n_hit) return fail(NABWA_EHITS, "reads with more hit rows than NABWA_ALNCAP2: raise it (their n_aln is reported as 0, every other read is resolved)");
+	}
 	return NABWA_OK;
 }
 
 extern "C" float nabwa_batch_last_kernel_ms(nabwa_batch_t *b) { return b ? b->last_ms : 0.f; }
 extern "C" float nabwa_batch_last_width_ms(nabwa_batch_t *b) { return b ? b->last_ms_w : 0.f; }
+extern "C" float nabwa_batch_last_deep_ms(nabwa_batch_t *b) { return b ? b->last_ms_deep : 0.f; }
 
 /* One extra, untimed run of both passes with the instrumented kernel: total Occ-bucket touches the
  * REFERENCE algorithm performs on this batch (the "algorithmic bytes" of the roofline are 48 B each). */
@@ -886,6 +966,7 @@ extern "C" int nabwa_cal_sa_reg_gap(nabwa_index_t *ix, const nabwa_gap_opt_t *op
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = now();
+	if (n_rows) *n_rows = 0;
 	int r = nabwa_batch_create(ix, opt, n, off, seq, rseq, per_read, &b);
 	if (r != NABWA_OK) return r;
 	const double t1 = now();
@@ -893,6 +974,11 @@ extern "C" int nabwa_cal_sa_reg_gap(nabwa_index_t *ix, const nabwa_gap_opt_t *op
 	if (r == NABWA_OK) r = nabwa_batch_sync(b, 0);
 	const double t2 = now();
 	if (r == NABWA_OK) r = nabwa_batch_fetch(b, n_aln, aln_out, aln_cap, n_rows, max_entries);
+	else if (r == NABWA_EHITS) {      /* a few reads have more hit rows than NABWA_ALNCAP2: every other read's result is still handed out */
+		const std::string msg = g_err;
+		const int r2 = nabwa_batch_fetch(b, n_aln, aln_out, aln_cap, n_rows, max_entries);
+		if (r2 != NABWA_OK) r = r2; else g_err = msg;
+	}
 	const double t3 = now();
 	nabwa_batch_destroy(b);
 	if (timing) fprintf(stderr, "[nabwa] cal_sa_reg_gap %d reads: upload + layout %.3f s, kernels %.3f s, compaction + download %.3f s, release %.3f s\n",

@@ -110,3 +110,16 @@ __device__ __forceinline__ uint32_t nabwa_base_at(const uint4 &q1, const uint4 &
 	const uint64_t lo = (uint64_t)q.y << 32 | q.x, hi = (uint64_t)q.w << 32 | q.z;
 	return (uint32_t)(lo >> t & 1ull) | (uint32_t)(hi >> t & 1ull) << 1;
 }
+
+// bucket touches the REFERENCE algorithm performs for one (k-1, l) query: one per
+// bwt_occ / bwt_occ4 body execution, one for a same-128-row-block pair (bwt.c:92-216)
+__device__ __forceinline__ uint32_t ref_touches(const DevBwt &B, uint32_t kq, uint32_t lq, bool four)
+{
+	const uint32_t NEG = 0xffffffffu;
+	const uint32_t bk = (kq == NEG || (!four && kq == B.seq_len)) ? 0u : 1u;
+	const uint32_t bl = (lq == NEG || (!four && lq == B.seq_len)) ? 0u : 1u;
+	if (kq == lq) return bk;
+	const uint32_t _k = kq - (kq >= B.primary ? 1u : 0u), _l = lq - (lq >= B.primary ? 1u : 0u);
+	if (!(_l >> 7 != _k >> 7 || kq == NEG || lq == NEG)) return 1u;
+	return bk + bl;
+}

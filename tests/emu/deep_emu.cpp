@@ -48,7 +48,7 @@ void build(EmuBwt &X, const uint32_t *words)
 }
 
 // bwt_cal_width (bwtaln.c:52-76) into the record layout kernel W writes: widths, bound bytes min(bid,127) | (w[p-1]==w[p]) << 7
-void cal_width(const DevBwt &B, int len, const uint8_t *str, uint32_t *wd, uint8_t *bd)
+void cal_width(const DevBwt &B, int len, const uint8_t *str, uint32_t *wd, uint8_t *bd, unsigned long long *touches)
 {
 	uint32_t k = 0, l = B.seq_len, pw = 0; int bid = 0;
 	for (int i = 0; i < len; ++i) {
@@ -56,6 +56,7 @@ void cal_width(const DevBwt &B, int len, const uint8_t *str, uint32_t *wd, uint8
 		if (c < 4) {
 			Occ4 ck, cl;
 			nabwa_occ4_pair(B, k - 1u, l, ck, cl);
+			*touches += ref_touches(B, k - 1u, l, false);
 			k = B.L2[c] + ck.c[c] + 1u; l = B.L2[c] + cl.c[c];
 		}
 		if (k > l || c > 3) { k = 0; l = B.seq_len; ++bid; }
@@ -86,7 +87,7 @@ uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries; float fnr; int max_diff, max_gapo, max_gape, max_seed_diff, seed_len, n_threads, max_top2, trim_qual; };
 
 // knobs: [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap
-// stats (may be NULL): 6 words, see DeepParams.  Returns 0.
+// stats: 8 words -- 6 as in DeepParams, [6] the reference's bucket touches in the width passes, [7] in bwt_match_gap.  Returns 0.
 extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const emu_opt *opt, int n, const int64_t *off,
 							   const uint8_t *seq, const uint8_t *rseq, int per_read, const int *knobs,
 							   int32_t *n_aln, uint32_t *rows /* n x aln_cap x 4 */, int32_t *max_ent, uint8_t *status,
@@ -131,14 +132,15 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	S.woff_bid = 2 * S.WL * 4; S.woff_sbid = S.woff_bid + 2 * S.WLB; S.wstride = align_up(S.woff_sbid + 2 * S.SLB, 64);
 	std::vector<uint8_t> wdata((size_t)(n ? n : 1) * S.wstride, 0);
 	std::vector<uint32_t> tmpw(max_len + 2);
+	unsigned long long wt = 0, st = 0;
 	for (int i = 0; i < n; ++i) {
 		uint8_t *rec = &wdata[(size_t)i * S.wstride];
 		const int L = rd_len[i];
 		if (L <= 0) continue;
 		for (int x = 0; x < 2; ++x) {
 			const uint8_t *str = (x ? pr.data() : ps.data()) + poff[i];
-			cal_width(X[x].B, L, str, (uint32_t*)rec + x * S.WL, rec + S.woff_bid + x * S.WLB);
-			if (L > opt->seed_len) cal_width(X[x].B, opt->seed_len, str + (L - opt->seed_len), tmpw.data(), rec + S.woff_sbid + x * S.SLB);
+			cal_width(X[x].B, L, str, (uint32_t*)rec + x * S.WL, rec + S.woff_bid + x * S.WLB, &wt);
+			if (L > opt->seed_len) cal_width(X[x].B, opt->seed_len, str + (L - opt->seed_len), tmpw.data(), rec + S.woff_sbid + x * S.SLB, &wt);
 		}
 	}
 	S.wdata = wdata.data();
@@ -146,6 +148,7 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	S.n_aln = n_aln; S.max_ent = max_ent; S.status = status; S.aln = (uint4*)rows; S.aln_cap = aln_cap;
 	unsigned int counter = 0, bump = 0;
 	S.work_counter = &counter;
+	S.touch_counter = &st;
 	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)knobs[2];
 	P.max_lanes = knobs[0]; P.careful_all = knobs[1]; P.NS = NS; P.stats = stats;
 	const int per_wave = knobs[5];
@@ -160,5 +163,6 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 		deep_wave_body(P, lds.data(), (uint32_t)w);
 		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
 	}
+	stats[6] = wt; stats[7] = st;
 	return 0;
 }

@@ -20,7 +20,7 @@ def build(asan=False):
         return out
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
     subprocess.run(["g++", "-std=c++17", "-fPIC", "-shared", "-I" + EMU_DIR, "-Wall", "-Wno-unused-function",
-                    "-Wno-unused-variable"] + flags + [srcs[0], "-o", out], check=True)
+                    "-Wno-unused-variable", "-Wno-unknown-pragmas"] + flags + [srcs[0], "-o", out], check=True)
     return out
 
 

@@ -51,10 +51,14 @@ def check(got, maxe, st, want, wmaxe, what):
 def test_golden_sai(emu, words, orc, name):
     """rows = the reference's .sai; max_entries = the oracle's (the .sai does not hold it)"""
     opt, gold, reads, seq, rseq, off = golden(name)
-    _, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off)
+    ctr = T.Counters()
+    _, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, counters=ctr)
     for lanes in (64, 5) if name in ("default", "adna", "m64") else (64,):
-        got, maxe, st, _ = E.run(emu, words, opt, seq, rseq, off, max_lanes=lanes)
+        got, maxe, st, stats = E.run(emu, words, opt, seq, rseq, off, max_lanes=lanes)
         check(got, maxe, st, gold, wmaxe, "%s, %d lanes" % (name, lanes))
+        # the instrumented kernel counts the reference algorithm's bucket touches (the roofline's algorithmic bytes): only the
+        # chains that are committed count, so speculation must not change the total
+        assert stats[6] + stats[7] == ctr.n_bucket, (name, lanes, stats[6:8], ctr.n_bucket)
 
 
 def noisy_reads(seed, n, lens, err):

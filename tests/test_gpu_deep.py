@@ -1,0 +1,124 @@
+"""Kernel D on the GPU (fm_deep.hip: one deep search per wavefront): the code that tests/test_deep_emu.py checks on a CPU
+wave emulation, now as it ships -- through the C ABI, against the reference's .sai goldens and the oracle."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+from test_gpu_parity import random_reads, to_gap_opt, toy_genome
+
+pytestmark = pytest.mark.gpu
+nabwa = importlib.import_module("network-aware-bwa_amd")
+
+SAI_SETS = ["default", "adna", "n3", "e3", "loggap", "k1R5", "i2", "q20", "m64", "nonstop"]
+
+
+@pytest.fixture(scope="module")
+def gix():
+    ix = nabwa.Index.load(T.TOY, 0, True)
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    lib = T.load_oracle()
+    return lib, T.OracleIndex(lib)
+
+
+@pytest.mark.parametrize("name", SAI_SETS)
+def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name):
+    """a first-pass arena of 16 entries sends nearly every read on to kernel D: rows = the reference's .sai, max_entries = the oracle's"""
+    monkeypatch.setenv("NABWA_CAP1", "16")
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "nonstop" else "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
+    _, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, n_threads=8)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    n2 = b.sync()
+    got, maxe = b.fetch()
+    b.close()
+    assert n2 > len(reads) // 3
+    bad = [reads[i][0] for i in range(len(reads)) if got[i].tobytes() != gold[i].tobytes()]
+    assert not bad, "kernel D differs from the reference .sai for %d reads, e.g. %s" % (len(bad), bad[:5])
+    assert np.array_equal(maxe, wmaxe)
+
+
+def deep_opt():
+    o = T.default_opt()
+    o.fnr, o.max_gapo, o.seed_len = 0.01, 2, 16500
+    return o
+
+
+def test_many_waves_share_the_pool(gix, orc):
+    """20 000 noisy reads with the deep option set: thousands of waves draw pages from one pool at the same time"""
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, 20000, toy_genome(), lens=(50, 60, 76), err=0.04, indel=0.2)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = deep_opt()
+    want, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, n_threads=16)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    for _ in range(2):                                  # the second run re-uses the pool and the per-wave page lists
+        b.run()
+        n2 = b.sync()
+        got, maxe = b.fetch()
+        assert n2 > 1000
+        bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
+        assert not bad, "%d reads differ, e.g. %s" % (len(bad), bad[:5])
+        assert np.array_equal(maxe, wmaxe)
+    b.close()
+
+
+@pytest.mark.parametrize("max_entries", [40, 2500])
+def test_max_entries_cutoff_on_the_gpu(gix, orc, monkeypatch, max_entries):
+    """bwtgap.c:140 inside a round: the lanes before the cut-off are committed, the search goes on pop by pop"""
+    monkeypatch.setenv("NABWA_CAP1", "16")
+    rng = np.random.default_rng(6)
+    reads = random_reads(rng, 400, toy_genome(), lens=(76, 100), err=0.05, indel=0.2)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = deep_opt()
+    opt.max_entries = max_entries
+    want, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, n_threads=8)
+    assert (wmaxe > max_entries).any()
+    got, maxe = gix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off)
+    bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
+    assert not bad and np.array_equal(maxe, wmaxe)
+
+
+def test_more_hit_rows_than_alncap2_is_an_error_with_the_other_reads_intact(gix, orc, monkeypatch):
+    """NABWA_ALNCAP2 = 1 row per read in the wide result arrays: reads with more hits cannot be answered.  That is its own
+    error code (never an empty answer that looks like "unmapped"), the resolved reads are still handed out, and the
+    bwa_seq_t-level entry reports the error too."""
+    monkeypatch.setenv("NABWA_CAP1", "16")
+    monkeypatch.setenv("NABWA_ALNCAP2", "1")
+    opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_adna.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    b.run()
+    with pytest.raises(nabwa.NabwaError) as e:
+        b.sync()
+    assert e.value.code == nabwa.EHITS
+    got, _ = b.fetch()
+    b.close()
+    multi = [i for i in range(len(reads)) if len(gold[i]) > 1]
+    assert multi
+    for i in range(len(reads)):
+        assert got[i].tobytes() == gold[i].tobytes() or (len(gold[i]) > 1 and len(got[i]) == 0)
+    with pytest.raises(nabwa.NabwaError) as e:
+        gix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off)
+    assert e.value.code == nabwa.EHITS
+    n = 50
+    arr = (nabwa.BwaSeq * n)()
+    keep = []
+    for i in range(n):
+        s = np.ascontiguousarray(seq[off[i]:off[i + 1]]); r = np.ascontiguousarray(rseq[off[i]:off[i + 1]])
+        keep += [s, r]
+        arr[i].seq = s.ctypes.data; arr[i].rseq = r.ctypes.data; arr[i].bits0 = len(s)
+    g = to_gap_opt(opt)
+    rc = nabwa.lib().nabwa_bwa_cal_sa_reg_gap(gix._h, n, arr, C.byref(g))
+    assert rc == (nabwa.EHITS if any(len(gold[i]) > 1 for i in range(n)) else nabwa.OK)

@@ -188,14 +188,18 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [
-    {"NABWA_CAP1": "48"},                                                    # tier A (first-pass kernel, 65534-entry arena) takes them all
-    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0"},                               # straight to the slot-reusing kernel
-    {"NABWA_CAP1": "48", "NABWA_TIER_A": "0", "NABWA_TIER_B_CAP": "64", "NABWA_TIER_SKIP": "0"},     # tier B too small for some: they go on to the larger tiers
-    {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1", "NABWA_TIER_B_CAP": "40", "NABWA_TIER_SKIP": "0"},    # A fails on the hit lists, B on the arena, the next ones finish
+    {"NABWA_CAP1": "48"},                                                    # straight to kernel D (one search per wavefront)
+    {"NABWA_CAP1": "48", "NABWA_TIER_A": "1"},                               # the first-pass kernel once more with its largest arena, kernel D for the rest
+    {"NABWA_CAP1": "16", "NABWA_DEEP_LANES": "3"},                           # rounds of three chains
+    {"NABWA_CAP1": "16", "NABWA_DEEP_STAGE": "9"},                           # the smallest staging buffers: chains continue over rounds
+    {"NABWA_CAP1": "16", "NABWA_DEEP_CAREFUL": "1"},                         # one pop per round
+    {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "48", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
+    {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1"},                              # the first pass fails on the hit lists too
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_tiers_of_the_flagged_reads_are_bit_exact(gix, monkeypatch, env):
-    """reads that outgrow the first pass are re-run in tiers of growing arenas (nabwa_api.hip: nabwa_batch_sync); whichever
-    tier finishes a read, the rows are the reference's -- on the option set ancient-DNA pipelines use (deep searches)"""
+def test_flagged_reads_through_kernel_d_are_bit_exact(gix, monkeypatch, env):
+    """reads that outgrow the first pass go to kernel D (fm_deep_body.hpp; nabwa_api.hip: nabwa_batch_sync): speculative rounds
+    of up to 64 chains, ordered commit, paged arenas -- the rows are the reference's, on the option set ancient-DNA pipelines
+    use (deep searches), under every knob that changes how the rounds are cut"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_adna.sai"))
@@ -205,6 +209,7 @@ def test_tiers_of_the_flagged_reads_are_bit_exact(gix, monkeypatch, env):
     b.run()
     n2 = b.sync()
     got, _ = b.fetch()
+    assert b.last_deep_ms() > 0
     b.close()
     assert n2 > 100
     assert all(got[i].tobytes() == gold[i].tobytes() for i in range(len(reads)))
@@ -226,7 +231,7 @@ def test_rerun_is_idempotent(gix):
 
 def test_unsupported_options_fail_loudly(gix):
     opt = nabwa.gap_init_opt()
-    opt.max_gape = 40           # > 128 score levels
+    opt.max_gape = 300          # the reference's own score field (11 bits, bwtgap.c:58) could not hold this either
     reads = [("a", "ACGT" * 20, "I" * 80)]
     seq, rseq, off, _ = T.encode_reads(reads)
     with pytest.raises(nabwa.NabwaError) as e:
@@ -333,15 +338,21 @@ def test_text_mode_companions(gix):
                 assert (int(got[0]), int(got[1])) == (k, l), (which, key)
 
 
-def test_more_than_64_score_levels_go_through_the_second_pass(gix, olib, oix):
-    """an option block whose entries can score above 63 (gap extensions not counted as differences, `aln -e 15`) is beyond
-    the first-pass kernel's 64-bit score mask: the whole batch takes the second pass, and the answers are the oracle's"""
+@pytest.mark.parametrize("block", ["e15", "e40", "n16", "o20"])
+def test_option_blocks_beyond_the_first_pass_go_to_kernel_d(gix, olib, oix, block):
+    """option blocks the first-pass kernel's compact entries cannot hold -- more than 64 score levels (`aln -e 15`), max_gape
+    > 31, max_diff > 14, max_gapo > 15 -- are not refused: the whole batch goes to kernel D, and the answers are the oracle's"""
     rng = np.random.default_rng(99)
-    reads = random_reads(rng, 300, toy_genome(), lens=(50, 76, 100), err=0.02)
+    reads = random_reads(rng, 300 if block == "e15" else 60, toy_genome(), lens=(50, 76, 100), err=0.02)
     seq, rseq, off, _ = T.encode_reads(reads)
     opt = T.default_opt()
-    opt.max_gape = 15
-    opt.mode &= ~1                                  # BWA_MODE_GAPE off, as `aln -e` does
+    if block in ("e15", "e40"):
+        opt.max_gape = 15 if block == "e15" else 40
+        opt.mode &= ~1                              # BWA_MODE_GAPE off, as `aln -e` does
+    elif block == "n16":
+        opt.fnr, opt.max_diff, opt.max_entries = 0.0, 16, 3000      # (the cut-off keeps the oracle's run short)
+    else:
+        opt.fnr, opt.max_diff, opt.max_gapo, opt.max_entries = 0.0, 20, 20, 3000
     want, wmax = T.oracle_cal_sa_reg_gap(olib, oix.h, opt, seq, rseq, off, per_read=0, n_threads=8)
     b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
     b.run()
