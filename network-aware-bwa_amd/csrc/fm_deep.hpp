@@ -5,8 +5,8 @@
 #define DEEP_PAGE_SH 8u
 #define DEEP_PAGE    (1u << DEEP_PAGE_SH)    /* entries per page */
 #define DEEP_NIL     0xffffffffu
-#define DEEP_NEWP    16u                       /* pages one commit can need at most (64 lanes x stage_k <= 48 entries) */
-#define DEEP_STAGE_MAX 48u
+#define DEEP_NEWP    64u                       /* pages one commit can need at most: 64 lanes x stage_k <= 240 entries / 256 + 1 <= 61 */
+#define DEEP_STAGE_MAX 240u
 #define DST_M 0
 #define DST_I 1
 #define DST_D 2
@@ -29,6 +29,6 @@ struct DeepParams {
 	uint32_t stage_k;
 	uint32_t NS;                     // score levels (LDS: 2 x NS + DEEP_NEWP words per wave)
 	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
-	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures
+	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures, [6] rank steps and [7] text finishes of exact tails (lane counts)
 };
 

@@ -52,6 +52,13 @@ DEEP_FN void deep_unpack(const uint4 &r, DeepLane &e)
 	e.state = (int)(r.w >> 24 & 3u); e.a = (int)(r.w >> 26 & 1u);
 }
 
+// the 2 low bits of each of 8 bytes, byte j -> bits 2j
+DEEP_FN uint32_t deep_squeeze(uint64_t v)
+{
+	uint64_t y = v & 0x0303030303030303ull;
+	y = (y | y >> 6) & 0x000F000F000F000Full; y = (y | y >> 12) & 0x000000FF000000FFull; y = (y | y >> 24) & 0xFFFFull;
+	return (uint32_t)y;
+}
 DEEP_FN int deep_ctz64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 // element c of a four-element array by selects: a dynamically indexed register array would live in scratch memory
 DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u ? a[0] : (c == 1u ? a[1] : (c == 2u ? a[2] : a[3])); }
@@ -72,6 +79,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	uint32_t n_own = 0, n_free = 0;
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
+	// text mode (nabwa_dev.hpp): an exact tail that has narrowed to ONE row is finished by comparing the read with the text
+	const bool text_ok = (S.text_mode & 2) && S.bwt[0].sa_full && S.bwt[1].sa_full && S.bwt[0].isa && S.bwt[1].isa && S.bwt[0].text && S.bwt[1].text;
+	LANE(uint32_t, ntl); LANE(uint32_t, ntx);      // statistics: rank steps / text finishes of this lane's exact tails
+	LANES { L(ntl) = 0; L(ntx) = 0; }
 
 	LANE(uint32_t, tu);       // scratch for broadcasts
 	LANE(DeepLane, e);
@@ -200,7 +211,34 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							else if (m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape)) {
 								// nothing may differ any more: bwt_match_exact_alt (bwt.c:237-252) over str[i-1 .. 0]
 								uint32_t k = E.k, l = E.l; int i = E.i; bool ok = true;
+								const uint32_t *const sa_full = q1 ? S.bwt[1].sa_full : S.bwt[0].sa_full;
 								while (i > 0) {
+									if (text_ok && k == l) {
+										// One row left: its suffix starts at text position pos, and the i symbols still to match are
+										// the text right in front of it -- str[j] against text[pos - i + j], 16 per step, both packed
+										// low bits first; the row of the extended suffix comes from the inverse suffix array.
+										const uint32_t pos = sa_full[k];
+										if (pos != 0xffffffffu) {
+											ok = pos >= (uint32_t)i;
+											const uint32_t *const txt = q1 ? S.bwt[1].text : S.bwt[0].text;
+											for (int j0 = 0; ok && j0 < i; j0 += 16) {
+												const uint4 q = *(const uint4*)(str + j0);
+												const uint64_t lo = (uint64_t)q.y << 32 | q.x, hi = (uint64_t)q.w << 32 | q.z;
+												const int nb = i - j0 < 16 ? i - j0 : 16;
+												const uint64_t mlo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull, mhi = nb >= 16 ? ~0ull : (nb > 8 ? (1ull << (8 * (nb - 8))) - 1ull : 0ull);
+												if (((lo & mlo) | (hi & mhi)) & 0xFCFCFCFCFCFCFCFCull) { ok = false; break; }      // an N never matches
+												const uint32_t rd = deep_squeeze(lo) | deep_squeeze(hi) << 16;
+												const uint32_t p0 = pos - (uint32_t)i + (uint32_t)j0, w0 = p0 >> 4;
+												const uint32_t t0 = txt[w0], t1 = txt[w0 + 1u];
+												const uint32_t tx = (uint32_t)(((uint64_t)t1 << 32 | t0) >> ((p0 & 15u) << 1));
+												const uint32_t mask = nb >= 16 ? 0xffffffffu : (1u << (2 * nb)) - 1u;
+												if ((rd ^ tx) & mask) ok = false;
+											}
+											if (ok) { const uint32_t *const isa = q1 ? S.bwt[1].isa : S.bwt[0].isa; k = l = isa[pos - (uint32_t)i]; }
+											L(ntx) += 1;
+											break;
+										}
+									}
 									const uint32_t c = str[i - 1];
 									if (c > 3u) { ok = false; break; }
 									Occ4 ck, cl;
@@ -208,7 +246,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 									if (counting) L(tch) += ref_touches(B, k - 1u, l, false);
 									k = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u; l = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
 									if (k > l) { ok = false; break; }
-									--i;
+									--i; L(ntl) += 1;
 								}
 								if (ok) { hit = true; E.k = k; E.l = l; } else L(act) = false;
 							}
@@ -445,12 +483,16 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 		if (counting && status == NABWA_ST_OK) { ONE_LANE { DEEP_ATOMIC_ADD_U64(S.touch_counter, rd_touch); } }
 	}
 	if (P.stats) {
+		uint32_t t6 = 0, t7 = 0;
+		LANES { L(d) = L(ntl); } WEXSCAN_U32(L(off), L(d), t6);
+		LANES { L(d) = L(ntx); } WEXSCAN_U32(L(off), L(d), t7);
 		ONE_LANE {
 #ifdef NABWA_EMU
-			P.stats[0] += st_rounds; P.stats[1] += st_run; P.stats[2] += st_commit; P.stats[3] += st_steps; P.stats[4] += st_careful; P.stats[5] += st_pool;
+			P.stats[0] += st_rounds; P.stats[1] += st_run; P.stats[2] += st_commit; P.stats[3] += st_steps; P.stats[4] += st_careful; P.stats[5] += st_pool; P.stats[6] += t6; P.stats[7] += t7;
 #else
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
+			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
 #endif
 		}
 	}

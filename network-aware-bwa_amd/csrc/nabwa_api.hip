@@ -713,6 +713,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		QW.n_aln = b->d_naln; QW.max_ent = b->d_maxent; QW.status = b->d_status; QW.aln = b->d_aln; QW.aln_cap = b->P.aln_cap;
 		long bw2 = (2 * (long)cnt + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
 		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
+		(void)hipMemsetAsync(b->d_counter, 0, 16, b->stream);       /* kernel W draws its work items from counter [1] */
 		nabwa_launch_fm_width(&QW, (int)bw2, b->stream);
 	};
 	auto recollect = [&](int which, unsigned int *left) -> int {
@@ -767,7 +768,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		}
 		nabwa_launch_assign_slots((int)cur, b->d_ovf_ids, b->d_wide_idx, b->stream);
 		// working memory of kernel D
-		uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 32);
+		uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 128);
 		if (K < 9u) K = 9u;
 		if (K > DEEP_STAGE_MAX) K = DEEP_STAGE_MAX;
 		int occ = nabwa_deep_occupancy((int)NS);
@@ -848,8 +849,8 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			if (timing) {
 				unsigned long long st[16];
 				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 128, hipMemcpyDeviceToHost));
-				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu\n",
-						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4]);
+				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text\n",
+						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7]);
 			}
 			todo = n_pool;
 		}

@@ -20,7 +20,7 @@ uint32_t ref_base(const uint32_t *w, uint32_t j)          // base j of the refer
 	return p[(j & 127u) >> 4] >> ((~j & 15u) << 1) & 3u;
 }
 
-struct EmuBwt { std::vector<uint4> bk; DevBwt B; };
+struct EmuBwt { std::vector<uint4> bk; std::vector<uint32_t> sa, sa_full, isa, text; DevBwt B; };
 
 void build(EmuBwt &X, const uint32_t *words)
 {
@@ -45,6 +45,40 @@ void build(EmuBwt &X, const uint32_t *words)
 		for (int g = 0; g < 3; ++g) o[1 + g] = make_uint4((uint32_t)lo[g], (uint32_t)(lo[g] >> 32), (uint32_t)hi[g], (uint32_t)(hi[g] >> 32));
 	}
 	X.B.bk = X.bk.data(); X.B.n_buckets = nb;
+}
+
+// the text-mode companions of an index -- SA value of every row, its inverse, the text 2 bits per base -- from the BWT and the
+// SA samples of the .sa file (7 header words, then SA[j * intv] for j >= 1): one LF walk per sample, as sa_fill_kernel does
+void build_text(EmuBwt &X, const uint32_t *sa_words)
+{
+	DevBwt &B = X.B;
+	B.sa_intv = sa_words[5];
+	B.n_sa = (uint32_t)(((uint64_t)B.seq_len + B.sa_intv) / B.sa_intv);
+	X.sa.assign(B.n_sa, 0xffffffffu);
+	for (uint32_t j = 1; j < B.n_sa; ++j) X.sa[j] = sa_words[7 + j - 1];
+	const size_t rows = (size_t)B.seq_len + 1, words = ((size_t)B.seq_len + 15) / 16 + 4;
+	X.sa_full.assign(rows, 0); X.isa.assign(rows, 0); X.text.assign(words, 0);
+	std::vector<uint8_t> tb(rows, 0);
+	for (uint32_t j = 0; j < B.n_sa; ++j) {
+		uint32_t row = j * B.sa_intv, v = j ? X.sa[j] : B.seq_len;
+		X.sa_full[row] = j ? v : 0xffffffffu;
+		X.isa[v] = row;
+		for (;;) {
+			if (row == B.primary) break;
+			const uint32_t kp = row - (row > B.primary ? 1u : 0u);
+			const uint32_t b = kp / NABWA_INTV, r = kp - b * NABWA_INTV;
+			const uint4 *p = B.bk + (size_t)b * 4;
+			const uint32_t c = nabwa_base_at(p[1], p[2], p[3], r);
+			const Occ4 o = nabwa_count4(p[0], p[1], p[2], p[3], r);
+			v -= 1u;
+			tb[v] = (uint8_t)c;
+			row = B.L2[c] + o.c[c];
+			if (row % B.sa_intv == 0u) break;
+			X.sa_full[row] = v; X.isa[v] = row;
+		}
+	}
+	for (size_t j = 0; j < B.seq_len; ++j) X.text[j >> 4] |= (uint32_t)(tb[j] & 3u) << (2u * (j & 15u));
+	B.sa = X.sa.data(); B.sa_full = X.sa_full.data(); B.isa = X.isa.data(); B.text = X.text.data();
 }
 
 // bwt_cal_width (bwtaln.c:52-76) into the record layout kernel W writes: widths, bound bytes min(bid,127) | (w[p-1]==w[p]) << 7
@@ -86,15 +120,17 @@ uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries; float fnr; int max_diff, max_gapo, max_gape, max_seed_diff, seed_len, n_threads, max_top2, trim_qual; };
 
-// knobs: [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap
-// stats: 8 words -- 6 as in DeepParams, [6] the reference's bucket touches in the width passes, [7] in bwt_match_gap.  Returns 0.
-extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const emu_opt *opt, int n, const int64_t *off,
+// knobs: [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap,
+// [7] text mode (needs sa0 / sa1: the .sa / .rsa file contents; touches are then not the reference's)
+// stats: 10 words -- 8 as in DeepParams, [8] the reference's bucket touches in the width passes, [9] in bwt_match_gap.  Returns 0.
+extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const uint32_t *sa0, const uint32_t *sa1, const emu_opt *opt, int n, const int64_t *off,
 							   const uint8_t *seq, const uint8_t *rseq, int per_read, const int *knobs,
 							   int32_t *n_aln, uint32_t *rows /* n x aln_cap x 4 */, int32_t *max_ent, uint8_t *status,
 							   unsigned long long *stats)
 {
 	EmuBwt X[2];
 	build(X[0], bwt0); build(X[1], bwt1);
+	if (knobs[7] && sa0 && sa1) { build_text(X[0], sa0); build_text(X[1], sa1); }
 	int max_len = 0;
 	for (int i = 0; i < n; ++i) if (off[i + 1] - off[i] > max_len) max_len = (int)(off[i + 1] - off[i]);
 	DeepParams P;
@@ -126,7 +162,7 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	S.rd_nN = nN.data(); S.n = n;
 	S.s_mm = opt->s_mm; S.s_gapo = opt->s_gapo; S.s_gape = opt->s_gape; S.mode = opt->mode; S.indel_end_skip = opt->indel_end_skip;
 	S.max_del_occ = opt->max_del_occ; S.max_entries = opt->max_entries; S.max_gape = opt->max_gape; S.max_seed_diff = opt->max_seed_diff;
-	S.seed_len = opt->seed_len; S.max_top2 = opt->max_top2;
+	S.seed_len = opt->seed_len; S.max_top2 = opt->max_top2; S.text_mode = knobs[7] ? 2 : 0;
 	// width records (layout of nabwa_api.hip: layout())
 	S.WL = align_up((uint32_t)max_len + 1, 16); S.WLB = S.WL + 16; S.SLB = align_up((uint32_t)(opt->seed_len > 65535 ? 0 : opt->seed_len) + 1, 16) + 16;
 	S.woff_bid = 2 * S.WL * 4; S.woff_sbid = S.woff_bid + 2 * S.WLB; S.wstride = align_up(S.woff_sbid + 2 * S.SLB, 64);
@@ -163,6 +199,6 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 		deep_wave_body(P, lds.data(), (uint32_t)w);
 		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
 	}
-	stats[6] = wt; stats[7] = st;
+	stats[8] = wt; stats[9] = st;
 	return 0;
 }

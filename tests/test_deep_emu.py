@@ -58,7 +58,11 @@ def test_golden_sai(emu, words, orc, name):
         check(got, maxe, st, gold, wmaxe, "%s, %d lanes" % (name, lanes))
         # the instrumented kernel counts the reference algorithm's bucket touches (the roofline's algorithmic bytes): only the
         # chains that are committed count, so speculation must not change the total
-        assert stats[6] + stats[7] == ctr.n_bucket, (name, lanes, stats[6:8], ctr.n_bucket)
+        assert stats[8] + stats[9] == ctr.n_bucket, (name, lanes, stats[8:10], ctr.n_bucket)
+    # text mode: an exact tail that has narrowed to one row is finished by comparing the read with the text
+    got, maxe, st, stats = E.run(emu, words, opt, seq, rseq, off, text=1)
+    check(got, maxe, st, gold, wmaxe, "%s, text mode" % name)
+    assert stats[7] > 0
 
 
 def noisy_reads(seed, n, lens, err):
@@ -74,7 +78,7 @@ def deep_opt():
 
 
 @pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=9), dict(stage_k=12, max_lanes=64),
-                                   dict(per_wave=25), dict(per_read=1)])
+                                   dict(stage_k=240, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9)])
 def test_noisy_reads_vs_oracle(emu, words, orc, knobs):
     reads = noisy_reads(11, 150, (50, 63, 76, 100), 0.04)
     seq, rseq, off, _ = T.encode_reads(reads)
@@ -137,7 +141,7 @@ def test_under_address_sanitizer():
     code = ("import sys; sys.path.insert(0, %r); import numpy as np, nabwa_testlib as T, emu_deep as E, test_deep_emu as D\n"
             "lib = E.load(asan=True); words = E.toy_words(); o = T.load_oracle(); ox = T.OracleIndex(o)\n"
             "reads = D.noisy_reads(14, 40, (50, 76, 100), 0.04); seq, rseq, off, _ = T.encode_reads(reads)\n"
-            "for kn in (dict(), dict(stage_k=9), dict(n_pages=8, own_cap=8), dict(per_wave=7)):\n"
+            "for kn in (dict(), dict(stage_k=9), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=200)):\n"
             "    opt = D.deep_opt(); want, wm = T.oracle_cal_sa_reg_gap(o, ox.h, opt, seq, rseq, off)\n"
             "    got, maxe, st, _ = E.run(lib, words, opt, seq, rseq, off, **kn)\n"
             "    assert all(st[i] == 3 or got[i].tobytes() == want[i].tobytes() for i in range(len(reads)))\n"

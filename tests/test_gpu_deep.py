@@ -54,8 +54,9 @@ def deep_opt():
     return o
 
 
-def test_many_waves_share_the_pool(gix, orc):
+def test_many_waves_share_the_pool(gix, orc, monkeypatch):
     """20 000 noisy reads with the deep option set: thousands of waves draw pages from one pool at the same time"""
+    monkeypatch.setenv("NABWA_CAP1", "128")
     rng = np.random.default_rng(5)
     reads = random_reads(rng, 20000, toy_genome(), lens=(50, 60, 76), err=0.04, indel=0.2)
     seq, rseq, off, _ = T.encode_reads(reads)
@@ -66,7 +67,7 @@ def test_many_waves_share_the_pool(gix, orc):
         b.run()
         n2 = b.sync()
         got, maxe = b.fetch()
-        assert n2 > 1000
+        assert n2 > 4000
         bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
         assert not bad, "%d reads differ, e.g. %s" % (len(bad), bad[:5])
         assert np.array_equal(maxe, wmaxe)

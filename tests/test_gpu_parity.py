@@ -193,7 +193,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     {"NABWA_CAP1": "16", "NABWA_DEEP_LANES": "3"},                           # rounds of three chains
     {"NABWA_CAP1": "16", "NABWA_DEEP_STAGE": "9"},                           # the smallest staging buffers: chains continue over rounds
     {"NABWA_CAP1": "16", "NABWA_DEEP_CAREFUL": "1"},                         # one pop per round
-    {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "48", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
+    {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "400", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
     {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1"},                              # the first pass fails on the hit lists too
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_flagged_reads_through_kernel_d_are_bit_exact(gix, monkeypatch, env):
