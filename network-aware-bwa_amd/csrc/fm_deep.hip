@@ -8,7 +8,7 @@
 #define NABWA_DEEP_WAVES 4    // waves per SIMD the register budget is bounded for (128 VGPRs): 16 searches per CU
 #endif
 
-extern __shared__ uint32_t s_deep[];
+extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];
 
 __global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
 {
@@ -17,12 +17,12 @@ __global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const Dee
 
 extern "C" void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s)
 {
-	const size_t lds = (size_t)(2u * P->NS + DEEP_NEWP) * 4u;
+	const size_t lds = (size_t)DEEP_LDS_WORDS(P->NS, P->lds_rd) * 4u;
 	hipLaunchKernelGGL(fm_deep_kernel, dim3(n_waves), dim3(64), lds, s, *P);
 }
 
-extern "C" int nabwa_deep_occupancy(int ns)
+extern "C" int nabwa_deep_occupancy(int ns, int lds_rd)
 {
 	int nb = 0;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_deep_kernel, 64, (size_t)(2u * (unsigned)ns + DEEP_NEWP) * 4u) == hipSuccess ? nb : 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_deep_kernel, 64, (size_t)DEEP_LDS_WORDS((unsigned)ns, (unsigned)lds_rd) * 4u) == hipSuccess ? nb : 0;
 }

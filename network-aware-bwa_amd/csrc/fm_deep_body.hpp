@@ -34,9 +34,11 @@ struct DeepLane { uint32_t k, l; int i, a, mm, go, ge, state, ldp; };
 #ifdef NABWA_EMU
 #define DEEP_FN static
 #define DEEP_ATOMIC_ADD_U64(p, v) (*(p) += (v))
+#define DEEP_CLOCK() 0ull
 #else
 #define DEEP_FN __device__ __forceinline__
 #define DEEP_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
+#define DEEP_CLOCK() ((unsigned long long)wall_clock64())      /* 100 MHz */
 #endif
 
 DEEP_FN uint4 deep_pack(uint32_t k, uint32_t l, int i, int ldp, int mm, int go, int ge, int state, int a, uint32_t cls)
@@ -52,6 +54,20 @@ DEEP_FN void deep_unpack(const uint4 &r, DeepLane &e)
 	e.state = (int)(r.w >> 24 & 3u); e.a = (int)(r.w >> 26 & 1u);
 }
 
+// nabwa_occ4_pair (nabwa_dev.hpp) with the loads of BOTH buckets issued before either is used: one memory latency per query
+DEEP_FN void deep_occ4_pair(const DevBwt &B, uint32_t kq, uint32_t lq, Occ4 &ck, Occ4 &cl)
+{
+	const uint32_t kp = kq - (kq >= B.primary ? 1u : 0u), lp = lq - (lq >= B.primary ? 1u : 0u);
+	const bool kvalid = kq != 0xffffffffu, lvalid = lq != 0xffffffffu;
+	const uint32_t bl = lvalid ? lp / NABWA_INTV : 0u, rl = lp - bl * NABWA_INTV;
+	const uint32_t bkk = kvalid ? kp / NABWA_INTV : bl, rk = kp - bkk * NABWA_INTV;
+	const uint4 *const pl = B.bk + (size_t)bl * 4, *const pk = B.bk + (size_t)bkk * 4;
+	const uint4 a0 = pl[0], a1 = pl[1], a2 = pl[2], a3 = pl[3];
+	uint4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+	if (bkk != bl) { b0 = pk[0]; b1 = pk[1]; b2 = pk[2]; b3 = pk[3]; }
+	if (lvalid) cl = nabwa_count4(a0, a1, a2, a3, rl); else { cl.c[0] = cl.c[1] = cl.c[2] = cl.c[3] = 0; }
+	if (kvalid) ck = nabwa_count4(b0, b1, b2, b3, rk); else { ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0; }
+}
 // the 2 low bits of each of 8 bytes, byte j -> bits 2j
 DEEP_FN uint32_t deep_squeeze(uint64_t v)
 {
@@ -72,15 +88,25 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 {
 	const DeepParams P = P_;          /* (a by-value copy: the kernel argument stays in scalar registers / the kernarg segment) */
 	const SearchParams &S = P.S;
-	uint32_t *const s_cnt = lds, *const s_top = lds + P.NS, *const s_newp = lds + 2 * P.NS;
+	// this wave's LDS: per score level the entry count and the top page; the pages a commit takes; and (lds_rd > 0) the read's
+	// own data -- bound bytes, seed bound bytes, bases of both strands -- copied in when the read starts
+	const uint32_t ns2 = (P.NS + 1u) & ~1u;
+	uint32_t *const s_cnt = lds, *const s_top = lds + ns2, *const s_newp = lds + 2 * ns2;
+	uint32_t *const s_off = s_newp + DEEP_NEWP;                           // 64 words: a class's slot offsets per lane (commit)
+	uint8_t *const s_bb = (uint8_t*)(s_off + 64), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
+	const bool lds_mode = P.lds_rd != 0u;
+	const uint32_t PL = P.rd_pl;
 	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
-	uint4 *const stage = P.stage + (size_t)wave * 64 * P.stage_k;
+	uint4 *const stage = P.stage + (size_t)wave * 3 * 64 * P.stage_k;     // [class][lane][stage_k]
 	const uint32_t K = P.stage_k;
 	uint32_t n_own = 0, n_free = 0;
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
+	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;      // the longest single read of this wave: time, rounds; time in reads altogether
+	const unsigned long long clk_start = DEEP_CLOCK();
 	// text mode (nabwa_dev.hpp): an exact tail that has narrowed to ONE row is finished by comparing the read with the text
 	const bool text_ok = (S.text_mode & 2) && S.bwt[0].sa_full && S.bwt[1].sa_full && S.bwt[0].isa && S.bwt[1].isa && S.bwt[0].text && S.bwt[1].text;
+	LANE(int, ts); LANE(uint32_t, tpos);             // exact tails: where a parked tail stands, the text position of its one row
 	LANE(uint32_t, ntl); LANE(uint32_t, ntx);      // statistics: rank steps / text finishes of this lane's exact tails
 	LANES { L(ntl) = 0; L(ntx) = 0; }
 
@@ -88,8 +114,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(DeepLane, e);
 	LANE(bool, act);
 	LANE(int, flag);
-	LANE(uint32_t, np);       // children staged
-	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // of them, per (canonical) class
+	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // children staged, per (canonical) class
 	LANE(int, rel);           // live entries relative to the count before this lane's first pop
 	LANE(int, peak);          // the largest value `rel` had right before a pop
 	LANE(uint32_t, d); LANE(uint32_t, off);
@@ -97,20 +122,26 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(uint32_t, tch);      // bucket touches of the reference algorithm in this lane's chain (instrumented runs only)
 	const bool counting = S.touch_counter != 0;
 
+	// the read's own data: from LDS, or (reads too long for it) from where kernel W / the batch put them
+#define DEEP_BB(a_, p_) (lds_mode ? (uint32_t)s_bb[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)] : (uint32_t)(rec + S.woff_bid)[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)])
+#define DEEP_SB(a_, p_) (lds_mode ? (uint32_t)s_sb[(uint32_t)(a_) * S.SLB + (uint32_t)(p_)] : (uint32_t)(rec + S.woff_sbid)[(uint32_t)(a_) * S.SLB + (uint32_t)(p_)])
+#define DEEP_RD(a_, p_) (lds_mode ? (uint32_t)s_sq[(uint32_t)(a_) * PL + (uint32_t)(p_)] : (uint32_t)((a_) ? S.rseq : S.seq)[sq_off + (size_t)(p_)])
+#define DEEP_RD16(a_, p_) (lds_mode ? *(const uint4*)(s_sq + (uint32_t)(a_) * PL + (uint32_t)(p_)) : *(const uint4*)(((a_) ? S.rseq : S.seq) + sq_off + (size_t)(p_)))
+
 	// n_new pages into s_newp[]: from this wave's free ones first, then from the pool; ok_ = false when the pool is dry
 #define DEEP_ALLOC(n_new_, ok_) do { \
 		const uint32_t nn_ = (n_new_); \
 		const uint32_t take_ = nn_ < n_free ? nn_ : n_free; \
-		LANES { if ((uint32_t)ln < take_) s_newp[ln] = freep[n_free - 1u - (uint32_t)ln]; } \
+		LANES { for (uint32_t t_ = (uint32_t)ln; t_ < take_; t_ += 64u) s_newp[t_] = freep[n_free - 1u - t_]; } \
 		n_free -= take_; \
 		const uint32_t rest_ = nn_ - take_; \
 		ok_ = true; \
 		if (rest_) { \
 			LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(P.page_bump, rest_); } \
-			const uint32_t base_ = WBCAST(tu, 0); \
+			const uint32_t base_ = WUNI(WBCAST(tu, 0)); \
 			if ((uint64_t)base_ + rest_ > P.n_pages || n_own + rest_ > P.own_cap) ok_ = false; \
 			else { \
-				LANES { if ((uint32_t)ln < rest_) { s_newp[take_ + (uint32_t)ln] = base_ + (uint32_t)ln; own[n_own + (uint32_t)ln] = base_ + (uint32_t)ln; } } \
+				LANES { for (uint32_t t_ = (uint32_t)ln; t_ < rest_; t_ += 64u) { s_newp[take_ + t_] = base_ + t_; own[n_own + t_] = base_ + t_; } } \
 				n_own += rest_; \
 			} \
 		} \
@@ -118,17 +149,18 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 
 	for (;;) {
 		LANES { L(tu) = 0; if (ln == 0) L(tu) = ATOMIC_ADD_U32(S.work_counter, 1u); }
-		const uint32_t idx = WBCAST(tu, 0);
+		const uint32_t idx = WUNI(WBCAST(tu, 0));
 		if (idx >= (uint32_t)S.n) break;
-		const uint32_t rid = S.ids ? (uint32_t)S.ids[idx] : idx;
-		const uint32_t item = S.res_slot ? (uint32_t)S.res_slot[rid] : idx;
-		const int len = S.rd_len[rid];
-		const size_t sq_off = (size_t)S.poff[rid];
-		const int MD = (int)S.rd_maxdiff[rid], MG = (int)S.rd_maxgapo[rid];
+		const uint32_t rid = WUNI(S.ids ? (uint32_t)S.ids[idx] : idx);
+		const uint32_t item = WUNI(S.res_slot ? (uint32_t)S.res_slot[rid] : idx);
+		const int len = WUNI(S.rd_len[rid]);
+		const size_t sq_off = (size_t)WUNI((uint32_t)S.poff[rid]);      /* (< 4 Gi padded bases per batch: nabwa_batch_create) */
+		const int MD = WUNI((int)S.rd_maxdiff[rid]), MG = WUNI((int)S.rd_maxgapo[rid]);
 		uint8_t *const rec = S.wdata + (size_t)rid * S.wstride;
 		uint4 *const out = S.aln + (size_t)item * S.aln_cap;
 		int n_aln = 0, max_ent = 0, status = NABWA_ST_OK;
 		unsigned long long rd_touch = 0;
+		const unsigned long long clk0 = P.stats ? DEEP_CLOCK() : 0ull, rounds0 = st_rounds;
 
 		if (len > 0 && (int)S.rd_nN[rid] <= MD) {          // too many N: no search (bwtgap.c:118-123)
 			const bool seeded = len > S.seed_len;
@@ -137,6 +169,16 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			LANES { for (uint32_t t = (uint32_t)ln; t < P.NS; t += 64u) { s_cnt[t] = 0; s_top[t] = DEEP_NIL; } }
 			LANES { for (uint32_t t = (uint32_t)ln; t < n_own; t += 64u) freep[t] = own[t]; }      // every page this wave holds is free again
 			n_free = n_own;
+			if (lds_mode) {
+				const uint32_t nb16 = (2u * S.WLB + 2u * S.SLB) / 16u, pl16 = ((uint32_t)len + 15u) / 16u;
+				LANES {
+					for (uint32_t t = (uint32_t)ln; t < nb16; t += 64u) ((uint4*)s_bb)[t] = ((const uint4*)(rec + S.woff_bid))[t];
+					for (uint32_t t = (uint32_t)ln; t < 2u * pl16; t += 64u) {
+						const uint32_t x = t >= pl16 ? 1u : 0u, c = t - x * pl16;
+						((uint4*)(s_sq + x * PL))[c] = ((const uint4*)((x ? S.rseq : S.seq) + sq_off))[c];
+					}
+				}
+			}
 			WAVE_SYNC();
 			bool done = false, careful = P.careful_all != 0;
 			uint32_t cur = 0;                                 // no level below `cur` holds an entry
@@ -145,7 +187,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			DEEP_ALLOC(1u, got_page);
 			if (!got_page) { status = NABWA_ST_POOL; done = true; ++st_pool; }
 			else {
-				const uint32_t p0 = s_newp[0];
+				const uint32_t p0 = WUNI(s_newp[0]);
 				ONE_LANE {
 					P.pages[(size_t)p0 * DEEP_PAGE + 0] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 0, 0u);
 					P.pages[(size_t)p0 * DEEP_PAGE + 1] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 1, 0u);
@@ -168,16 +210,16 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				if (!found) break;     // only children that were counted but never stored are left: the reference pops one of them and stops (bwtgap.c:144)
 				const int s = (int)cur;
 				if (!nonstop && n_aln > 0 && s > best_score + S.s_mm) break;      // bwtgap.c:144
-				const uint32_t cs = s_cnt[s];
+				const uint32_t cs = WUNI(s_cnt[s]);
 				uint32_t W = careful ? 1u : (uint32_t)P.max_lanes;
 				if (W > cs) W = cs;
 				const int T0 = s + S.s_mm, T1 = s + S.s_gapo, T2 = s + S.s_gape;
 				const uint32_t can1 = T1 == T0 ? 0u : 1u, can2 = T2 == T0 ? 0u : (T2 == T1 ? can1 : 2u);
-				const uint32_t topq = (cs - 1u) >> DEEP_PAGE_SH, top_pg = s_top[s];
+				const uint32_t topq = (cs - 1u) >> DEEP_PAGE_SH, top_pg = WUNI(s_top[s]);
 				uint32_t prev_pg = DEEP_NIL;
-				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = P.page_prev[top_pg];
+				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = WUNI(P.page_prev[top_pg]);
 				LANES {
-					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(np) = 0; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
+					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
 					if (L(act)) {
 						const uint32_t p = cs - 1u - (uint32_t)ln;
 						const uint32_t pg = (p >> DEEP_PAGE_SH) == topq ? top_pg : prev_pg;
@@ -195,9 +237,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						if (L(rel) > L(peak)) L(peak) = L(rel);
 						L(rel) -= 1;
 						const int m = max_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
-						const uint8_t *const bb = rec + S.woff_bid + (uint32_t)E.a * S.WLB;
 						bool go_on = m >= 0;
-						if (go_on && E.i > 0 && m < (int)(bb[E.i - 1] & 127u)) go_on = false;      // bwtgap.c:156
+						if (go_on && E.i > 0 && m < (int)(DEEP_BB(E.a, E.i - 1) & 127u)) go_on = false;      // bwtgap.c:156
 						if (!go_on) L(act) = false;
 						else {
 							const bool q1 = E.a == 0;                                         // the index searched: bwts[1 - a] (bwtgap.c:149)
@@ -205,69 +246,31 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							B.bk = q1 ? S.bwt[1].bk : S.bwt[0].bk; B.primary = q1 ? S.bwt[1].primary : S.bwt[0].primary;
 							B.seq_len = q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len;
 							B.L2[0] = 0; B.L2[1] = q1 ? S.bwt[1].L2[1] : S.bwt[0].L2[1]; B.L2[2] = q1 ? S.bwt[1].L2[2] : S.bwt[0].L2[2]; B.L2[3] = q1 ? S.bwt[1].L2[3] : S.bwt[0].L2[3];
-							const uint8_t *const str = (E.a ? S.rseq : S.seq) + sq_off;
 							bool hit = false;
 							if (E.i == 0) hit = true;
 							else if (m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape)) {
-								// nothing may differ any more: bwt_match_exact_alt (bwt.c:237-252) over str[i-1 .. 0]
-								uint32_t k = E.k, l = E.l; int i = E.i; bool ok = true;
-								const uint32_t *const sa_full = q1 ? S.bwt[1].sa_full : S.bwt[0].sa_full;
-								while (i > 0) {
-									if (text_ok && k == l) {
-										// One row left: its suffix starts at text position pos, and the i symbols still to match are
-										// the text right in front of it -- str[j] against text[pos - i + j], 16 per step, both packed
-										// low bits first; the row of the extended suffix comes from the inverse suffix array.
-										const uint32_t pos = sa_full[k];
-										if (pos != 0xffffffffu) {
-											ok = pos >= (uint32_t)i;
-											const uint32_t *const txt = q1 ? S.bwt[1].text : S.bwt[0].text;
-											for (int j0 = 0; ok && j0 < i; j0 += 16) {
-												const uint4 q = *(const uint4*)(str + j0);
-												const uint64_t lo = (uint64_t)q.y << 32 | q.x, hi = (uint64_t)q.w << 32 | q.z;
-												const int nb = i - j0 < 16 ? i - j0 : 16;
-												const uint64_t mlo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull, mhi = nb >= 16 ? ~0ull : (nb > 8 ? (1ull << (8 * (nb - 8))) - 1ull : 0ull);
-												if (((lo & mlo) | (hi & mhi)) & 0xFCFCFCFCFCFCFCFCull) { ok = false; break; }      // an N never matches
-												const uint32_t rd = deep_squeeze(lo) | deep_squeeze(hi) << 16;
-												const uint32_t p0 = pos - (uint32_t)i + (uint32_t)j0, w0 = p0 >> 4;
-												const uint32_t t0 = txt[w0], t1 = txt[w0 + 1u];
-												const uint32_t tx = (uint32_t)(((uint64_t)t1 << 32 | t0) >> ((p0 & 15u) << 1));
-												const uint32_t mask = nb >= 16 ? 0xffffffffu : (1u << (2 * nb)) - 1u;
-												if ((rd ^ tx) & mask) ok = false;
-											}
-											if (ok) { const uint32_t *const isa = q1 ? S.bwt[1].isa : S.bwt[0].isa; k = l = isa[pos - (uint32_t)i]; }
-											L(ntx) += 1;
-											break;
-										}
-									}
-									const uint32_t c = str[i - 1];
-									if (c > 3u) { ok = false; break; }
-									Occ4 ck, cl;
-									nabwa_occ4_pair(B, k - 1u, l, ck, cl);
-									if (counting) L(tch) += ref_touches(B, k - 1u, l, false);
-									k = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u; l = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
-									if (k > l) { ok = false; break; }
-									--i; L(ntl) += 1;
-								}
-								if (ok) { hit = true; E.k = k; E.l = l; } else L(act) = false;
+								// nothing may differ any more: the chain ends in an exact tail (bwt_match_exact_alt, bwt.c:237-252).  It is
+								// parked here and walked after the loop together with the other chains' tails: a tail is a run of
+								// dependent loads, and inside this loop every other lane of the wave would wait for each of them
+								L(flag) = DF_TAIL; L(act) = false;
 							}
 							if (hit) { L(flag) = DF_HIT; L(act) = false; }
 							else if (L(act)) {
 								// ---- expansion (bwtgap.c:201-260)
 								const int i = E.i - 1;
 								Occ4 ck, cl;
-								nabwa_occ4_pair(B, E.k - 1u, E.l, ck, cl);
+								deep_occ4_pair(B, E.k - 1u, E.l, ck, cl);
 								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, true);
 								const uint32_t occ = E.l - E.k + 1u;
 								bool allow_diff = true, allow_M = true;
 								if (i > 0) {
-									const uint32_t B1 = bb[i - 1], B0 = bb[i];
+									const uint32_t B1 = DEEP_BB(E.a, i - 1), B0 = DEEP_BB(E.a, i);
 									const int b1 = (int)(B1 & 127u), b0 = (int)(B0 & 127u);
 									if (b1 > m - 1) allow_diff = false;
 									else if (b1 == m - 1 && b0 == m - 1 && (B0 & 128u)) allow_M = false;
 									const int ii = i - (len - S.seed_len);
 									if (seeded && ii > 0) {
-										const uint8_t *const sb = rec + S.woff_sbid + (uint32_t)E.a * S.SLB;
-										const uint32_t S1 = sb[ii - 1], S0 = sb[ii];
+										const uint32_t S1 = DEEP_SB(E.a, ii - 1), S0 = DEEP_SB(E.a, ii);
 										const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
 										const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
 										if (s1 > m_seed - 1) allow_diff = false;
@@ -283,9 +286,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 									L(rel) += 1; \
 									const int sc_ = (cls_) == DCL_MM ? T0 : ((cls_) == DCL_GO ? T1 : T2); \
 									if (nonstop || n_aln == 0 || sc_ <= best_score + S.s_mm) { \
-										stg[L(np)] = deep_pack((nk_), (nl_), (ni_), (ni_), (nmm_), (ngo_), (nge_), (nstate_), E.a, (cls_)); \
-										L(np) += 1; \
 										const uint32_t cn_ = (cls_) == DCL_MM ? 0u : ((cls_) == DCL_GO ? can1 : can2); \
+										const uint32_t at_ = cn_ == 0u ? L(cc0) : (cn_ == 1u ? L(cc1) : L(cc2)); \
+										stg[(size_t)cn_ * 64u * K + at_] = deep_pack((nk_), (nl_), (ni_), (ni_), (nmm_), (ngo_), (nge_), (nstate_), E.a, 0u); \
 										if (cn_ == 0u) L(cc0) += 1; else if (cn_ == 1u) L(cc1) += 1; else L(cc2) += 1; \
 									} } while (0)
 								int tmp = E.go + E.ge;
@@ -312,7 +315,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 										}
 									}
 								}
-								const uint32_t c = str[i];
+								const uint32_t c = DEEP_RD(E.a, i);
 								bool match = false; uint32_t mk_ = 0, ml_ = 0;
 								if (allow_diff && allow_M) {
 #pragma unroll
@@ -332,13 +335,73 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
 								if (match) { L(rel) += 1; E.k = mk_; E.l = ml_; E.i = i; E.ldp = 0; E.state = DST_M; }
 								else L(act) = false;
-								if (L(act) && (careful || L(np) + 9u > K)) { L(flag) = DF_CONT; L(act) = false; }
+								if (L(act) && (careful || L(cc0) + 9u > K || L(cc1) + 9u > K || L(cc2) + 9u > K)) { L(flag) = DF_CONT; L(act) = false; }
 							}
 						}
 					} }
 					// a chain that ended in a hit or ran out of staging room: the lanes above it will be dropped
-					const uint64_t sm = WBALLOT(L(flag) != DF_NONE);
-					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) L(act) = false; } }
+					const uint64_t sm = WBALLOT(L(flag) == DF_HIT || L(flag) == DF_CONT);
+					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) { L(act) = false; if (L(flag) == DF_TAIL) L(flag) = DF_NONE; } } }
+				}
+
+				// ---------------------------------------------------------------- the parked exact tails, all together: every turn
+				// of this loop is ONE memory round trip per lane -- a rank step over the next symbol (str[i-1]) while the interval
+				// has several rows; once ONE row is left (text mode, nabwa_dev.hpp) its suffix's text position, then the comparison
+				// of the i symbols still to match with the text right in front of it (str[j] against text[pos - i + j], 16 per
+				// word pair, both packed low bits first), then the row of the extended suffix from the inverse suffix array
+				LANES { L(ts) = L(flag) == DF_TAIL ? ((text_ok && L(e).k == L(e).l) ? 1 : 0) : -1; }
+				while (WBALLOT(L(ts) >= 0) != 0ull) {
+					LANES { if (L(ts) >= 0) {
+						DeepLane &E = L(e);
+						const bool q1 = E.a == 0;
+						bool fail = false, hit = false;
+						if (L(ts) == 0 || L(ts) == 4) {
+							DevBwt B;
+							B.bk = q1 ? S.bwt[1].bk : S.bwt[0].bk; B.primary = q1 ? S.bwt[1].primary : S.bwt[0].primary;
+							B.seq_len = q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len;
+							B.L2[0] = 0; B.L2[1] = q1 ? S.bwt[1].L2[1] : S.bwt[0].L2[1]; B.L2[2] = q1 ? S.bwt[1].L2[2] : S.bwt[0].L2[2]; B.L2[3] = q1 ? S.bwt[1].L2[3] : S.bwt[0].L2[3];
+							const uint32_t c = DEEP_RD(E.a, E.i - 1);
+							if (c > 3u) fail = true;
+							else {
+								Occ4 ck, cl;
+								deep_occ4_pair(B, E.k - 1u, E.l, ck, cl);
+								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, false);
+								E.k = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u; E.l = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
+								L(ntl) += 1;
+								if (E.k > E.l) fail = true;
+								else if (--E.i == 0) hit = true;
+								else if (L(ts) == 0 && text_ok && E.k == E.l) L(ts) = 1;
+							}
+						} else if (L(ts) == 1) {
+							const uint32_t pos = (q1 ? S.bwt[1].sa_full : S.bwt[0].sa_full)[E.k];
+							if (pos == 0xffffffffu) L(ts) = 4;                      // (the empty suffix: rank steps to the end)
+							else if (pos < (uint32_t)E.i) fail = true;                // the text begins before the read does
+							else { L(tpos) = pos; L(ts) = 2; }
+						} else if (L(ts) == 2) {
+							const uint32_t *const txt = q1 ? S.bwt[1].text : S.bwt[0].text;
+							bool ok = true;
+							for (int j0 = 0; ok && j0 < E.i; j0 += 16) {
+								const uint4 q = DEEP_RD16(E.a, j0);
+								const uint64_t lo = (uint64_t)q.y << 32 | q.x, hi = (uint64_t)q.w << 32 | q.z;
+								const int nb = E.i - j0 < 16 ? E.i - j0 : 16;
+								const uint64_t mlo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull, mhi = nb >= 16 ? ~0ull : (nb > 8 ? (1ull << (8 * (nb - 8))) - 1ull : 0ull);
+								if (((lo & mlo) | (hi & mhi)) & 0xFCFCFCFCFCFCFCFCull) { ok = false; break; }      // an N never matches
+								const uint32_t rd = deep_squeeze(lo) | deep_squeeze(hi) << 16;
+								const uint32_t p0 = L(tpos) - (uint32_t)E.i + (uint32_t)j0, w0 = p0 >> 4;
+								const uint32_t t0 = txt[w0], t1 = txt[w0 + 1u];
+								const uint32_t tx = (uint32_t)(((uint64_t)t1 << 32 | t0) >> ((p0 & 15u) << 1));
+								const uint32_t mask = nb >= 16 ? 0xffffffffu : (1u << (2 * nb)) - 1u;
+								if ((rd ^ tx) & mask) ok = false;
+							}
+							L(ntx) += 1;
+							if (ok) L(ts) = 3; else fail = true;
+						} else {
+							E.k = E.l = (q1 ? S.bwt[1].isa : S.bwt[0].isa)[L(tpos) - (uint32_t)E.i];
+							hit = true;
+						}
+						if (fail) { L(flag) = DF_NONE; L(ts) = -1; }
+						else if (hit) { L(flag) = DF_HIT; L(ts) = -1; }
+					} }
 				}
 
 				// ---------------------------------------------------------------- commit, in the reference's order
@@ -357,63 +420,76 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					if (mx > max_ent) max_ent = (int)mx;
 				}
 				LANES { L(tu) = (uint32_t)(L(nst) + L(rel)); }
-				n_entries = (int)WBCAST(tu, jl);
+				n_entries = (int)WUNI(WBCAST(tu, jl));
 				st_commit += (unsigned)(jl + 1);
 				if (counting) { uint32_t tt = 0; LANES { L(d) = ln <= jl ? L(tch) : 0u; } WEXSCAN_U32(L(off), L(d), tt); rd_touch += tt; }
 				// the popped entries leave level s
 				const uint32_t newc = cs - (uint32_t)(jl + 1);
 				ONE_LANE { s_cnt[s] = newc; }
 				if (newc == 0u || ((newc - 1u) >> DEEP_PAGE_SH) != topq) {      // its top page is empty now
-					if (newc && prev_pg == DEEP_NIL) prev_pg = P.page_prev[top_pg];
+					if (newc && prev_pg == DEEP_NIL) prev_pg = WUNI(P.page_prev[top_pg]);
 					ONE_LANE { freep[n_free] = top_pg; s_top[s] = newc ? prev_pg : DEEP_NIL; }
 					++n_free;
 				}
 				WAVE_SYNC();
 				bool pool_fail = false;
-				// the staged children go to their levels: lane by lane, within a lane in chain order
-				for (uint32_t c = 0; c < 3u && !pool_fail; ++c) {
-					if ((c == 1u && can1 != 1u) || (c == 2u && can2 != 2u)) continue;
-					LANES { L(d) = ln <= jl ? (c == 0u ? L(cc0) : (c == 1u ? L(cc1) : L(cc2))) : 0u; }
-					WEXSCAN_U32(L(off), L(d), tot);
-					if (tot == 0u) continue;
-					const int Tc = c == 0u ? T0 : (c == 1u ? T1 : T2);
-					if ((uint32_t)Tc >= P.NS) { pool_fail = true; break; }   // (cannot happen: the host sizes NS by the largest score an entry can have)
-					const uint32_t cT = s_cnt[Tc], old_top = s_top[Tc];
-					const uint32_t q_new = cT ? ((cT - 1u) >> DEEP_PAGE_SH) + 1u : 0u, q_last = (cT + tot - 1u) >> DEEP_PAGE_SH;
-					const uint32_t n_new = q_last + 1u > q_new ? q_last + 1u - q_new : 0u;
-					if (n_new) { bool okp = false; DEEP_ALLOC(n_new, okp); if (!okp) { pool_fail = true; break; } }
-					ONE_LANE {
-						for (uint32_t t = 0; t < n_new; ++t) P.page_prev[s_newp[t]] = t ? s_newp[t - 1u] : old_top;
-						s_cnt[Tc] = cT + tot;
-						if (n_new) s_top[Tc] = s_newp[n_new - 1u];
-					}
-					LANES { if (ln <= jl) {
-						uint32_t w = cT + L(off);
-						const uint4 *const stg = stage + (size_t)ln * K;
-						for (uint32_t r = 0; r < L(np); ++r) {
-							uint4 v = stg[r];
-							const uint32_t cls = v.w >> 27 & 3u;
-							const uint32_t cn = cls == DCL_MM ? 0u : (cls == DCL_GO ? can1 : can2);
-							if (cn != c) continue;
-							v.w &= ~(3u << 27);
-							const uint32_t q = w >> DEEP_PAGE_SH;
-							const uint32_t pg = q < q_new ? old_top : s_newp[q - q_new];
-							P.pages[(size_t)pg * DEEP_PAGE + (w & (DEEP_PAGE - 1u))] = v;
-							++w;
-						}
-					} }
-					WAVE_SYNC();
+				// the staged children go to their levels: lane by lane, within a lane in chain order.  Per (canonical) class: the
+				// lanes' slots by prefix sum, the pages those slots need; then ONE pass over each lane's staging buffer
+				uint32_t tot0 = 0, tot1 = 0, tot2 = 0;
+				LANE(uint32_t, o0); LANE(uint32_t, o1); LANE(uint32_t, o2);
+				LANES { L(d) = ln <= jl ? L(cc0) : 0u; } WEXSCAN_U32(L(o0), L(d), tot0);
+				LANES { L(d) = ln <= jl ? L(cc1) : 0u; } WEXSCAN_U32(L(o1), L(d), tot1);
+				LANES { L(d) = ln <= jl ? L(cc2) : 0u; } WEXSCAN_U32(L(o2), L(d), tot2);
+				if ((tot0 && (uint32_t)T0 >= P.NS) || (tot1 && (uint32_t)T1 >= P.NS) || (tot2 && (uint32_t)T2 >= P.NS)) pool_fail = true;   // (cannot happen: the host sizes NS by the largest score an entry can have)
+				uint32_t cT0 = 0, cT1 = 0, cT2 = 0, ot0 = DEEP_NIL, ot1 = DEEP_NIL, ot2 = DEEP_NIL, qn0 = 0, qn1 = 0, qn2 = 0, nn0 = 0, nn1 = 0, nn2 = 0;
+				if (!pool_fail) {
+#define DEEP_LEVEL(tot_, T_, cT_, ot_, qn_, nn_) if (tot_) { cT_ = WUNI(s_cnt[T_]); ot_ = WUNI(s_top[T_]); qn_ = cT_ ? ((cT_ - 1u) >> DEEP_PAGE_SH) + 1u : 0u; \
+						const uint32_t ql_ = (cT_ + tot_ - 1u) >> DEEP_PAGE_SH; nn_ = ql_ + 1u > qn_ ? ql_ + 1u - qn_ : 0u; }
+					DEEP_LEVEL(tot0, T0, cT0, ot0, qn0, nn0)
+					DEEP_LEVEL(tot1, T1, cT1, ot1, qn1, nn1)
+					DEEP_LEVEL(tot2, T2, cT2, ot2, qn2, nn2)
+#undef DEEP_LEVEL
+					if (nn0 + nn1 + nn2) { bool okp = false; DEEP_ALLOC(nn0 + nn1 + nn2, okp); if (!okp) pool_fail = true; }
 				}
-				const int fl = WBCAST(flag, jl);
+				if (!pool_fail) {
+					const uint32_t nb1 = nn0, nb2 = nn0 + nn1;        // where each class's new pages start in s_newp[]
+					ONE_LANE {
+#define DEEP_LINK(tot_, T_, cT_, ot_, nn_, nb_) if (tot_) { for (uint32_t t = 0; t < nn_; ++t) P.page_prev[s_newp[nb_ + t]] = t ? s_newp[nb_ + t - 1u] : ot_; \
+						s_cnt[T_] = cT_ + tot_; if (nn_) s_top[T_] = s_newp[nb_ + nn_ - 1u]; }
+						DEEP_LINK(tot0, T0, cT0, ot0, nn0, 0u)
+						DEEP_LINK(tot1, T1, cT1, ot1, nn1, nb1)
+						DEEP_LINK(tot2, T2, cT2, ot2, nn2, nb2)
+#undef DEEP_LINK
+					}
+					// the copy is spread evenly over the wave, whatever the lanes' chains staged: slot g of a class belongs to the
+					// lane j with off_j <= g < off_j + count_j (a search in the prefix sums, which sit in LDS for it)
+#define DEEP_COPY(c_, tot_, oc_, cT_, ot_, qn_, nb_) if (tot_) { \
+						LANES { s_off[ln] = ln <= jl ? L(oc_) : (tot_); } \
+						WAVE_SYNC(); \
+						LANES { for (uint32_t g = (uint32_t)ln; g < (tot_); g += 64u) { \
+							uint32_t j = 0; \
+							for (uint32_t stp = 32u; stp; stp >>= 1) if (s_off[j + stp] <= g) j += stp; \
+							const uint4 v = stage[((size_t)(c_) * 64u + j) * K + (g - s_off[j])]; \
+							const uint32_t w = (cT_) + g, q = w >> DEEP_PAGE_SH; \
+							const uint32_t pg = q < (qn_) ? (ot_) : s_newp[(nb_) + q - (qn_)]; \
+							P.pages[(size_t)pg * DEEP_PAGE + (w & (DEEP_PAGE - 1u))] = v; \
+						} } \
+						WAVE_SYNC(); }
+					DEEP_COPY(0u, tot0, o0, cT0, ot0, qn0, 0u)
+					DEEP_COPY(1u, tot1, o1, cT1, ot1, qn1, nb1)
+					DEEP_COPY(2u, tot2, o2, cT2, ot2, qn2, nb2)
+#undef DEEP_COPY
+				}
+				const int fl = WUNI(WBCAST(flag, jl));
 				if (!pool_fail && !over && fl == DF_CONT) {
 					// the chain of lane jl goes on in the next round: its current entry is the newest of level s again
-					const uint32_t cT = s_cnt[s], old_top = s_top[s];
+					const uint32_t cT = WUNI(s_cnt[s]), old_top = WUNI(s_top[s]);
 					const bool need = (cT & (DEEP_PAGE - 1u)) == 0u;
 					bool okp = true;
 					if (need) DEEP_ALLOC(1u, okp);
 					if (!okp) pool_fail = true;
 					else {
-						const uint32_t pg = need ? s_newp[0] : old_top;
+						const uint32_t pg = need ? WUNI(s_newp[0]) : old_top;
 						ONE_LANE { if (need) { P.page_prev[pg] = old_top; s_top[s] = pg; } s_cnt[s] = cT + 1u; }
 						LANES { if (ln == jl) P.pages[(size_t)pg * DEEP_PAGE + (cT & (DEEP_PAGE - 1u))] =
 							deep_pack(L(e).k, L(e).l, L(e).i, L(e).ldp, L(e).mm, L(e).go, L(e).ge, L(e).state, L(e).a, 0u); }
@@ -423,10 +499,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				if (pool_fail) { status = NABWA_ST_POOL; ++st_pool; break; }
 				if (!over && fl == DF_HIT) {
 					// ---- hit bookkeeping (bwtgap.c:166-199), the wave together
-					LANES { L(tu) = L(e).k; } const uint32_t hk = WBCAST(tu, jl);
-					LANES { L(tu) = L(e).l; } const uint32_t hl = WBCAST(tu, jl);
-					LANES { L(tu) = (uint32_t)L(e).mm | (uint32_t)L(e).go << 8 | (uint32_t)L(e).ge << 16 | (uint32_t)L(e).a << 24; } const uint32_t hinfo = WBCAST(tu, jl);
-					LANES { L(tu) = (uint32_t)L(e).ldp; } const int h_ldp = (int)WBCAST(tu, jl);
+					LANES { L(tu) = L(e).k; } const uint32_t hk = WUNI(WBCAST(tu, jl));
+					LANES { L(tu) = L(e).l; } const uint32_t hl = WUNI(WBCAST(tu, jl));
+					LANES { L(tu) = (uint32_t)L(e).mm | (uint32_t)L(e).go << 8 | (uint32_t)L(e).ge << 16 | (uint32_t)L(e).a << 24; } const uint32_t hinfo = WUNI(WBCAST(tu, jl));
+					LANES { L(tu) = (uint32_t)L(e).ldp; } const int h_ldp = (int)WUNI(WBCAST(tu, jl));
 					const int h_mm = (int)(hinfo & 0xffu), h_go = (int)(hinfo >> 8 & 0xffu), h_ge = (int)(hinfo >> 16 & 0xffu), h_a = (int)(hinfo >> 24 & 1u);
 					const int score = s;
 					bool do_add = true;
@@ -447,7 +523,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							// gap_shadow (bwtgap.c:81-91) on this strand's widths, positions < last_diff_pos, 64 at a time; then the
 							// "w[t-1] == w[t]" bits of the bound bytes of positions 1 .. last_diff_pos are refreshed
 							const uint32_t x = hl - hk + 1u, mx = h_a ? S.bwt[0].seq_len : S.bwt[1].seq_len;
-							uint32_t *const wp = (uint32_t*)rec + (uint32_t)h_a * S.WL; uint8_t *const bp = rec + S.woff_bid + (uint32_t)h_a * S.WLB;
+							uint32_t *const wp = (uint32_t*)rec + (uint32_t)h_a * S.WL;
+							uint8_t *const bp = lds_mode ? s_bb + (uint32_t)h_a * S.WLB : rec + S.woff_bid + (uint32_t)h_a * S.WLB;
 							uint32_t jj = 0;
 							for (int t0 = 0; t0 < h_ldp; t0 += 64) {
 								const uint64_t eqm = WBALLOT(t0 + ln < h_ldp && wp[t0 + ln] == x);
@@ -480,6 +557,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			}
 		}
 		ONE_LANE { S.n_aln[item] = n_aln; S.max_ent[item] = max_ent; S.status[item] = (uint8_t)status; }
+		if (P.stats) { const unsigned long long dt = DEEP_CLOCK() - clk0; st_sumclk += dt; if (dt > st_maxclk) st_maxclk = dt; if (st_rounds - rounds0 > st_maxrounds) st_maxrounds = st_rounds - rounds0; }
 		if (counting && status == NABWA_ST_OK) { ONE_LANE { DEEP_ATOMIC_ADD_U64(S.touch_counter, rd_touch); } }
 	}
 	if (P.stats) {
@@ -493,6 +571,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
+			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}
 	}

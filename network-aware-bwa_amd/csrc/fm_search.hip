@@ -535,6 +535,9 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			else {
 				if (max_ent < n_entries) max_ent = n_entries;
 				if (n_entries > P.max_entries) finish = true;                 // bwtgap.c:140
+				// a search that is still running after trip_budget trips is handed on to kernel D, which gives it a whole wave: the
+				// launch cannot end before its longest lane does, and one lane walks a long search pop by pop
+				else if (!COUNT && P.trip_budget && rd_trips > P.trip_budget) { status = NABWA_ST_OVERFLOW; finish = true; }
 			}
 			if (!finish) {
 				const int best_mem = mask_first();
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 			if (pf_now) r_ent = ent[pf_cand];
 		}
+		if (!COUNT && P.trip_budget && st != LS_IDLE && st != LS_EXIT) ++rd_trips;
 		if (COUNT && st != LS_IDLE && st != LS_EXIT) {
 			++rd_trips;
 			if (kind == 1) { if (kx) ++rk_kf; else if (tx) ++rk_tx; else if (two) ++rk_row2; else ++rk_row1; if (e_go | e_ge) ++rk_gap; }
@@ -1138,6 +1142,29 @@ __global__ __launch_bounds__(256) void collect_kernel(int n, const uint8_t *__re
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i < n && status[i] == which) ids[atomicAdd(count, 1u)] = i;
+}
+
+// The same, in the order kernel D should start them: its launch ends with its longest search, so the searches that look
+// longest go first.  Key = max_diff - (the lower bound of the read's differences from kernel W: the smaller restart count of
+// its two strands): the more differences the bounds leave open, the larger the tree.  One pass per key value, largest first.
+__global__ __launch_bounds__(256) void collect_keyed_kernel(int n, const uint8_t *__restrict__ status, int32_t *__restrict__ ids,
+															unsigned int *__restrict__ count, int which, const uint8_t *__restrict__ cls,
+															const uint8_t *__restrict__ md, int lo, int hi)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n || status[i] != which) return;
+	const int c0 = cls[2 * (size_t)i], c1 = cls[2 * (size_t)i + 1];
+	const int k = (int)md[i] - (c0 < c1 ? c0 : c1);
+	if (k >= lo && k <= hi) ids[atomicAdd(count, 1u)] = i;
+}
+
+extern "C" void nabwa_launch_collect_keyed(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which,
+										   const uint8_t *cls, const uint8_t *md, int max_key, hipStream_t s)
+{
+	if (n <= 0) return;
+	for (int key = max_key; key >= 0; --key)
+		hipLaunchKernelGGL(collect_keyed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, status, ids, count, which, cls, md,
+						   key ? key : -0x7fffffff, key == max_key ? 0x7fffffff : key);
 }
 
 // ids of the reads whose status is `which` (NABWA_ST_OVERFLOW after kernel S, NABWA_ST_POOL / NABWA_ST_HITCAP after kernel D)

@@ -32,7 +32,9 @@ void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int al
 						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
 void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which, hipStream_t s);
 void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s);
-int nabwa_deep_occupancy(int ns);
+void nabwa_launch_collect_keyed(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which,
+								const uint8_t *cls, const uint8_t *md, int max_key, hipStream_t s);
+int nabwa_deep_occupancy(int ns, int lds_rd);
 void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s);
 void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
 							   const uint8_t *status2, int32_t *n_aln, int32_t *max_ent, uint8_t *status,
@@ -425,6 +427,7 @@ struct nabwa_batch {
 	uint4 *d_pages; uint32_t *d_page_prev, *d_deep_own; uint4 *d_deep_stage; unsigned long long *d_deep_ctr;
 	size_t deep_pages, deep_own_words, deep_stage_ent;
 	hipEvent_t evd0, evd1; float last_ms_deep; int deep_ran, deep_only;
+	int deep_cfg; uint32_t deep_K, deep_lds_rd, deep_rd_pl; size_t deep_n_pages; uint64_t deep_cap_pages; long deep_waves_max;
 };
 
 static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
@@ -618,6 +621,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	b->NS_wide = NS;
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
+	P.trip_budget = (uint32_t)env_int("NABWA_TRIP_BUDGET", 2000);   /* 0: never; measured 10 M x 100 bp: 0 -> 123.6 ms per pass, 2000 -> 108.9 (1111 reads handed on, kernel D 2 ms), 1000 -> 116.2, 500 -> 189.6 */
 	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
 	{
 		P.w_sync = (n > 0 && min_len == max_len) ? env_int("NABWA_W_SYNC", 1) : 0;
@@ -681,7 +685,9 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 		HIPCHK(hipMemsetAsync(b->d_naln, 0, (size_t)b->n * 4, b->stream));
 	}
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
-	nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->stream);
+	/* the reads the first pass hands on, in the order kernel D should start them (largest-looking searches first) */
+	if (b->class_sort && env_int("NABWA_DEEP_ORDER", 1)) nabwa_launch_collect_keyed(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->d_cls, b->d_md, 6, b->stream);
+	else nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->stream);
 	HIPCHK(hipGetLastError());
 	return NABWA_OK;
 }
@@ -752,8 +758,6 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		/* a chain's matching child must be the only child of its own score (fm_deep_body.hpp) */
 		if (b->opt.s_mm < 1 || b->opt.s_gapo < 1 || b->opt.s_gape < 1) return fail(NABWA_EINVAL, "deep searches need s_mm, s_gapo, s_gape >= 1");
 		const double tt0 = now();
-		hipDeviceProp_t prop;
-		HIPCHK(hipGetDeviceProperties(&prop, b->ix->device));
 		const uint32_t NS = b->NS_wide;
 		// rows of the wide result arrays for the reads that are left
 		if (b->n2 < (int)cur || b->aln_cap2 != env_int("NABWA_ALNCAP2", 1024)) {
@@ -767,38 +771,51 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			b->n2 = (int)cur;
 		}
 		nabwa_launch_assign_slots((int)cur, b->d_ovf_ids, b->d_wide_idx, b->stream);
-		// working memory of kernel D
-		uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 128);
-		if (K < 9u) K = 9u;
-		if (K > DEEP_STAGE_MAX) K = DEEP_STAGE_MAX;
-		int occ = nabwa_deep_occupancy((int)NS);
-		if (occ < 1) occ = 1;
-		if (env_int("NABWA_DEEP_WAVES_PER_CU", 0) > 0) occ = env_int("NABWA_DEEP_WAVES_PER_CU", 0);
-		long n_waves = (long)prop.multiProcessorCount * occ;
-		if (n_waves > (long)cur) n_waves = (long)cur;
-		size_t budget = (size_t)env_int("NABWA_DEEP_GB", 32) << 30;
-		{
-			size_t fr = 0, tot = 0;
-			HIPCHK(hipMemGetInfo(&fr, &tot));
-			size_t avail = fr + b->deep_pages * ((size_t)DEEP_PAGE * 16 + 4);
-			{ std::lock_guard<std::mutex> lk(b->ix->pool->mu); avail += b->ix->pool->idle_bytes; }
-			avail = avail > ((size_t)6 << 30) ? avail - ((size_t)6 << 30) : ((size_t)64 << 20);
-			if (budget > avail) budget = avail;
+		// kernel D's launch shape and pool size: worked out once per batch (device queries cost as much as a small launch)
+		if (!b->deep_cfg) {
+			hipDeviceProp_t prop;
+			HIPCHK(hipGetDeviceProperties(&prop, b->ix->device));
+			uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 96);
+			if (K < 9u) K = 9u;
+			if (K > DEEP_STAGE_MAX) K = DEEP_STAGE_MAX;
+			// the read's own data (bound bytes, seed bound bytes, both strands' bases) sits in the wave's LDS when it is small enough
+			const uint32_t rd_pl = align_up((uint32_t)(b->max_len > 0 ? b->max_len : 1), 16);
+			uint32_t lds_rd = 2u * b->P.WLB + 2u * b->P.SLB + 2u * rd_pl;
+			if (lds_rd > (uint32_t)env_int("NABWA_DEEP_LDS_MAX", 6144)) lds_rd = 0;
+			int occ = nabwa_deep_occupancy((int)NS, (int)lds_rd);
+			if (occ < 1) occ = 1;
+			if (env_int("NABWA_DEEP_WAVES_PER_CU", 0) > 0) occ = env_int("NABWA_DEEP_WAVES_PER_CU", 0);
+			size_t budget = (size_t)env_int("NABWA_DEEP_GB", 32) << 30;
+			{
+				size_t fr = 0, tot = 0;
+				HIPCHK(hipMemGetInfo(&fr, &tot));
+				size_t avail = fr;
+				{ std::lock_guard<std::mutex> lk(b->ix->pool->mu); avail += b->ix->pool->idle_bytes; }
+				avail = avail > ((size_t)6 << 30) ? avail - ((size_t)6 << 30) : ((size_t)64 << 20);
+				if (budget > avail) budget = avail;
+			}
+			if (getenv("NABWA_DEEP_PAGES")) budget = (size_t)env_int("NABWA_DEEP_PAGES", 64) * ((size_t)DEEP_PAGE * 16 + 4);     /* (tests: a pool that runs dry) */
+			size_t n_pages = budget / ((size_t)DEEP_PAGE * 16 + 4);
+			if (n_pages > 0xfffffff0ull) n_pages = 0xfffffff0ull;
+			if (n_pages < 2) n_pages = 2;
+			// pages one search can hold at most: its live entries are bounded by the cut-off (bwtgap.c:140) plus one round's
+			// children, and every score level may have a partly filled page
+			uint64_t cap_pages = ((uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 3ull * 64ull * K + 2) / DEEP_PAGE + NS + 4;
+			if (cap_pages > n_pages) cap_pages = n_pages;
+			b->deep_K = K; b->deep_lds_rd = lds_rd; b->deep_rd_pl = rd_pl; b->deep_n_pages = n_pages; b->deep_cap_pages = cap_pages;
+			b->deep_waves_max = (long)prop.multiProcessorCount * occ;
+			b->deep_cfg = 1;
 		}
-		if (getenv("NABWA_DEEP_PAGES")) budget = (size_t)env_int("NABWA_DEEP_PAGES", 64) * ((size_t)DEEP_PAGE * 16 + 4);     /* (tests: a pool that runs dry) */
-		size_t n_pages = budget / ((size_t)DEEP_PAGE * 16 + 4);
-		if (n_pages > 0xfffffff0ull) n_pages = 0xfffffff0ull;
-		if (n_pages < 2) n_pages = 2;
-		// pages one search can hold at most: its live entries are bounded by the cut-off (bwtgap.c:140) plus one round's
-		// children, and every score level may have a partly filled page
-		uint64_t cap_pages = ((uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 64ull * K + 2) / DEEP_PAGE + NS + 4;
-		if (cap_pages > n_pages) cap_pages = n_pages;
+		const uint32_t K = b->deep_K, lds_rd = b->deep_lds_rd, rd_pl = b->deep_rd_pl;
+		const size_t n_pages = b->deep_n_pages; const uint64_t cap_pages = b->deep_cap_pages;
+		long n_waves = b->deep_waves_max;
+		if (n_waves > (long)cur) n_waves = (long)cur;
 		if (b->deep_pages < n_pages) {
 			if (b->d_pages) { HIPCHK(pool_free(b->ix, b->d_pages)); HIPCHK(pool_free(b->ix, b->d_page_prev)); b->d_pages = 0; b->d_page_prev = 0; b->deep_pages = 0; }
 			HIPCHK(pool_malloc(b->ix, (void**)&b->d_pages, n_pages * DEEP_PAGE * 16)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_page_prev, n_pages * 4));
 			b->deep_pages = n_pages;
 		}
-		const size_t own_words = (size_t)n_waves * 2 * cap_pages, stage_ent = (size_t)n_waves * 64 * K;
+		const size_t own_words = (size_t)n_waves * 2 * cap_pages, stage_ent = (size_t)n_waves * 3 * 64 * K;
 		if (b->deep_own_words < own_words) {
 			if (b->d_deep_own) HIPCHK(pool_free(b->ix, b->d_deep_own));
 			b->d_deep_own = 0; b->deep_own_words = 0;
@@ -817,7 +834,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		D.S.n_aln = b->d_naln2; D.S.max_ent = b->d_maxent2; D.S.status = b->d_status2; D.S.aln = b->d_aln2; D.S.aln_cap = b->aln_cap2;
 		D.pages = b->d_pages; D.page_prev = b->d_page_prev; D.n_pages = (uint32_t)n_pages;
 		D.page_bump = (unsigned int*)(b->d_deep_ctr + 8);
-		D.own = b->d_deep_own; D.stage = b->d_deep_stage; D.stage_k = K; D.NS = NS;
+		D.own = b->d_deep_own; D.stage = b->d_deep_stage; D.stage_k = K; D.NS = NS; D.lds_rd = lds_rd; D.rd_pl = rd_pl;
 		D.careful_all = env_int("NABWA_DEEP_CAREFUL", 0); D.max_lanes = env_int("NABWA_DEEP_LANES", 64);
 		if (D.max_lanes < 1) D.max_lanes = 1;
 		if (D.max_lanes > 64) D.max_lanes = 64;
@@ -849,8 +866,8 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			if (timing) {
 				unsigned long long st[16];
 				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 128, hipMemcpyDeviceToHost));
-				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text\n",
-						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7]);
+				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text; longest read %.3f s / %llu rounds, all reads %.1f wave-s, longest wave %.3f s\n",
+						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
 			}
 			todo = n_pool;
 		}

@@ -17,7 +17,12 @@
 #define ONE_LANE                 if (ln == 0)                /* side effects that depend on wave-uniform values only */
 #define WBALLOT(expr)            ((uint64_t)__ballot(expr))
 #define WBCAST(name, lane_)      __shfl(name, (int)(lane_))  /* value of the per-lane variable `name` in one lane */
-#define WAVE_SYNC()              __syncthreads()             /* block = one wave: orders this wave's LDS / global accesses */
+/* Lanes of one wave exchange data through LDS and global memory (one lane stores, another loads later).  A wave's memory
+ * instructions reach LDS and its CU's vector cache in program order, so wavefront scope needs no wait and no cache action --
+ * only the compiler must not move accesses across the point (LLVM AMDGPU memory model: a wavefront-scope fence emits nothing).
+ * (A workgroup barrier here drained every outstanding store first: several store latencies per round.) */
+#define WAVE_SYNC()              do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define WUNI(x)                  __builtin_amdgcn_readfirstlane(x)   /* a value all lanes hold: keep it in a scalar register */
 #define ATOMIC_ADD_U32(p, v)     atomicAdd((p), (v))
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
@@ -34,7 +39,7 @@ __device__ __forceinline__ int64_t wave_max_i64(int64_t v)
 }
 /* dst (per lane) = sum of src over the lower lanes, total (uniform) = sum over all lanes */
 #define WEXSCAN_U32(dst, src, total) do { const uint32_t in_ = (src); const uint32_t inc_ = wave_incl_scan_u32(in_); \
-	dst = inc_ - in_; total = (uint32_t)__shfl((int)inc_, 63); } while (0)
+	dst = inc_ - in_; total = (uint32_t)__builtin_amdgcn_readlane((int)inc_, 63); } while (0)
 #define WMAX_I64(total, expr)    do { total = wave_max_i64((int64_t)(expr)); } while (0)
 #else
 // ---------------------------------------------------------------------------------------- CPU emulation of one wave
@@ -45,6 +50,7 @@ __device__ __forceinline__ int64_t wave_max_i64(int64_t v)
 #define WBALLOT(expr)            ([&]() -> uint64_t { uint64_t b_ = 0; for (int ln = 0; ln < 64; ++ln) if (expr) b_ |= 1ull << ln; return b_; }())
 #define WBCAST(name, lane_)      name[(lane_)]
 #define WAVE_SYNC()              do { } while (0)
+#define WUNI(x)                  (x)
 #define ATOMIC_ADD_U32(p, v)     emu_atomic_add((p), (v))
 static inline unsigned int emu_atomic_add(unsigned int *p, unsigned int v) { const unsigned int o = *p; *p = o + v; return o; }
 #define WEXSCAN_U32(dst, src, total) do { uint32_t a_ = 0; for (int ln = 0; ln < 64; ++ln) { const uint32_t in_ = (src); dst = a_; a_ += in_; } total = a_; } while (0)

@@ -18,6 +18,8 @@ for f in glob.glob(os.path.join(root, "g*", "**", "*counter_collection.csv"), re
             k = "S"
         elif "fm_width_kernel<false>" in nm:
             k = "W"
+        elif "fm_deep_kernel" in nm:                      # kernel D: one deep search per wavefront
+            k = "D"
         else:
             continue
         d = acc.setdefault(k, {})

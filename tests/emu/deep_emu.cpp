@@ -120,7 +120,7 @@ uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries; float fnr; int max_diff, max_gapo, max_gape, max_seed_diff, seed_len, n_threads, max_top2, trim_qual; };
 
-// knobs: [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap,
+// knobs: [8] 1 = the read's own data in (emulated) LDS;  [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap,
 // [7] text mode (needs sa0 / sa1: the .sa / .rsa file contents; touches are then not the reference's)
 // stats: 10 words -- 8 as in DeepParams, [8] the reference's bucket touches in the width passes, [9] in bwt_match_gap.  Returns 0.
 extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const uint32_t *sa0, const uint32_t *sa1, const emu_opt *opt, int n, const int64_t *off,
@@ -191,12 +191,14 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	const int n_waves = per_wave > 0 ? (n + per_wave - 1) / per_wave : 1;
 	std::vector<uint4> pages((size_t)P.n_pages * DEEP_PAGE);
 	std::vector<uint32_t> prev(P.n_pages, 0), own((size_t)n_waves * 2 * P.own_cap, 0);
-	std::vector<uint4> stage((size_t)n_waves * 64 * P.stage_k);
-	std::vector<uint32_t> lds(2 * NS + DEEP_NEWP);
+	std::vector<uint4> stage((size_t)n_waves * 3 * 64 * P.stage_k);
+	P.rd_pl = align_up((uint32_t)(max_len > 0 ? max_len : 1), 16);
+	P.lds_rd = knobs[8] ? 2u * S.WLB + 2u * S.SLB + 2u * P.rd_pl : 0u;
+	std::vector<uint32_t> lds(DEEP_LDS_WORDS(NS, P.lds_rd) + 4);
 	P.pages = pages.data(); P.page_prev = prev.data(); P.page_bump = &bump; P.own = own.data(); P.stage = stage.data();
 	for (int w = 0; w < n_waves; ++w) {
 		S.n = per_wave > 0 ? ((w + 1) * per_wave < n ? (w + 1) * per_wave : n) : n;
-		deep_wave_body(P, lds.data(), (uint32_t)w);
+		deep_wave_body(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
 		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
 	}
 	stats[8] = wt; stats[9] = st;

@@ -78,7 +78,7 @@ def deep_opt():
 
 
 @pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=9), dict(stage_k=12, max_lanes=64),
-                                   dict(stage_k=240, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9)])
+                                   dict(stage_k=240, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1)])
 def test_noisy_reads_vs_oracle(emu, words, orc, knobs):
     reads = noisy_reads(11, 150, (50, 63, 76, 100), 0.04)
     seq, rseq, off, _ = T.encode_reads(reads)
