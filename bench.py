@@ -202,7 +202,9 @@ def main():
         if want_cpu:
             cpu, bit_exact = cpu_baseline(T, host_bwt, opt, seq, rseq, off, batch, args)
         reads_per_s = args.reads * world * args.steps / elapsed
-        out = {"metric": "aligned reads/s to GRCh38 (100 bp SE), FM-index search (bwa_cal_sa_reg_gap), bit-exact vs CPU",
+        what = "50-76 bp damaged SE, ancient-DNA options" if args.adna else "%d bp SE" % args.read_len
+        out = {"metric": "aligned reads/s to GRCh38 (%s), FM-index search (bwa_cal_sa_reg_gap)%s" % (
+                   what, ", bit-exact vs CPU" if bit_exact else (", CPU sample DIFFERS" if bit_exact is False else ", CPU comparison not run")),
                "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
