@@ -219,6 +219,14 @@ int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const 
 					const uint8_t *rseq, const int32_t *full_len, const int32_t *n_aln, const nabwa_aln1_t *aln,
 					int n_occ, uint64_t *rng48, nabwa_se_t *out);
 
+/* The two halves of nabwa_se_finish on their own, as bam2bam's two passes need them:
+ * nabwa_se_posn   = posn_singleton (bam2bam.c:622-641): hit choice on the caller's drand48 stream, bwt_sa batch, mapQ;
+ * nabwa_se_refine = bwa_refine_gapped (bwase.c:356-423; finish_singleton, bam2bam.c:643-651) on positioned records + the
+ *                   flag / contig / XT fields bwa_update_bam1 derives.  NABWA_ECAP if an MD string exceeds NABWA_MAX_MD. */
+int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+				  const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, uint64_t *rng48, nabwa_se_t *out);
+int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, nabwa_se_t *inout);
+
 /* ---- paired-end chain (config 3) ------------------------------------------------------------ */
 /* pe_opt_t (bwtaln.h:158-164), same layout; defaults as bwa_init_pe_opt (bwape.c:27-41) */
 typedef struct {
@@ -250,6 +258,21 @@ int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, co
 int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 					int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
 					const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2]);
+
+/* ---- the same phases on the reference's own records (bwa_seq_t), one call per phase and batch ---------------------
+ * Each replaces the per-record function of the same role in bam2bam.c; fields are left as that function leaves them, and
+ * multi / multi[].cigar / cigar / md are malloc'd for bwa_free_read_seq1 (bwaseqio.c:253-261) to free.
+ *   nabwa_bwa_posn_se       posn_singleton (bam2bam.c:622-641): bwa_aln2seq_core(.., 1, max_occ_se), bwa_cal_pac_pos_core, multi positions
+ *   nabwa_bwa_refine_gapped bwa_refine_gapped(bns, n, seqs, pac, ntbns) (bwase.h:16; bam2bam.c:649,799-800), seq un-reversed as there
+ *   nabwa_bwa_posn_pe       posn_pair (bam2bam.c:683-703); records interleaved, 2 * pair + end
+ *   nabwa_bwa_finish_pe     finish_pair up to bwa_update_bam1 (bam2bam.c:705-800): pairing (bwape.h:46), bwa_paired_sw1 (bwape.h:49),
+ *                           multi lists, bwa_refine_gapped on both ends
+ * rng48: the drand48 state (srand48(seed) == ((uint64_t)seed << 16) | 0x330E), consumed in record order. */
+int nabwa_bwa_posn_se(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int max_occ_se, int n, nabwa_bwa_seq_t *seqs, uint64_t *rng48);
+int nabwa_bwa_refine_gapped(nabwa_index_t *ix, int n, nabwa_bwa_seq_t *seqs);
+int nabwa_bwa_posn_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t *rng48);
+int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+						int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2]);
 
 /* Read-back of the index parts derived at load time (tests): what 0 = full SA, 1 = inverse SA, 2 = text bases (one per
  * word), 3 = interval-table entries {k, l} of the last level (two words per key), 4 = the table's depth T (one word). */

@@ -70,7 +70,7 @@ static inline int pac2real(const nabwa_reference *R, int64_t pos, int len, int *
 struct RefineJob { int rec, multi, strand, ext, len; int64_t pos; int64_t win_lo; int win_n; };
 
 /* MD string and NM of an alignment (bwa_cal_md1, bwase.c:253-315) */
-static inline void make_md(const nabwa_reference *R, int n_cigar, const uint16_t *cigar, int len, uint32_t pos0, const uint8_t *q,
+static inline bool make_md(const nabwa_reference *R, int n_cigar, const uint16_t *cigar, int len, uint32_t pos0, const uint8_t *q,
 					char *md, int cap, int *nm_out)
 {
 	int64_t pos = pos0; int u = 0, nm = 0, y = 0; std::string s; char num[16];
@@ -100,6 +100,7 @@ static inline void make_md(const nabwa_reference *R, int n_cigar, const uint16_t
 	flush_num();
 	snprintf(md, cap, "%s", s.c_str());
 	*nm_out = nm;
+	return (int)s.size() < cap;          /* false: the string did not fit (the caller reports NABWA_ECAP, never a cut-off tag) */
 }
 
 
@@ -232,13 +233,13 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 
 /* MD / NM of a mapped record, then the quality-trimmed tail as a soft clip (bwase.c:399-419, :320-354).
  * `fwd` is scratch for the un-reversed read. */
-static inline void md_and_trim(const nabwa_reference *R, nabwa_se_t &s, const uint8_t *seq_i, const uint8_t *rseq_i, std::vector<uint8_t> &fwd)
+static inline bool md_and_trim(const nabwa_reference *R, nabwa_se_t &s, const uint8_t *seq_i, const uint8_t *rseq_i, std::vector<uint8_t> &fwd)
 {
 	const int len = s.len;
 	const uint8_t *q;
 	if (s.strand) q = rseq_i;
 	else { fwd.resize(len); for (int k = 0; k < len; ++k) fwd[k] = seq_i[len - 1 - k]; q = fwd.data(); }
-	make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
+	const bool md_fits = make_md(R, s.n_cigar, s.cigar, len, s.pos, q, s.md, NABWA_MAX_MD, &s.nm);
 	if (len != s.full_len) {                                   /* bwa_correct_trimmed */
 		const int clip = s.full_len - len;
 		if (s.strand == 0) {
@@ -254,4 +255,5 @@ static inline void md_and_trim(const nabwa_reference *R, nabwa_se_t &s, const ui
 		}
 		s.len = s.full_len;
 	}
+	return md_fits;
 }

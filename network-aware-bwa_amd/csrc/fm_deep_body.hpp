@@ -407,9 +407,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// ---------------------------------------------------------------- commit, in the reference's order
 				const uint64_t stopm = WBALLOT(L(flag) != DF_NONE && (uint32_t)ln < W);
 				int jl = stopm ? deep_ctz64(stopm) : (int)W - 1;            // the last lane whose chain counts
-				uint32_t tot = 0;
-				LANES { L(d) = ln <= jl ? (uint32_t)L(rel) : 0u; }
-				WEXSCAN_U32(L(off), L(d), tot);
+				{ uint32_t tot = 0; LANES { L(d) = ln <= jl ? (uint32_t)L(rel) : 0u; } WEXSCAN_U32(L(off), L(d), tot); (void)tot; }
 				LANES { L(nst) = n_entries + (int)L(off); }                  // live entries before this lane's first pop
 				const uint64_t over = WBALLOT(ln <= jl && (int64_t)L(nst) + L(peak) > (int64_t)S.max_entries);
 				if (over) { careful = true; jl = deep_ctz64(over) - 1; }   // the cut-off (bwtgap.c:140) falls into that lane's chain

@@ -321,12 +321,13 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 	t4 = now();
 
 	/* ---- E. MD / NM / trimmed tail per end, then the flag and mate fields (bwase.c:399-419, bam2bam.c:430-525) */
+	int md_over = 0;
 	auto phaseE = [&](int lo, int hi) {
 		std::vector<uint8_t> fwd;
 		for (int pr = lo; pr < hi; ++pr) {
 			for (int j = 0; j < 2; ++j) {
 				nabwa_se_t &s = PE(out, pr, j).se;
-				if (s.type != 0) md_and_trim(R, s, seq + off[2 * pr + j], rseq + off[2 * pr + j], fwd);
+				if (s.type != 0 && !md_and_trim(R, s, seq + off[2 * pr + j], rseq + off[2 * pr + j], fwd)) md_over = 1;
 			}
 			for (int j = 0; j < 2; ++j) {                              /* end 0 first, as bam2bam.c:804-805 */
 				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &p = r.se;
@@ -367,6 +368,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 		for (int t = 0; t < nt; ++t) th.emplace_back(phaseE, (int)((int64_t)n_pairs * t / nt), (int)((int64_t)n_pairs * (t + 1) / nt));
 		for (auto &x : th) x.join();
 	}
+	if (md_over) return nabwa_fail(NABWA_ECAP, "MD string longer than NABWA_MAX_MD");
 	if (timing) fprintf(stderr, "[nabwa] pe_finish %d pairs: pairing (%zu hit rows) %.3f s, multi %.3f s, mate rescue (%zu alignments) %.3f s, "
 						"refinement (%zu jobs) %.3f s, md/flags %.3f s\n", n_pairs, n_hit_rows, t1 - t0, t2 - t1, n_sw, t3 - t2, n_refine, t4 - t3, now() - t4);
 	return NABWA_OK;

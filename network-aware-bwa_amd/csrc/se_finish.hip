@@ -307,20 +307,34 @@ extern "C" int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefi
 
 /* ------------------------------------------------------------------ the chain */
 
-extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const uint8_t *seq,
-							   const uint8_t *rseq, const int32_t *full_len, const int32_t *n_aln, const nabwa_aln1_t *aln,
-							   int n_occ, uint64_t *rng48, nabwa_se_t *out)
+/* host threads of the finishing chains: slices of independent records */
+static int host_threads(int n)
 {
-	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !seq || !rseq || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
-	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+	if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
+	if (n < 4096) nt = 1;
+	return nt;
+}
+static void in_threads(int nt, size_t count, const std::function<void(size_t, size_t)> &f)
+{
+	if (nt == 1) { f(0, count); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; ++t) th.emplace_back(f, count * t / nt, count * (t + 1) / nt);
+	for (auto &x : th) x.join();
+}
+
+/* posn_singleton (bam2bam.c:622-641) for n reads in record order: bwa_aln2seq_core with the caller's drand48 stream, all
+ * bwt_sa walks of the batch (main hits and multi hits) as one GPU batch, bwa_approx_mapQ */
+extern "C" int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+							 const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, uint64_t *rng48, nabwa_se_t *out)
+{
+	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (n_occ < 0 || n_occ + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
-	const nabwa_reference *R = ix->ref;
 	const uint32_t rlen = ix->bwt[1].seq_len;
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	double t0 = now(), t1, t2, t3;
-
-	/* ---- phase 1, host, record order: hit choice with the caller's RNG stream (bwase.c:19-95) */
+	const double t0 = now();
+	/* ---- host, record order: hit choice with the caller's RNG stream (bwase.c:19-95) */
 	std::vector<uint8_t> which; std::vector<uint32_t> rows;           /* SA lookups: [main of each mapped read][multi...] */
 	std::vector<int> look_rec, look_multi;
 	which.reserve((size_t)n + n / 4); rows.reserve((size_t)n + n / 4); look_rec.reserve((size_t)n + n / 4); look_multi.reserve((size_t)n + n / 4);
@@ -336,31 +350,21 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 		if (na == 0) continue;
 		choose_main(s, na, A, rng48);
 		list_multi(s, na, A, n_occ);
-		int j;
 		which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look_rec.push_back(i); look_multi.push_back(-1);
-		for (j = 0; j < s.n_multi; ++j) {
+		for (int j = 0; j < s.n_multi; ++j) {
 			which.push_back(s.multi[j].strand ? 0 : 1); rows.push_back(s.multi[j].pos); look_rec.push_back(i); look_multi.push_back(j);
 		}
 	}
-
-	t1 = now();
-	/* ---- phase 2, GPU: all bwt_sa walks of the batch (bwt.c:72-81) */
+	const double t1 = now();
+	/* ---- GPU: all bwt_sa walks of the batch (bwt.c:72-81) */
 	std::vector<uint32_t> sa(rows.size());
 	if (!rows.empty()) {
 		int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data());
 		if (r != NABWA_OK) return r;
 	}
-	int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
-	if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
-	if (n < 4096) nt = 1;
-	auto in_threads = [&](size_t count, const std::function<void(size_t, size_t)> &f) {
-		if (nt == 1) { f(0, count); return; }
-		std::vector<std::thread> th;
-		for (int t = 0; t < nt; ++t) th.emplace_back(f, count * t / nt, count * (t + 1) / nt);
-		for (auto &x : th) x.join();
-	};
+	const int nt = host_threads(n);
 	/* positions (bwase.c:146-151, bam2bam.c:635-636): every looked-up row belongs to one record field, so slices are independent */
-	in_threads(rows.size(), [&](size_t lo, size_t hi) {
+	in_threads(nt, rows.size(), [&](size_t lo, size_t hi) {
 		for (size_t t = lo; t < hi; ++t) {
 			nabwa_se_t &s = out[look_rec[t]];
 			const uint32_t p = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
@@ -372,7 +376,7 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 	for (int i = 0; i < n; ++i) if (out[i].len > longest) longest = out[i].len;
 	std::vector<int> md_of(longest + 1, opt->max_diff);
 	if (opt->fnr > 0.0f) for (int L = 0; L <= longest; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
-	in_threads((size_t)n, [&](size_t lo, size_t hi) {
+	in_threads(nt, (size_t)n, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
 			nabwa_se_t &s = out[i];
 			if (s.type == 0) continue;
@@ -380,23 +384,35 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 			s.mapQ = s.seQ = q;
 		}
 	});
+	if (timing) fprintf(stderr, "[nabwa] se_posn %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) + positions + mapQ %.3f s\n", n, t1 - t0, rows.size(), now() - t1);
+	return NABWA_OK;
+}
 
-	t2 = now();
-	/* ---- phase 3, GPU: gap refinement of every gapped hit as one batch of global alignments (bwase.c:189-237) */
+/* The non-BAM part of finish_singleton (bam2bam.c:643-651) for n positioned records: bwa_refine_gapped (bwase.c:356-423 --
+ * refine_gapped_core of every gapped hit as ONE GPU batch of banded global alignments, bwa_cal_md1, bwa_correct_trimmed), then
+ * the flag / contig / XT logic bwa_update_bam1 applies to a single-end record (bam2bam.c:430-525). */
+extern "C" int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, nabwa_se_t *out)
+{
+	if (!ix || n < 0 || (n && (!off || !seq || !rseq || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	const nabwa_reference *R = ix->ref;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t2 = now();
 	size_t n_jobs = 0;
 	{
 		int r = refine_batch(ix, out, sizeof(nabwa_se_t), n, off, seq, rseq, &n_jobs);
 		if (r != NABWA_OK) return r;
 	}
-
-	t3 = now();
-	/* ---- phase 4, host threads: MD / NM, trimmed tail, flags (bwase.c:253-354, :458-571); records are independent */
+	const double t3 = now();
+	/* host threads: MD / NM, trimmed tail, flags (bwase.c:253-354, :458-571); records are independent */
+	int md_over = 0;
 	auto phase4 = [&](int lo, int hi) {
 		std::vector<uint8_t> fwd;
 		for (int i = lo; i < hi; ++i) {
 			nabwa_se_t &s = out[i];
 			if (s.type == 0) { s.flag = 4; continue; }
-			md_and_trim(R, s, seq + off[i], rseq + off[i], fwd);
+			if (!md_and_trim(R, s, seq + off[i], rseq + off[i], fwd)) md_over = 1;
 			int64_t end = s.pos;
 			if (s.n_cigar) { for (int k = 0; k < s.n_cigar; ++k) { const int op = COP(s.cigar[k]); if (op == 0 || op == 2) end += CLEN(s.cigar[k]); } }
 			else end += s.len;
@@ -409,8 +425,19 @@ extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 			s.xt = s.nn > 10 ? 'N' : "NURM"[s.type];
 		}
 	};
-	in_threads((size_t)n, [&](size_t lo, size_t hi) { phase4((int)lo, (int)hi); });
-	if (timing) fprintf(stderr, "[nabwa] se_finish %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) %.3f s, refinement (%zu jobs) %.3f s, md/flags %.3f s\n",
-						n, t1 - t0, rows.size(), t2 - t1, n_jobs, t3 - t2, now() - t3);
+	in_threads(host_threads(n), (size_t)n, [&](size_t lo, size_t hi) { phase4((int)lo, (int)hi); });
+	if (md_over) return nabwa_fail(NABWA_ECAP, "MD string longer than NABWA_MAX_MD");
+	if (timing) fprintf(stderr, "[nabwa] se_refine %d reads: refinement (%zu jobs) %.3f s, md/flags %.3f s\n", n, n_jobs, t3 - t2, now() - t3);
 	return NABWA_OK;
+}
+
+extern "C" int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const uint8_t *seq,
+							   const uint8_t *rseq, const int32_t *full_len, const int32_t *n_aln, const nabwa_aln1_t *aln,
+							   int n_occ, uint64_t *rng48, nabwa_se_t *out)
+{
+	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !seq || !rseq || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	int r = nabwa_se_posn(ix, opt, n, off, full_len, n_aln, aln, n_occ, rng48, out);
+	if (r == NABWA_OK) r = nabwa_se_refine(ix, n, off, seq, rseq, out);
+	return r;
 }

@@ -470,3 +470,30 @@ int ref_pe_isize_pairs(ref_pe_batch_t *b, double ap_prior, int64_t L, double *o)
 	o[0] = avg; o[1] = std; o[3] = low; o[4] = high; o[5] = hb;
 	return 0;
 }
+
+/* ------------------------------------------------------------------ the phases of bam2bam on the CALLER's bwa_seq_t records
+ * (tests of the product's bwa_seq_t-level entry points: both sides get the same array).  Every call is the reference's. */
+/* posn_singleton (bam2bam.c:622-641) for each record in order, then the bwa_refine_gapped of finish_singleton (:649) */
+void ref_se_records(ref_index_t *ix, const gap_opt_t *opt, int max_occ_se, int n, bwa_seq_t *s)
+{
+	int i, j;
+	bwase_initialize();
+	for (i = 0; i < n; ++i) {
+		bwa_seq_t *p = s + i;
+		bwa_aln2seq_core(p->n_aln, p->aln, p, 1, max_occ_se);
+		bwa_cal_pac_pos_core(ix->bwt[0], ix->bwt[1], p, opt->max_diff, opt->fnr);
+		for (j = 0; j < p->n_multi; ++j) {
+			bwt_multi1_t *q = p->multi + j;
+			if (q->strand) q->pos = bwt_sa(ix->bwt[0], q->pos);
+			else q->pos = ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], q->pos) + p->len);
+		}
+	}
+	bwa_refine_gapped(ix->bns, n, s, ix->pac, 0);
+}
+/* posn_pair for every pair, then finish_pair up to bwa_update_bam1 (the glue above) */
+void ref_pe_records(ref_index_t *ix, const gap_opt_t *opt, const double *iiv, int n_pairs, bwa_seq_t *s)
+{
+	ref_pe_batch_t b; b.n = n_pairs; b.s = s;
+	ref_pe_posn(&b, ix, opt);
+	ref_pe_finish(&b, ix, opt, iiv);
+}

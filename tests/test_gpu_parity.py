@@ -181,7 +181,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     monkeypatch.delenv("NABWA_ALNCAP1")
     b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
     b.run()
-    assert b.sync() < 20            # only the few reads with > NABWA_CAP1 pushes or > 16 hits
+    assert b.sync() < 150           # only the reads with > NABWA_CAP1 pushes, > 16 hits or more than NABWA_TRIP_BUDGET trips
     assert b.checksum() == cs          # device checksum is independent of which pass produced a row
     assert b.checksum()[1] == sum(len(g) for g in gold)
     b.close()
@@ -193,7 +193,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     {"NABWA_CAP1": "16", "NABWA_DEEP_LANES": "3"},                           # rounds of three chains
     {"NABWA_CAP1": "16", "NABWA_DEEP_STAGE": "9"},                           # the smallest staging buffers: chains continue over rounds
     {"NABWA_CAP1": "16", "NABWA_DEEP_CAREFUL": "1"},                         # one pop per round
-    {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "400", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
+    {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "6000", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
     {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1"},                              # the first pass fails on the hit lists too
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_flagged_reads_through_kernel_d_are_bit_exact(gix, monkeypatch, env):

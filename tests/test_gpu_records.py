@@ -1,0 +1,147 @@
+"""The phases after the search on the reference's own records (bwa_seq_t): nabwa_bwa_posn_se / nabwa_bwa_refine_gapped /
+nabwa_bwa_posn_pe / nabwa_bwa_finish_pe against the reference's functions run on the same arrays (oracle/_ref, compiled from
+/root/reference: bwa_aln2seq_core, bwa_cal_pac_pos_core, bwt_sa, pairing, bwa_paired_sw1, bwa_refine_gapped in bam2bam's
+order), field for field -- what makes posn_* / finish_* (bam2bam.c:622-811) one-line swaps."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import nabwa_testlib as T
+
+pytestmark = pytest.mark.gpu
+nabwa = importlib.import_module("network-aware-bwa_amd")
+
+
+class Multi1(C.Structure):
+    """bwt_multi1_t (reference bwtaln.h:58-62)"""
+    _fields_ = [("pos", C.c_uint32), ("bits", C.c_uint32), ("cigar", C.c_void_p)]
+
+
+def make_records(reads, seq, rseq, off, hits, full, extra=None):
+    n = len(reads)
+    arr = (nabwa.BwaSeq * n)()
+    keep = []
+    for i in range(n):
+        # seq is un-reversed in place by bwa_refine_gapped: every side gets its own copy
+        s = np.ascontiguousarray(seq[off[i]:off[i + 1]]).copy()
+        r = np.ascontiguousarray(rseq[off[i]:off[i + 1]]).copy()
+        a = np.ascontiguousarray(hits[i]).copy()
+        keep += [s, r, a]
+        L = len(s)
+        arr[i].seq = s.ctypes.data if L else None
+        arr[i].rseq = r.ctypes.data if L else None
+        arr[i].bits0 = L | ((extra[i] if extra is not None else 0) << 24)
+        arr[i].clip_len = L
+        arr[i].lenbits = int(full[i])
+        arr[i].n_aln = len(a)
+        arr[i].aln = a.ctypes.data if len(a) else None
+    return arr, keep
+
+
+def record_fields(q, L):
+    """L: the (trimmed) length the record came with -- bwa_correct_trimmed sets len = full_len, the buffer stays as it was"""
+    out = dict(bits0=q.bits0 & ~(1 << 23), bits1=q.bits1, score=q.score, clip_len=q.clip_len, sa=q.sa, pos=q.pos, c1c2seq=q.c1c2seq,
+               lenbits=q.lenbits, n_multi=q.n_multi, seq=bytes((C.c_uint8 * L).from_address(q.seq)) if L else b"")
+    tp = q.bits0 >> 21 & 3
+    out["cigar"] = bytes((C.c_uint16 * q.n_cigar).from_address(q.cigar)) if q.cigar else b""
+    out["md"] = C.string_at(q.md) if q.md else None
+    if tp == 0:
+        out["score"] = out["sa"] = out["pos"] = 0          # fields of an unmapped read are whatever was there before
+        out["bits1"] = 0
+    m = []
+    for j in range(q.n_multi):
+        e = Multi1.from_address(q.multi + 16 * j)
+        nc = e.bits & 0x7fff
+        m.append((e.pos, e.bits >> 15, bytes((C.c_uint16 * nc).from_address(e.cigar)) if e.cigar else b""))
+    out["multi"] = m
+    return out
+
+
+@pytest.fixture(scope="module")
+def ref():
+    lib = T.load_ref()
+    if lib is None:
+        pytest.skip("the compiled reference (oracle/_ref) did not travel")
+    lib.ref_index_load.restype = C.c_void_p
+    lib.ref_se_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ref_pe_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    return lib, C.c_void_p(lib.ref_index_load(T.TOY.encode(), 1))
+
+
+@pytest.mark.parametrize("name", ["default", "adna", "q20"])
+def test_se_phases_on_reference_records(ref, name):
+    rlib, rix = ref
+    opt, _ = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    seq, rseq, off, full = T.encode_reads(reads, opt.trim_qual)
+    g = nabwa.GapOpt()
+    C.memmove(C.byref(g), C.byref(opt), 64)
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    hits, _ = ix.cal_sa_reg_gap(g, seq, rseq, off, per_read=False)
+    want, k1 = make_records(reads, seq, rseq, off, hits, full)
+    rlib.ref_seed48(11)
+    rlib.ref_se_records(rix, C.byref(opt), 3, len(reads), want)
+    got, k2 = make_records(reads, seq, rseq, off, hits, full)
+    st = C.c_uint64(nabwa.srand48_state(11))
+    L = nabwa.lib()
+    L.nabwa_bwa_posn_se.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.nabwa_bwa_refine_gapped.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    # two batches: the drand48 stream continues across calls as the reference's process-global one does
+    cut = 301
+    n = len(reads)
+    for lo, hi in ((0, cut), (cut, n)):
+        part = C.byref(got, lo * C.sizeof(nabwa.BwaSeq))
+        assert L.nabwa_bwa_posn_se(ix._h, C.byref(g), 3, hi - lo, part, C.byref(st)) == 0, L.nabwa_last_error()
+    assert L.nabwa_bwa_refine_gapped(ix._h, n, got) == 0, L.nabwa_last_error()
+    for i in range(n):
+        a, b = record_fields(got[i], int(off[i + 1] - off[i])), record_fields(want[i], int(off[i + 1] - off[i]))
+        assert a == b, (reads[i][0], {k: (a[k], b[k]) for k in a if a[k] != b[k]})
+    ix.close()
+
+
+def test_pe_phases_on_reference_records(ref):
+    rlib, rix = ref
+    opts, hits_e, reads_e = [], [], []
+    for e in (1, 2):
+        o, h = T.read_sai(os.path.join(T.GOLDEN, "pe_%d.sai" % e))
+        opts.append(o)
+        hits_e.append(h)
+        reads_e.append(T.read_fastq(os.path.join(T.GOLDEN, "reads_pe_%d.fq" % e)))
+    opt = opts[0]
+    n_pairs = len(reads_e[0])
+    reads, hits = [], []
+    for i in range(n_pairs):
+        for e in (0, 1):
+            reads.append(reads_e[e][i])
+            hits.append(hits_e[e][i])
+    seq, rseq, off, full = T.encode_reads(reads)
+    extra = [1 | (64 if i % 2 == 0 else 128) for i in range(len(reads))]       # SAM_FPD | SAM_FR1 / SAM_FR2
+    g = nabwa.GapOpt()
+    C.memmove(C.byref(g), C.byref(opt), 64)
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    L = nabwa.lib()
+    L.nabwa_bwa_posn_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.nabwa_bwa_finish_pe.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    for iiv in ([0.0] * 6, [400.0, 40.0, 1e-5, 250.0, 550.0, 640.0]):          # no estimate (null_ii) / a usable one
+        want, k1 = make_records(reads, seq, rseq, off, hits, full, extra)
+        rlib.ref_seed48(11)
+        v = (C.c_double * 6)(*iiv)
+        rlib.ref_pe_records(rix, C.byref(opt), v, n_pairs, want)
+        got, k2 = make_records(reads, seq, rseq, off, hits, full, extra)
+        st = C.c_uint64(nabwa.srand48_state(11))
+        assert L.nabwa_bwa_posn_pe(ix._h, C.byref(g), n_pairs, got, C.byref(st)) == 0, L.nabwa_last_error()
+        ii = nabwa.IsizeInfo(iiv[0], iiv[1], iiv[2], int(iiv[3]), int(iiv[4]), int(iiv[5]))
+        po = nabwa.pe_opt_default()
+        tot = (C.c_uint64 * 2)()
+        mapped = (C.c_uint64 * 2)()
+        assert L.nabwa_bwa_finish_pe(ix._h, C.byref(g), C.byref(po), C.byref(ii), n_pairs, got, tot, mapped) == 0, L.nabwa_last_error()
+        for i in range(len(reads)):
+            a, b = record_fields(got[i], int(off[i + 1] - off[i])), record_fields(want[i], int(off[i + 1] - off[i]))
+            if (want[i].bits0 >> 21 & 3) == 0:             # an unmapped end: bwa_update_bam1 gives it its mate's place later; nothing here is defined
+                a = {k: a[k] for k in ("n_multi", "cigar", "md")}
+                b = {k: b[k] for k in ("n_multi", "cigar", "md")}
+            assert a == b, (reads[i][0], iiv[0], {k: (a[k], b[k]) for k in a if a[k] != b[k]})
+    ix.close()
