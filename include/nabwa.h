@@ -207,6 +207,10 @@ typedef struct {
 /* Annotation side of the index (replaces bns_restore + bwt_restore_pac, bntseq.c:88-148): <prefix>.ann,
  * .amb and .pac are read into host memory and attached to the index. */
 int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefix);
+/* the same from memory (bntseq_t: contigs with offsets and lengths, bntamb1_t holes, the .pac bytes) */
+int nabwa_index_set_reference(nabwa_index_t *ix, int64_t l_pac, uint32_t seed, int n_seqs, const char *const *names,
+							  const int64_t *offsets, const int32_t *lens, int n_holes, const int64_t *hole_off,
+							  const int32_t *hole_len, const char *hole_amb, const uint8_t *pac);
 
 /* bwa_aln2seq_core (bwase.c:19-95) -> bwa_cal_pac_pos_core + multi-hit positions (bwase.c:139-181,
  * bam2bam.c:629-637) -> bwa_refine_gapped (bwase.c:356-423: gap refinement, MD/NM, trimmed-tail clip) for
@@ -226,6 +230,9 @@ int nabwa_se_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const 
 int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
 				  const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, uint64_t *rng48, nabwa_se_t *out);
 int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, nabwa_se_t *inout);
+/* nabwa_se_posn with a hit-list bound per read (singletons: max_occ_se, ends of pairs: 0 -- one drand48 stream for a mixed file) */
+int nabwa_se_posn_v(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+					const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out);
 
 /* ---- paired-end chain (config 3) ------------------------------------------------------------ */
 /* pe_opt_t (bwtaln.h:158-164), same layout; defaults as bwa_init_pe_opt (bwape.c:27-41) */
@@ -273,6 +280,36 @@ int nabwa_bwa_refine_gapped(nabwa_index_t *ix, int n, nabwa_bwa_seq_t *seqs);
 int nabwa_bwa_posn_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t *rng48);
 int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 						int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2]);
+
+/* ---- the batching front-end: BAM records in, BAM records out (what sits behind `bwa bam2bam` / `bwa worker`) --------
+ * A batch = n_rec records as they stand in an uncompressed BAM stream (u32 block_size + block), in file order, mates adjacent.
+ *   create : read_bam_pair's record logic (bwaseqio.c:340-494: singleton / pair, QC flag over mates, erase_unwanted_tags) and
+ *            bam1_to_seq (bwaseqio.c:272-307)
+ *   pass1  : pair_aln + pair_posn + improve_isize_est per logical record, in record order on the caller's drand48 stream
+ *            (bam2bam.c:1143-1176, 608-703; insert_size.c:141-165)
+ *   pass2  : pair_finish incl. bwa_update_bam1 (bam2bam.c:1178-1216, 643-658, 705-811, 430-593), each read group with its
+ *            own insert-size estimate
+ *   output : the records (uncompressed BAM bytes; BGZF and the header are the caller's, as they are bam2bam's own bgzf.c)
+ * Between the passes of ALL batches: nabwa_isize_table_infer_all (infer_all_isizes, insert_size.c:167-173). */
+typedef struct nabwa_isize_table nabwa_isize_table_t;
+typedef struct nabwa_bam_batch nabwa_bam_batch_t;
+nabwa_isize_table_t *nabwa_isize_table_create(double ap_prior, int64_t genome_len);
+void nabwa_isize_table_destroy(nabwa_isize_table_t *t);
+int nabwa_isize_table_infer_all(nabwa_isize_table_t *t);
+/* the estimate of a read group; returns 1 and all zeros (null_ii, bam2bam.c:106) when it has none */
+int nabwa_isize_table_get(const nabwa_isize_table_t *t, const char *rg, nabwa_isize_t *out);
+/* histograms of another shard's pass 1 added in (N GPUs: the one cross-shard reduction of the pipeline) */
+int nabwa_isize_table_merge(nabwa_isize_table_t *t, const nabwa_isize_table_t *other);
+/* encode_iinfo / decode_iinfo (insert_size.c:185-213): the blob a `bwa worker` is sent; encode returns the size needed */
+int64_t nabwa_isize_table_encode(const nabwa_isize_table_t *t, uint8_t *out, int64_t cap);
+int nabwa_isize_table_decode(nabwa_isize_table_t *t, const uint8_t *in, int64_t n);
+int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
+						   const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out);
+int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab);
+int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2]);
+int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes);
+int nabwa_bam_batch_counts(const nabwa_bam_batch_t *b, int *n_records, int *n_logical);
+void nabwa_bam_batch_destroy(nabwa_bam_batch_t *b);
 
 /* Read-back of the index parts derived at load time (tests): what 0 = full SA, 1 = inverse SA, 2 = text bases (one per
  * word), 3 = interval-table entries {k, l} of the last level (two words per key), 4 = the table's depth T (one word). */

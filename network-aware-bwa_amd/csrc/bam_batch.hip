@@ -1,0 +1,529 @@
+// bam_batch.hip -- the batching front-end behind `bwa bam2bam` / `bwa worker`: BAM records in, BAM records out.
+//
+// The reference handles one logical record (a singleton or a pair) at a time: read_bam_pair -> pair_aln -> pair_posn ->
+// improve_isize_est -> [all records] -> infer_all_isizes -> pair_finish -> bwa_update_bam1 (bam2bam.c:1143-1216, 608-811,
+// 430-593; bwaseqio.c:340-494; insert_size.c:141-213).  Here the same steps run over a BATCH of records:
+//   create : split the records into singletons and pairs (read_bam_pair_core's rules), OR the QC flag over mates, erase the
+//            tags the aligner regenerates (erase_unwanted_tags), encode the reads (bam1_to_seq incl. reverse flag and trimming)
+//   pass 1 : bwa_cal_sa_reg_gap of every read [GPU, kernels W / S / D], the hit choice IN RECORD ORDER on the caller's drand48
+//            stream (posn_singleton: bwa_aln2seq_core(.., 1, max_occ_se); posn_pair: bwa_aln2seq), all bwt_sa walks as one
+//            GPU batch, mapQ, and the per-@RG insert-size histograms (improve_isize_est)
+//   pass 2 : finish_singleton / finish_pair per read group with that group's estimate (pairing, mate rescue and gap
+//            refinement as GPU batches inside nabwa_pe_finish / nabwa_se_refine), then bwa_update_bam1: flags, coordinates,
+//            bin, CIGAR, reverse-complemented SEQ/QUAL, mate fields, tags in the reference's order and types
+// All host code; the GPU work is what the entry points it calls do.  bam2bam.c itself cannot be compiled in the build
+// container (<zmq.h>), so the BAM-specific bytes are checked through every field the reference's samse / sampe SAM exposes
+// (tests/test_gpu_bam.py), not against a bam2bam run: DESIGN.md says so.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/nabwa.h"
+#include "nabwa_internal.hpp"
+#include "finish_common.hpp"
+
+#define F_PD 1
+#define F_PP 2
+#define F_SU 4
+#define F_MU 8
+#define F_SR 16
+#define F_MR 32
+#define F_R1 64
+#define F_R2 128
+#define F_SC 256
+#define F_QC 512
+
+/* ------------------------------------------------------------------ per-@RG insert-size table (insert_size.c:141-213) */
+
+struct nabwa_isize_table {
+	struct Rg { nabwa_isize_t ii; std::vector<uint16_t> hist; bool has_hist; };
+	std::map<std::string, Rg> rg;        /* (the reference keeps a khash; its iteration order only decides the order of log lines) */
+	double ap_prior; int64_t L;
+};
+
+extern "C" nabwa_isize_table_t *nabwa_isize_table_create(double ap_prior, int64_t genome_len)
+{
+	nabwa_isize_table *t = new nabwa_isize_table();
+	t->ap_prior = ap_prior; t->L = genome_len;
+	return t;
+}
+extern "C" void nabwa_isize_table_destroy(nabwa_isize_table_t *t) { delete t; }
+
+/* improve_isize_est (insert_size.c:141-165): one logical record's contribution.  The 16-bit bins wrap as the reference's do
+ * (its "hit the ceiling" test compares an unsigned short with -1 and never fires). */
+static void isize_add(nabwa_isize_table *t, const std::string &rg, int bin)
+{
+	if (bin < 0) return;
+	auto it = t->rg.find(rg);
+	if (it == t->rg.end()) {
+		nabwa_isize_table::Rg r; memset(&r.ii, 0, sizeof(r.ii)); r.hist.assign(100000, 0); r.has_hist = true;
+		it = t->rg.emplace(rg, std::move(r)).first;
+	}
+	if (!it->second.has_hist) return;
+	it->second.hist[bin] = (uint16_t)(it->second.hist[bin] + 1);
+}
+
+/* infer_all_isizes (insert_size.c:167-173): every read group that still has its histogram gets its estimate */
+extern "C" int nabwa_isize_table_infer_all(nabwa_isize_table_t *t)
+{
+	if (!t) return nabwa_fail(NABWA_EINVAL, "null argument");
+	for (auto &kv : t->rg)
+		if (kv.second.has_hist) {
+			nabwa_isize_infer(kv.second.hist.data(), t->ap_prior, t->L, &kv.second.ii);
+			kv.second.hist.clear(); kv.second.hist.shrink_to_fit(); kv.second.has_hist = false;
+		}
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_isize_table_get(const nabwa_isize_table_t *t, const char *rg, nabwa_isize_t *out)
+{
+	if (!t || !rg || !out) return nabwa_fail(NABWA_EINVAL, "null argument");
+	auto it = t->rg.find(rg);
+	if (it == t->rg.end() || it->second.has_hist) { memset(out, 0, sizeof(*out)); return 1; }      /* null_ii (bam2bam.c:106,715) */
+	*out = it->second.ii;
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_isize_table_merge(nabwa_isize_table_t *t, const nabwa_isize_table_t *other)      /* the host add between passes of N shards */
+{
+	if (!t || !other) return nabwa_fail(NABWA_EINVAL, "null argument");
+	for (const auto &kv : other->rg) {
+		if (!kv.second.has_hist) continue;
+		auto it = t->rg.find(kv.first);
+		if (it == t->rg.end()) { t->rg.emplace(kv.first, kv.second); continue; }
+		if (!it->second.has_hist) continue;
+		for (size_t b = 0; b < 100000; ++b) it->second.hist[b] = (uint16_t)(it->second.hist[b] + kv.second.hist[b]);
+	}
+	return NABWA_OK;
+}
+
+/* encode_iinfo / decode_iinfo (insert_size.c:185-213): the blob `bwa worker` receives -- per read group its name, NUL, then the
+ * raw isize_info_t (a dead histogram pointer, then avg, std, ap_prior, low, high, high_bayesian: 48 bytes) */
+extern "C" int64_t nabwa_isize_table_encode(const nabwa_isize_table_t *t, uint8_t *out, int64_t cap)
+{
+	if (!t) return nabwa_fail(NABWA_EINVAL, "null argument");
+	int64_t need = 0;
+	for (const auto &kv : t->rg) need += (int64_t)kv.first.size() + 1 + 8 + (int64_t)sizeof(nabwa_isize_t);
+	if (!out || cap < need) return need;
+	uint8_t *p = out;
+	for (const auto &kv : t->rg) {
+		memcpy(p, kv.first.c_str(), kv.first.size() + 1); p += kv.first.size() + 1;
+		memset(p, 0, 8); p += 8;
+		memcpy(p, &kv.second.ii, sizeof(nabwa_isize_t)); p += sizeof(nabwa_isize_t);
+	}
+	return need;
+}
+extern "C" int nabwa_isize_table_decode(nabwa_isize_table_t *t, const uint8_t *in, int64_t n)
+{
+	if (!t || (n && !in)) return nabwa_fail(NABWA_EINVAL, "null argument");
+	const uint8_t *p = in, *q = in + n;
+	while (p < q) {
+		const size_t l = strnlen((const char*)p, (size_t)(q - p));
+		if (p + l + 1 + 8 + sizeof(nabwa_isize_t) > q) return nabwa_fail(NABWA_EINVAL, "error when decoding isize info");
+		nabwa_isize_table::Rg r; r.has_hist = false;
+		memcpy(&r.ii, p + l + 1 + 8, sizeof(nabwa_isize_t));
+		t->rg[std::string((const char*)p, l)] = r;
+		p += l + 1 + 8 + sizeof(nabwa_isize_t);
+	}
+	return NABWA_OK;
+}
+
+/* ------------------------------------------------------------------ BAM records */
+
+struct BamRec {                    /* one record, parsed: offsets are into `data` (everything after the 32 bytes of core) */
+	int32_t tid, pos; uint32_t bin, mapq, l_qname, flag, n_cigar; int32_t l_qseq, mtid, mpos, isize;
+	std::vector<uint8_t> data;     /* qname, cigar, seq, qual, tags */
+	size_t off_cigar() const { return l_qname; }
+	size_t off_seq() const { return l_qname + 4 * (size_t)n_cigar; }
+	size_t off_qual() const { return off_seq() + ((size_t)l_qseq + 1) / 2; }
+	size_t off_aux() const { return off_qual() + (size_t)l_qseq; }
+};
+
+static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r)
+{
+	if (len < 36) return false;
+	uint32_t bs; memcpy(&bs, p, 4);
+	if ((int64_t)bs + 4 != len || bs < 32) return false;
+	uint32_t y, z;
+	memcpy(&r.tid, p + 4, 4); memcpy(&r.pos, p + 8, 4); memcpy(&y, p + 12, 4); memcpy(&z, p + 16, 4);
+	memcpy(&r.l_qseq, p + 20, 4); memcpy(&r.mtid, p + 24, 4); memcpy(&r.mpos, p + 28, 4); memcpy(&r.isize, p + 32, 4);
+	r.bin = y >> 16; r.mapq = y >> 8 & 0xff; r.l_qname = y & 0xff; r.flag = z >> 16; r.n_cigar = z & 0xffff;
+	r.data.assign(p + 36, p + len);
+	if (r.l_qseq < 0 || r.off_aux() > r.data.size() || r.l_qname == 0) return false;
+	return true;
+}
+
+/* erase_unwanted_tags (bwaseqio.c:413-464): AM NM CM SM MD X0 X1 XA XC XG XM XN XO XT YQ go, everything else stays */
+static bool erase_tags(BamRec &r)
+{
+	size_t p = r.off_aux(), q = p; const size_t end = r.data.size();
+	uint8_t *d = r.data.data();
+	while (p < end) {
+		if (p + 3 > end) return false;
+		bool keep = true;
+		switch (d[p]) {
+			case 'A': case 'S': case 'C': case 'N': keep = d[p + 1] != 'M'; break;
+			case 'M': keep = d[p + 1] != 'D'; break;
+			case 'X': keep = !(d[p + 1] && strchr("01ACGMNOT", d[p + 1])); break;
+			case 'Y': keep = d[p + 1] != 'Q'; break;
+		}
+		size_t len = 3;
+		switch (d[p + 2] & ~32) {
+			case 'C': case 'A': len += 1; break;
+			case 'S': len += 2; break;
+			case 'I': case 'F': len += 4; break;
+			case 'D': len += 8; break;
+			case 'Z': case 'H': while (p + len < end && d[p + len]) ++len; ++len; break;
+			case 'B': {
+				if (p + 8 > end) return false;
+				const size_t count = (size_t)d[p + 4] | (size_t)d[p + 5] << 8 | (size_t)d[p + 6] << 16 | (size_t)d[p + 7] << 24;
+				len += 5;
+				switch (d[p + 3] & ~32) { case 'C': case 'A': len += count; break; case 'S': len += 2 * count; break;
+										  case 'I': case 'F': len += 4 * count; break; case 'D': len += 8 * count; break; }
+				break;
+			}
+		}
+		if (p + len > end) return false;
+		if (keep) { memmove(d + q, d + p, len); q += len; }
+		p += len;
+	}
+	r.data.resize(q);
+	return true;
+}
+
+/* bam_get_rg (bamlite.c:157-190): the read group of a record, "" when it has none */
+static std::string get_rg(const BamRec &r)
+{
+	size_t p = r.off_aux(); const size_t end = r.data.size(); const uint8_t *d = r.data.data();
+	while (p + 4 < end) {
+		if (d[p] == 'R' && d[p + 1] == 'G') {
+			if (d[p + 2] == 'Z') return std::string((const char*)d + p + 3, strnlen((const char*)d + p + 3, end - p - 3));
+			if (d[p + 2] == 'A') return std::string(1, (char)d[p + 3]);
+		}
+		switch (d[p + 2]) {
+			case 'A': case 'C': case 'c': p += 4; break;
+			case 'S': case 's': p += 5; break;
+			case 'I': case 'i': case 'f': p += 7; break;
+			case 'd': p += 11; break;
+			case 'Z': case 'H': p += 3; while (p < end && d[p]) ++p; ++p; break;
+			case 'B': {
+				if (p + 8 > end) return "";
+				const size_t count = (size_t)d[p + 4] | (size_t)d[p + 5] << 8 | (size_t)d[p + 6] << 16 | (size_t)d[p + 7] << 24;
+				size_t w = 1; switch (d[p + 3]) { case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; case 'd': w = 8; break; }
+				p += 8 + w * count; break;
+			}
+			default: return "";
+		}
+	}
+	return "";
+}
+
+static inline int nib4(uint8_t v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }   /* complement of a 4-bit base code = its bits reversed */
+
+/* revcom_bam1 (bam2bam.c:335-362): flip the strand flag, reverse-complement SEQ, reverse QUAL */
+static void revcom_rec(BamRec &r)
+{
+	r.flag ^= F_SR;
+	const int L = r.l_qseq;
+	uint8_t *s = r.data.data() + r.off_seq(), *q = r.data.data() + r.off_qual();
+	std::vector<uint8_t> codes(L);
+	for (int i = 0; i < L; ++i) codes[i] = (uint8_t)(s[i >> 1] >> ((~i & 1) << 2) & 15);
+	memset(s, 0, ((size_t)L + 1) / 2);
+	for (int i = 0; i < L; ++i) s[i >> 1] |= (uint8_t)(nib4(codes[L - 1 - i]) << ((~i & 1) << 2));
+	for (int a = 0, b = L - 1; a < b; ++a, --b) { const uint8_t t = q[a]; q[a] = q[b]; q[b] = t; }
+}
+
+static inline uint32_t reg2bin(uint32_t beg, uint32_t end)      /* bam_reg2bin (bam2bam.c:324-333) */
+{
+	--end;
+	if (beg >> 14 == end >> 14) return 4681 + (beg >> 14);
+	if (beg >> 17 == end >> 17) return 585 + (beg >> 17);
+	if (beg >> 20 == end >> 20) return 73 + (beg >> 20);
+	if (beg >> 23 == end >> 23) return 9 + (beg >> 23);
+	if (beg >> 26 == end >> 26) return 1 + (beg >> 26);
+	return 0;
+}
+
+static void push_int(BamRec &r, char u, char v, int x) { const uint8_t b[7] = { (uint8_t)u, (uint8_t)v, 'i', (uint8_t)x, (uint8_t)(x >> 8), (uint8_t)(x >> 16), (uint8_t)(x >> 24) }; r.data.insert(r.data.end(), b, b + 7); }
+static void push_char(BamRec &r, char u, char v, char c) { const uint8_t b[4] = { (uint8_t)u, (uint8_t)v, 'A', (uint8_t)c }; r.data.insert(r.data.end(), b, b + 4); }
+static void push_str(BamRec &r, char u, char v, const char *s) { const uint8_t b[3] = { (uint8_t)u, (uint8_t)v, 'Z' }; r.data.insert(r.data.end(), b, b + 3); r.data.insert(r.data.end(), (const uint8_t*)s, (const uint8_t*)s + strlen(s) + 1); }
+
+static void set_cigar(BamRec &r, int n, const uint32_t *c)       /* bam_resize_cigar + the copy (bam2bam.c:411-420,467-477) */
+{
+	const size_t at = r.off_cigar();
+	std::vector<uint8_t> nc(4 * (size_t)n);
+	if (n) memcpy(nc.data(), c, 4 * (size_t)n);
+	r.data.erase(r.data.begin() + at, r.data.begin() + at + 4 * (size_t)r.n_cigar);
+	r.data.insert(r.data.begin() + at, nc.begin(), nc.end());
+	r.n_cigar = (uint32_t)n;
+}
+
+/* bwa_update_bam1 (bam2bam.c:430-593).  p: this end's finished record; mate: the other end's (null for a singleton); pe: this
+ * end's pair fields.  p / mate are in the state nabwa_se_refine / nabwa_pe_finish leave them in, i.e. with the side effects the
+ * reference's calls have on them (an unmapped end takes its mate's place, a contig-bridging hit loses its mapQ) already applied. */
+static void update_bam(BamRec &out, const nabwa_reference *R, const nabwa_se_t &p, const nabwa_se_t *mate, const nabwa_pe_t *pe,
+					   int mode, int max_top2)
+{
+	if (p.clip_len < p.full_len) push_int(out, 'X', 'C', p.clip_len);
+	if (p.type != 0 || (mate && mate->type != 0)) {
+		if ((p.strand != 0) != ((out.flag & F_SR) != 0)) revcom_rec(out);
+		out.flag &= ~(uint32_t)(F_PP | F_SU | F_MU | F_SC | F_MR);
+		const int fl = p.flag;                 /* what the chain derived: proper pair, self / mate unmapped, mate strand */
+		out.flag |= (uint32_t)(fl & (F_PP | F_SU | F_MU | F_MR));
+		const int seqid = p.seqid;
+		const int64_t off = R->anns[seqid].offset;
+		out.tid = seqid; out.pos = (int32_t)((int64_t)p.pos - off);
+		out.bin = reg2bin((uint32_t)((int64_t)p.pos - off), (uint32_t)(rec_pos_end(p) - off));
+		out.mapq = (uint32_t)p.mapQ & 0xff;
+		if (p.n_cigar) {
+			uint32_t c[NABWA_MAX_CIGAR];
+			for (int j = 0; j < p.n_cigar; ++j) c[j] = (uint32_t)CLEN(p.cigar[j]) << 4 | (uint32_t)"\000\001\002\004"[COP(p.cigar[j])];
+			set_cigar(out, p.n_cigar, c);
+		} else if (p.type == 0) set_cigar(out, 0, 0);
+		else { const uint32_t c = (uint32_t)p.len << 4; set_cigar(out, 1, &c); }
+		if (mate && mate->type != 0) { out.mtid = pe->m_seqid; out.mpos = (int32_t)(pe->m_rpos - 1); out.isize = (int32_t)pe->isize; }
+		else if (mate) { out.mtid = seqid; out.mpos = (int32_t)((int64_t)p.pos - off); out.isize = 0; }
+		else { out.mtid = -1; out.mpos = -1; out.isize = 0; }
+		if (p.type != 0) {
+			push_char(out, 'X', 'T', p.xt);
+			push_int(out, (mode & NABWA_MODE_COMPREAD) ? 'N' : 'C', 'M', p.nm);
+			if (p.nn) push_int(out, 'X', 'N', p.nn);
+			if (mate) { push_int(out, 'S', 'M', p.seQ); push_int(out, 'A', 'M', pe->am); }
+			if (p.type != 3) {                                     /* X0 / X1 do not exist for a mate-rescued alignment */
+				push_int(out, 'X', '0', (int)p.c1);
+				if ((int64_t)p.c1 <= (int64_t)max_top2) push_int(out, 'X', '1', (int)p.c2);
+			}
+			push_int(out, 'X', 'M', p.n_mm); push_int(out, 'X', 'O', p.n_gapo); push_int(out, 'X', 'G', p.n_gapo + p.n_gape);
+			push_str(out, 'M', 'D', p.md);
+			if (p.n_multi) {
+				std::string xa; char buf[128];
+				for (int i = 0; i < p.n_multi; ++i) {
+					const nabwa_multi_t &q = p.multi[i];
+					int64_t e = q.pos;
+					if (q.n_cigar) { for (int k = 0; k < q.n_cigar; ++k) { const int op = COP(q.cigar[k]); if (op == 0 || op == 2) e += CLEN(q.cigar[k]); } } else e += p.len;
+					int sid; pac2real(R, q.pos, (int)(e - q.pos), &sid);
+					snprintf(buf, sizeof buf, "%s,%c%d,", R->anns[sid].name.c_str(), q.strand ? '-' : '+', (int)((int64_t)q.pos - R->anns[sid].offset + 1)); xa += buf;
+					if (q.n_cigar) for (int k = 0; k < q.n_cigar; ++k) { snprintf(buf, sizeof buf, "%d%c", CLEN(q.cigar[k]), "MIDS"[COP(q.cigar[k])]); xa += buf; }
+					else { snprintf(buf, sizeof buf, "%dM", p.len); xa += buf; }
+					snprintf(buf, sizeof buf, ",%d;", q.gap + q.mm); xa += buf;
+				}
+				push_str(out, 'X', 'A', xa.c_str());
+			}
+		}
+	} else {                       /* neither this read nor its mate has a match */
+		out.tid = -1; out.pos = -1; out.bin = 0; out.mapq = 0; out.mtid = -1; out.mpos = -1; out.isize = 0;
+		out.flag &= ~(uint32_t)(F_PP | F_MU | F_SC);
+		out.flag |= F_SU;
+		if (mate && mate->type == 0) out.flag |= F_MU;
+		set_cigar(out, 0, 0);
+	}
+}
+
+static void write_rec(const BamRec &r, std::vector<uint8_t> &o)
+{
+	const uint32_t bs = 32 + (uint32_t)r.data.size();
+	const uint32_t y = r.bin << 16 | (r.mapq & 0xff) << 8 | (r.l_qname & 0xff), z = r.flag << 16 | (r.n_cigar & 0xffff);
+	uint8_t h[36];
+	memcpy(h, &bs, 4); memcpy(h + 4, &r.tid, 4); memcpy(h + 8, &r.pos, 4); memcpy(h + 12, &y, 4); memcpy(h + 16, &z, 4);
+	memcpy(h + 20, &r.l_qseq, 4); memcpy(h + 24, &r.mtid, 4); memcpy(h + 28, &r.mpos, 4); memcpy(h + 32, &r.isize, 4);
+	o.insert(o.end(), h, h + 36); o.insert(o.end(), r.data.begin(), r.data.end());
+}
+
+/* ------------------------------------------------------------------ the batch */
+
+struct nabwa_bam_batch {
+	nabwa_index *ix; nabwa_gap_opt_t opt; nabwa_pe_opt_t popt;
+	std::vector<BamRec> rec;                       /* in logical-record order: singletons, and pairs as read 1, read 2 */
+	std::vector<int> kind;                         /* per logical record: 1 or 2 */
+	std::vector<int> first;                        /* per logical record: index of its first read */
+	std::vector<std::string> rg;                   /* per logical record */
+	std::vector<int64_t> off; std::vector<uint8_t> seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
+	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
+	std::vector<nabwa_pe_t> res;                   /* per read: the chain's record (singletons use .se only) */
+	int phase;                                     /* 0 created, 1 positioned, 2 finished */
+};
+
+static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };      /* bam_nt16_nt4_table (bwaseqio.c:10) */
+
+extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
+									  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out)
+{
+	if (!ix || !opt || !popt || !out || n_rec < 0 || (n_rec && (!in || !in_off))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	nabwa_bam_batch *b = new nabwa_bam_batch();
+	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0;
+	b->rec.resize(n_rec);
+	for (int i = 0; i < n_rec; ++i)
+		if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i])) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
+	/* logical records (read_bam_pair_core, bwaseqio.c:346-410): a paired read takes the next record as its mate -- same name,
+	 * flags read 1 / read 2 in either order; anything else is the reference's "lone mate" error (no broken-input mode here) */
+	for (int i = 0; i < n_rec; ) {
+		if (b->rec[i].flag & F_PD) {
+			if (i + 1 >= n_rec) { delete b; return nabwa_fail(NABWA_EINVAL, "a paired read at the end of the batch without its mate (keep mates in one batch)"); }
+			BamRec &r0 = b->rec[i], &r1 = b->rec[i + 1];
+			const uint32_t f0 = r0.flag & (F_PD | F_R1 | F_R2), f1 = r1.flag & (F_PD | F_R1 | F_R2);
+			if (strcmp((const char*)r0.data.data(), (const char*)r1.data.data()) != 0) { delete b; return nabwa_fail(NABWA_EINVAL, "lone mate: two paired reads whose names do not match"); }
+			if (f0 == (F_PD | F_R2) && f1 == (F_PD | F_R1)) std::swap(r0, r1);
+			else if (!(f0 == (F_PD | F_R1) && f1 == (F_PD | F_R2))) { delete b; return nabwa_fail(NABWA_EINVAL, "a pair whose read 1 / read 2 flags are wrong"); }
+			r0.flag |= r1.flag & F_QC; r1.flag |= r0.flag & F_QC;          /* either none or both pass QC (bwaseqio.c:486-489) */
+			b->kind.push_back(2); b->first.push_back(i); i += 2;
+		} else { b->kind.push_back(1); b->first.push_back(i); i += 1; }
+	}
+	for (auto &r : b->rec) if (!erase_tags(r)) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed tags in a BAM record"); }
+	for (size_t k = 0; k < b->kind.size(); ++k) b->rg.push_back(get_rg(b->rec[b->first[k]]));
+	/* bam1_to_seq (bwaseqio.c:272-307) */
+	b->off.assign(n_rec + 1, 0); b->full_len.assign(n_rec ? n_rec : 1, 0);
+	std::vector<uint8_t> codes, quals, s, r;
+	for (int i = 0; i < n_rec; ++i) {
+		const BamRec &x = b->rec[i];
+		const int L = x.l_qseq;
+		codes.resize(L ? L : 1); quals.resize(L ? L : 1); s.resize(L ? L : 1); r.resize(L ? L : 1);
+		const uint8_t *sq = x.data.data() + x.off_seq(), *ql = x.data.data() + x.off_qual();
+		for (int j = 0; j < L; ++j) { codes[j] = nt16_nt4[sq[j >> 1] >> ((~j & 1) << 2) & 15]; quals[j] = ql[j] + 33 < 126 ? ql[j] : 93; }
+		const int len = nabwa_encode_read(L, codes.data(), quals.data(), (x.flag & F_SR) != 0, opt->trim_qual, 1, s.data(), r.data());
+		b->seq.insert(b->seq.end(), s.begin(), s.begin() + len); b->rseq.insert(b->rseq.end(), r.begin(), r.begin() + len);
+		b->off[i + 1] = b->off[i] + len; b->full_len[i] = L;
+	}
+	b->seq.push_back(0); b->rseq.push_back(0);
+	*out = b;
+	return NABWA_OK;
+}
+
+extern "C" void nabwa_bam_batch_destroy(nabwa_bam_batch_t *b) { delete b; }
+
+/* pass 1: pair_aln + pair_posn + improve_isize_est of every logical record (bam2bam.c:1143-1176) */
+extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab)
+{
+	if (!b || !rng48 || !tab) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (b->phase != 0) return nabwa_fail(NABWA_EINVAL, "pass 1 already ran on this batch");
+	const int n = (int)b->rec.size();
+	b->n_aln.assign(n ? n : 1, 0); b->max_ent.assign(n ? n : 1, 0); b->row0.assign(n + 1, 0);
+	/* bwa_cal_sa_reg_gap, one read per call in the reference (bam2bam.c:616,676) -> per_read = 1 */
+	int64_t n_rows = 0;
+	int rc;
+	{
+		nabwa_batch_t *sb = 0;
+		rc = nabwa_batch_create(b->ix, &b->opt, n, b->off.data(), b->seq.data(), b->rseq.data(), 1, &sb);
+		if (rc != NABWA_OK) return rc;
+		rc = nabwa_batch_run(sb);
+		if (rc == NABWA_OK) rc = nabwa_batch_sync(sb, 0);
+		if (rc == NABWA_OK) {
+			rc = nabwa_batch_fetch(sb, b->n_aln.data(), 0, 0, &n_rows, b->max_ent.data());
+			if (rc == NABWA_ECAP || rc == NABWA_OK) {
+				b->rows.resize(n_rows ? (size_t)n_rows : 1);
+				rc = n_rows ? nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data()) : NABWA_OK;
+			}
+		}
+		nabwa_batch_destroy(sb);
+		if (rc != NABWA_OK) return rc;
+	}
+	for (int i = 0; i < n; ++i) b->row0[i + 1] = b->row0[i] + b->n_aln[i];
+	/* posn_singleton / posn_pair in record order: singletons list up to max_occ_se other hits, ends of pairs none */
+	std::vector<uint8_t> n_occ(n ? n : 1, 0);
+	for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) n_occ[b->first[k]] = (uint8_t)b->popt.max_occ_se;
+	std::vector<nabwa_se_t> se(n ? n : 1);
+	rc = nabwa_se_posn_v(b->ix, &b->opt, n, b->off.data(), b->full_len.data(), b->n_aln.data(), b->rows.data(), n_occ.data(), rng48, se.data());
+	if (rc != NABWA_OK) return rc;
+	b->res.assign(n ? n : 1, nabwa_pe_t());
+	for (int i = 0; i < n; ++i) { memset(&b->res[i], 0, offsetof(nabwa_pe_t, se)); b->res[i].se = se[i]; b->res[i].extra_flag = 0; b->res[i].m_seqid = 0; b->res[i].am = 0; b->res[i].pad = 0; b->res[i].m_rpos = 0; b->res[i].isize = 0; }
+	/* improve_isize_est (insert_size.c:141-165) */
+	for (size_t k = 0; k < b->kind.size(); ++k) {
+		const int i = b->first[k];
+		const nabwa_se_t &s0 = b->res[i].se;
+		const nabwa_se_t &s1 = b->kind[k] == 2 ? b->res[i + 1].se : s0;
+		isize_add(tab, b->rg[k], nabwa_isize_bin(b->kind[k], s0.mapQ, s1.mapQ, s0.pos, s0.len, s1.pos, s1.len));
+	}
+	b->phase = 1;
+	return NABWA_OK;
+}
+
+/* pass 2: pair_finish of every logical record (bam2bam.c:1178-1216, 643-658, 705-811) */
+extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2])
+{
+	if (!b || !tab) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (b->phase != 1) return nabwa_fail(NABWA_EINVAL, "pass 2 needs a batch that went through pass 1 once");
+	const nabwa_reference *R = b->ix->ref;
+	/* ---- singletons: bwa_refine_gapped + what bwa_update_bam1 derives */
+	{
+		std::vector<int> idx;
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) idx.push_back(b->first[k]);
+		if (!idx.empty()) {
+			std::vector<int64_t> off(idx.size() + 1, 0); std::vector<uint8_t> sq, rq; std::vector<nabwa_se_t> se(idx.size());
+			for (size_t t = 0; t < idx.size(); ++t) {
+				const int i = idx[t]; const int64_t L = b->off[i + 1] - b->off[i];
+				sq.insert(sq.end(), b->seq.begin() + b->off[i], b->seq.begin() + b->off[i] + L);
+				rq.insert(rq.end(), b->rseq.begin() + b->off[i], b->rseq.begin() + b->off[i] + L);
+				off[t + 1] = off[t] + L; se[t] = b->res[i].se;
+			}
+			sq.push_back(0); rq.push_back(0);
+			int rc = nabwa_se_refine(b->ix, (int)idx.size(), off.data(), sq.data(), rq.data(), se.data());
+			if (rc != NABWA_OK) return rc;
+			for (size_t t = 0; t < idx.size(); ++t) b->res[idx[t]].se = se[t];
+		}
+	}
+	/* ---- pairs, one read group at a time with that group's estimate (pass 2 draws no random numbers: its order is free) */
+	{
+		std::map<std::string, std::vector<int>> groups;
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2) groups[b->rg[k]].push_back(b->first[k]);
+		for (auto &g : groups) {
+			nabwa_isize_t ii;
+			nabwa_isize_table_get(tab, g.first.c_str(), &ii);
+			const std::vector<int> &idx = g.second;
+			const int np = (int)idx.size();
+			std::vector<int64_t> off(2 * (size_t)np + 1, 0); std::vector<uint8_t> sq, rq; std::vector<nabwa_pe_t> pe(2 * (size_t)np);
+			std::vector<int32_t> na(2 * (size_t)np); std::vector<nabwa_aln1_t> rows;
+			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) {
+				const int i = idx[t] + e; const int64_t L = b->off[i + 1] - b->off[i];
+				sq.insert(sq.end(), b->seq.begin() + b->off[i], b->seq.begin() + b->off[i] + L);
+				rq.insert(rq.end(), b->rseq.begin() + b->off[i], b->rseq.begin() + b->off[i] + L);
+				off[2 * t + e + 1] = off[2 * t + e] + L; pe[2 * t + e] = b->res[i]; na[2 * t + e] = b->n_aln[i];
+				rows.insert(rows.end(), b->rows.begin() + b->row0[i], b->rows.begin() + b->row0[i + 1]);
+			}
+			sq.push_back(0); rq.push_back(0); rows.push_back(nabwa_aln1_t());
+			int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows.data(), pe.data(), n_tot, n_mapped);
+			if (rc != NABWA_OK) return rc;
+			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) b->res[idx[t] + e] = pe[2 * t + e];
+		}
+	}
+	/* ---- bwa_update_bam1 */
+	for (size_t k = 0; k < b->kind.size(); ++k) {
+		const int i = b->first[k];
+		if (b->kind[k] == 1) update_bam(b->rec[i], R, b->res[i].se, 0, 0, b->opt.mode, b->opt.max_top2);
+		else {
+			update_bam(b->rec[i], R, b->res[i].se, &b->res[i + 1].se, &b->res[i], b->opt.mode, b->opt.max_top2);
+			update_bam(b->rec[i + 1], R, b->res[i + 1].se, &b->res[i].se, &b->res[i + 1], b->opt.mode, b->opt.max_top2);
+		}
+	}
+	b->phase = 2;
+	return NABWA_OK;
+}
+
+/* the records as they now are (after create: cleaned; after pass 2: aligned), in logical-record order */
+extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes)
+{
+	if (!b || !n_bytes) return nabwa_fail(NABWA_EINVAL, "null argument");
+	std::vector<uint8_t> o;
+	int64_t at = 0;
+	for (size_t i = 0; i < b->rec.size(); ++i) {
+		const size_t before = o.size();
+		write_rec(b->rec[i], o);
+		if (out_off) out_off[i] = at;
+		at += (int64_t)(o.size() - before);
+	}
+	if (out_off) out_off[b->rec.size()] = at;
+	*n_bytes = at;
+	if (!out || cap < at) return nabwa_fail(NABWA_ECAP, "output buffer too small");
+	if (at) memcpy(out, o.data(), (size_t)at);
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_bam_batch_counts(const nabwa_bam_batch_t *b, int *n_records, int *n_logical)
+{
+	if (!b) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (n_records) *n_records = (int)b->rec.size();
+	if (n_logical) *n_logical = (int)b->kind.size();
+	return NABWA_OK;
+}

@@ -305,6 +305,24 @@ extern "C" int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefi
 	return NABWA_OK;
 }
 
+/* The same from memory: one or more contigs (names, offsets, lengths), ambiguity holes, the packed bases (.pac layout: 4 per
+ * byte, first base in the top bits).  bench.py attaches its synthetic genome this way. */
+extern "C" int nabwa_index_set_reference(nabwa_index_t *ix, int64_t l_pac, uint32_t seed, int n_seqs, const char *const *names,
+										  const int64_t *offsets, const int32_t *lens, int n_holes, const int64_t *hole_off,
+										  const int32_t *hole_len, const char *hole_amb, const uint8_t *pac)
+{
+	if (!ix || l_pac < 0 || n_seqs < 1 || !offsets || !lens || !pac || (n_holes && (!hole_off || !hole_len || !hole_amb))) return nabwa_fail(NABWA_EINVAL, "bad argument");
+	nabwa_reference *R = new nabwa_reference();
+	R->l_pac = l_pac; R->seed = seed;
+	for (int i = 0; i < n_seqs; ++i) { nabwa_ann a; a.offset = offsets[i]; a.len = lens[i]; a.n_ambs = 0; a.name = names && names[i] ? names[i] : "seq"; R->anns.push_back(a); }
+	for (int i = 0; i < n_holes; ++i) { nabwa_hole h; h.offset = hole_off[i]; h.len = hole_len[i]; h.amb = hole_amb[i]; R->holes.push_back(h); }
+	R->pac.assign(pac, pac + (l_pac + 3) / 4);
+	R->pac.resize(R->pac.size() + 8);
+	delete ix->ref;
+	ix->ref = R;
+	return NABWA_OK;
+}
+
 /* ------------------------------------------------------------------ the chain */
 
 /* host threads of the finishing chains: slices of independent records */
@@ -325,11 +343,30 @@ static void in_threads(int nt, size_t count, const std::function<void(size_t, si
 
 /* posn_singleton (bam2bam.c:622-641) for n reads in record order: bwa_aln2seq_core with the caller's drand48 stream, all
  * bwt_sa walks of the batch (main hits and multi hits) as one GPU batch, bwa_approx_mapQ */
+static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out);
+
 extern "C" int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
 							 const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, uint64_t *rng48, nabwa_se_t *out)
 {
+	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, n_occ, 0, rng48, out);
+}
+
+/* the same with a bound per read: a file that mixes singletons (max_occ_se other hits listed, bam2bam.c:629) and ends of pairs
+ * (none, bam2bam.c:692-694) is still ONE drand48 stream in record order */
+extern "C" int nabwa_se_posn_v(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+							   const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out)
+{
+	if (n && !n_occ_v) return nabwa_fail(NABWA_EINVAL, "null argument");
+	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, 0, n_occ_v, rng48, out);
+}
+
+static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out)
+{
 	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (n_occ < 0 || n_occ + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
+	if (n_occ_v) for (int i = 0; i < n; ++i) if (n_occ_v[i] + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
 	const uint32_t rlen = ix->bwt[1].seq_len;
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -349,7 +386,7 @@ extern "C" int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int 
 		a0 += na;
 		if (na == 0) continue;
 		choose_main(s, na, A, rng48);
-		list_multi(s, na, A, n_occ);
+		list_multi(s, na, A, n_occ_v ? (int)n_occ_v[i] : n_occ);
 		which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look_rec.push_back(i); look_multi.push_back(-1);
 		for (int j = 0; j < s.n_multi; ++j) {
 			which.push_back(s.multi[j].strand ? 0 : 1); rows.push_back(s.multi[j].pos); look_rec.push_back(i); look_multi.push_back(j);
