@@ -207,6 +207,10 @@ typedef struct {
 /* Annotation side of the index (replaces bns_restore + bwt_restore_pac, bntseq.c:88-148): <prefix>.ann,
  * .amb and .pac are read into host memory and attached to the index. */
 int nabwa_index_attach_reference(nabwa_index_t *ix, const char *prefix);
+/* what bns_restore read (bntseq.c:88-139): contigs (name, offset in the concatenated reference, length), total length, srand48 seed */
+int nabwa_index_n_contigs(const nabwa_index_t *ix);
+int nabwa_index_contig(const nabwa_index_t *ix, int i, char *name, int name_cap, int64_t *offset, int32_t *len);
+int nabwa_index_reference_info(const nabwa_index_t *ix, int64_t *l_pac, uint32_t *seed);
 /* the same from memory (bntseq_t: contigs with offsets and lengths, bntamb1_t holes, the .pac bytes) */
 int nabwa_index_set_reference(nabwa_index_t *ix, int64_t l_pac, uint32_t seed, int n_seqs, const char *const *names,
 							  const int64_t *offsets, const int32_t *lens, int n_holes, const int64_t *hole_off,

@@ -1,0 +1,268 @@
+// bam2bam_main.cpp -- `nabwa_bam2bam`: the command line of `bwa bam2bam -t 1` (bam2bam.c:1942-2098) on top of libnabwa.so.
+//
+//     nabwa_bam2bam -g PREFIX [alignment options of bwa bam2bam] [-f out.bam] in.bam
+//
+// BAM in (BGZF or plain gzip, as the reference's bamlite reads it) -> both passes of the reference's sequential loop
+// (bam2bam.c:1143-1216) through the batch front-end of the library (nabwa_bam_batch_*, bam_batch.hip) -> BGZF BAM out with
+// the header bwa_print_bam_header writes (@HD VN:1.4, a new @PG chained to the old one, @SQ from the .ann file, the other old
+// lines kept; bam2bam.c:164-301).  Host code only; the GPU work is the library's.  Not provided: the 0MQ master / worker modes
+// (-p, `bwa worker`: libzmq is absent from the build image), resuming from .sai files (-0 -1 -2), --only-aligned,
+// --drop-aligned, --skip-duplicates, --broken-input, --debug-bam -- each is refused, none is silently ignored.
+// -t is accepted and ignored (one GPU; NABWA_DEVICE picks it), --temp-dir likewise (the records wait in memory between the passes).
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/nabwa.h"
+
+static const char *VERSION = "0.5.10-evan.6.3+nabwa";
+
+static void die(const char *what, const char *why) { fprintf(stderr, "[nabwa_bam2bam] %s: %s\n", what, why); exit(1); }
+
+/* ---------------------------------------------------------------- BGZF out (bgzf.c: blocks of <= 0xff00 input bytes, level 2) */
+static void bgzf_block(const uint8_t *in, size_t n, int level, std::vector<uint8_t> &out)
+{
+	uint8_t buf[0x10000 + 64];
+	z_stream zs; memset(&zs, 0, sizeof(zs));
+	zs.next_in = (Bytef*)in; zs.avail_in = (uInt)n; zs.next_out = buf + 18; zs.avail_out = sizeof(buf) - 18 - 8;
+	if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK || deflate(&zs, Z_FINISH) != Z_STREAM_END) die("BGZF", "deflate failed");
+	const size_t clen = zs.total_out; deflateEnd(&zs);
+	static const uint8_t hdr[16] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0 };
+	memcpy(buf, hdr, 16);
+	const uint16_t bsize = (uint16_t)(clen + 25);
+	buf[16] = (uint8_t)bsize; buf[17] = (uint8_t)(bsize >> 8);
+	const uint32_t crc = (uint32_t)crc32(crc32(0, 0, 0), in, (uInt)n), isz = (uint32_t)n;
+	uint8_t *t = buf + 18 + clen;
+	memcpy(t, &crc, 4); memcpy(t + 4, &isz, 4);
+	out.insert(out.end(), buf, buf + 18 + clen + 8);
+}
+
+struct BgzfOut {
+	FILE *f; std::vector<uint8_t> pend; int level;
+	void write(const void *p, size_t n) { const uint8_t *b = (const uint8_t*)p; pend.insert(pend.end(), b, b + n); if (pend.size() >= (64u << 20)) flush(false); }
+	void flush(bool all)
+	{
+		const size_t BS = 0xff00;
+		const size_t n_full = pend.size() / BS, n_blocks = all ? (pend.size() + BS - 1) / BS : n_full;
+		if (!n_blocks) return;
+		int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+		if ((size_t)nt > n_blocks) nt = (int)n_blocks;
+		std::vector<std::vector<uint8_t>> parts(nt);
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() {
+			for (size_t k = n_blocks * t / nt; k < n_blocks * (t + 1) / nt; ++k) {
+				const size_t o = k * BS, m = pend.size() - o < BS ? pend.size() - o : BS;
+				bgzf_block(pend.data() + o, m, level, parts[t]);
+			}
+		});
+		for (auto &x : th) x.join();
+		for (auto &p : parts) if (!p.empty() && fwrite(p.data(), 1, p.size(), f) != p.size()) die("output", "write failed");
+		const size_t done = n_blocks * BS < pend.size() ? n_blocks * BS : pend.size();
+		pend.erase(pend.begin(), pend.begin() + done);
+	}
+	void close()
+	{
+		flush(true);
+		static const uint8_t eof[28] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+		if (fwrite(eof, 1, 28, f) != 28 || fflush(f) != 0) die("output", "write failed");
+		if (f != stdout) fclose(f);
+	}
+};
+
+/* ---------------------------------------------------------------- the header (bam2bam.c:164-301) */
+static void find_pp_tag(const std::string &h, std::string &pp, std::string &id, bool &has_pp)
+{
+	std::set<std::string> present, linked;
+	size_t p = 0;
+	while (p < h.size()) {
+		size_t e = h.find('\n', p); if (e == std::string::npos) e = h.size();
+		if (h.compare(p, 3, "@PG") == 0) {
+			size_t q = p;
+			while (q < e) {
+				size_t fe = h.find('\t', q); if (fe == std::string::npos || fe > e) fe = e;
+				if (fe - q > 3 && h[q + 2] == ':' && ((h[q] == 'I' && h[q + 1] == 'D') || (h[q] == 'P' && h[q + 1] == 'P')))
+					(h[q] == 'I' ? present : linked).insert(h.substr(q + 3, fe - q - 3));
+				q = fe + 1;
+			}
+		}
+		p = e + 1;
+	}
+	has_pp = false;
+	for (const auto &x : present) if (!linked.count(x)) { pp = x; has_pp = true; break; }
+	id = "bwa";
+	for (int n = 1; present.count(id); ++n) id = "bwa-" + std::to_string(n);
+}
+
+static std::string header_text(nabwa_index_t *ix, const std::string &old, int argc, char **argv)
+{
+	std::string pp, id; bool has_pp;
+	find_pp_tag(old, pp, id, has_pp);
+	std::string t = "@HD\tVN:1.4\n@PG\tID:" + id + (has_pp ? "\tPP:" + pp : "") + "\tPN:bwa\tVN:" + VERSION + (argc ? "\tCL:" : "");
+	for (int i = 0; i < argc; ++i) { t += argv[i]; t += i == argc - 1 ? '\n' : ' '; }
+	const int ns = nabwa_index_n_contigs(ix);
+	for (int i = 0; i < ns; ++i) { char name[1024]; int64_t off; int32_t len; nabwa_index_contig(ix, i, name, sizeof name, &off, &len); t += std::string("@SQ\tSN:") + name + "\tLN:" + std::to_string(len) + "\n"; }
+	size_t p = 0;
+	while (p < old.size() && old[p]) {
+		size_t e = old.find('\n', p); if (e == std::string::npos) e = old.size();
+		const bool boring = e - p >= 3 && old[p] == '@' && ((old[p + 1] == 'S' && old[p + 2] == 'Q') || (old[p + 1] == 'H' && old[p + 2] == 'D'));
+		if (!boring) { t.append(old, p, e - p); t += '\n'; }
+		p = e + 1;
+	}
+	return t;
+}
+
+int main(int argc, char **argv)
+{
+	static struct option longopts[] = {
+		{ "num-diff", 1, 0, 'n' }, { "max-gap-open", 1, 0, 'o' }, { "max-gap-extensions", 1, 0, 'e' }, { "indel-near-end", 1, 0, 'i' },
+		{ "deletion-occurences", 1, 0, 'd' }, { "seed-length", 1, 0, 'l' }, { "seed-mismatches", 1, 0, 'k' }, { "queue-size", 1, 0, 'm' },
+		{ "num-threads", 1, 0, 't' }, { "mismatch-penalty", 1, 0, 'M' }, { "gap-open-penalty", 1, 0, 'O' }, { "gap-extension-penalty", 1, 0, 'E' },
+		{ "max-best-hits", 1, 0, 'R' }, { "trim-quality", 1, 0, 'q' }, { "log-gap-penalty", 0, 0, 'L' }, { "non-iterative", 0, 0, 'N' },
+		{ "output", 1, 0, 'f' }, { "genome", 1, 0, 'g' }, { "only-aligned", 0, 0, 128 }, { "drop-aligned", 0, 0, 133 }, { "debug-bam", 0, 0, 129 },
+		{ "broken-input", 0, 0, 130 }, { "skip-duplicates", 0, 0, 131 }, { "temp-dir", 1, 0, 132 }, { "max-insert-size", 1, 0, 'a' },
+		{ "max-occurences", 1, 0, 'C' }, { "max-occurences-se", 1, 0, 'D' }, { "max-hits", 1, 0, 'h' }, { "max-discordant-hits", 1, 0, 'H' },
+		{ "chimeric-rate", 1, 0, 'c' }, { "disable-sw", 0, 0, 's' }, { "disable-isize-estimate", 0, 0, 'A' }, { "listen-port", 1, 0, 'p' }, { 0, 0, 0, 0 } };
+	nabwa_gap_opt_t go; nabwa_gap_init_opt(&go);
+	nabwa_pe_opt_t po; nabwa_pe_opt_default(&po);
+	const char *prefix = 0, *ofile = 0; int c, opte = -1;
+	while ((c = getopt_long(argc, argv, "g:n:o:e:i:d:l:k:LR:m:t:NM:O:E:q:f:C:D:a:sc:h:H:Ap:0:1:2:", longopts, 0)) >= 0) {
+		switch (c) {
+			case 'g': prefix = optarg; break;
+			case 'n': if (strstr(optarg, ".")) { go.fnr = (float)atof(optarg); go.max_diff = -1; } else { go.max_diff = atoi(optarg); go.fnr = -1.0f; } break;
+			case 'o': go.max_gapo = atoi(optarg); break;
+			case 'e': opte = atoi(optarg); break;
+			case 'M': go.s_mm = atoi(optarg); break;
+			case 'O': go.s_gapo = atoi(optarg); break;
+			case 'E': go.s_gape = atoi(optarg); break;
+			case 'd': go.max_del_occ = atoi(optarg); break;
+			case 'i': go.indel_end_skip = atoi(optarg); break;
+			case 'l': go.seed_len = atoi(optarg); break;
+			case 'k': go.max_seed_diff = atoi(optarg); break;
+			case 'm': go.max_entries = atoi(optarg); break;
+			case 't': go.n_threads = atoi(optarg); break;
+			case 'L': go.mode |= NABWA_MODE_LOGGAP; break;
+			case 'R': go.max_top2 = atoi(optarg); break;
+			case 'q': go.trim_qual = atoi(optarg); break;
+			case 'N': go.mode |= NABWA_MODE_NONSTOP; go.max_top2 = 0x7fffffff; break;
+			case 'f': ofile = optarg; break;
+			case 'C': po.max_occ = atoi(optarg); break;
+			case 'D': po.max_occ_se = atoi(optarg); break;
+			case 'a': po.max_isize = atoi(optarg); break;
+			case 's': po.is_sw = 0; break;
+			case 'c': po.ap_prior = atof(optarg); break;
+			case 'A': po.force_isize = 1; break;
+			case 'h': po.n_multi = atoi(optarg); break;
+			case 'H': po.N_multi = atoi(optarg); break;
+			case 132: break;
+			case 'p': case '0': case '1': case '2': case 128: case 129: case 130: case 131: case 133:
+				fprintf(stderr, "[nabwa_bam2bam] this option of bwa bam2bam is not provided (0MQ modes, .sai resume, --only-aligned, --drop-aligned, --debug-bam, --broken-input, --skip-duplicates)\n");
+				return 1;
+			default: return 1;
+		}
+	}
+	if (opte > 0) { go.max_gape = opte; go.mode &= ~NABWA_MODE_GAPE; }
+	if (optind + 1 > argc || !prefix) {
+		fprintf(stderr, "\nUsage:   nabwa_bam2bam -g PREFIX [options of bwa bam2bam] [-f out.bam] <in.bam>\n\n");
+		return 1;
+	}
+	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;
+	nabwa_index_t *ix = 0;
+	if (nabwa_index_load(prefix, device, 1, 1, &ix) != NABWA_OK) die("genome index", nabwa_last_error());
+	int64_t genome_len = 0; uint32_t seed = 0;
+	nabwa_index_reference_info(ix, &genome_len, &seed);
+	fprintf(stderr, "[nabwa_bam2bam] genome length is %ld\n", (long)genome_len);
+
+	/* ---- input: magic, header text, reference list (bamlite.c: bam_header_read) */
+	gzFile in = strcmp(argv[optind], "-") ? gzopen(argv[optind], "r") : gzdopen(0, "r");
+	if (!in) die(argv[optind], "cannot open");
+	gzbuffer(in, 1 << 20);
+	auto rd = [&](void *p, size_t n) -> bool { return gzread(in, p, (unsigned)n) == (int)n; };
+	char magic[4]; int32_t l_text = 0, n_ref = 0;
+	if (!rd(magic, 4) || memcmp(magic, "BAM\1", 4) || !rd(&l_text, 4) || l_text < 0) die(argv[optind], "not a BAM file");
+	std::string old(l_text, '\0');
+	if (l_text && !rd(&old[0], l_text)) die(argv[optind], "truncated header");
+	old.resize(strlen(old.c_str()));
+	if (!rd(&n_ref, 4)) die(argv[optind], "truncated header");
+	for (int i = 0; i < n_ref; ++i) { int32_t ln, tl; if (!rd(&ln, 4)) die(argv[optind], "truncated header"); std::vector<char> nm(ln); if (!rd(nm.data(), ln) || !rd(&tl, 4)) die(argv[optind], "truncated header"); }
+
+	FILE *of = ofile ? fopen(ofile, "wb") : stdout;
+	if (!of) die(ofile, "cannot create");
+	BgzfOut out{ of, {}, 2 };
+	{
+		const std::string text = header_text(ix, old, argc, argv);
+		const int32_t hl = (int32_t)text.size(), ns = nabwa_index_n_contigs(ix);
+		out.write("BAM\1", 4); out.write(&hl, 4); out.write(text.data(), text.size()); out.write(&ns, 4);
+		for (int i = 0; i < ns; ++i) { char name[1024]; int64_t off; int32_t len; nabwa_index_contig(ix, i, name, sizeof name, &off, &len); const int32_t nl = (int32_t)strlen(name) + 1; out.write(&nl, 4); out.write(name, nl); out.write(&len, 4); }
+	}
+
+	/* ---- pass 1 over batches of records (mates stay together); single-end batches are finished and written at once */
+	nabwa_isize_table_t *tab = nabwa_isize_table_create(po.ap_prior, genome_len);
+	uint64_t rng = ((uint64_t)seed << 16) | 0x330E;            /* srand48(bns->seed), bam2bam.c:1745 */
+	const long BATCH = getenv("NABWA_BAM_BATCH") ? atol(getenv("NABWA_BAM_BATCH")) : (1L << 20);
+	std::vector<nabwa_bam_batch_t*> waiting;
+	uint64_t n_tot[2] = { 0, 0 }, n_mapped[2] = { 0, 0 };
+	long tot_seqs = 0; bool any_pairs = false;
+	auto emit = [&](nabwa_bam_batch_t *b) {
+		int64_t nb = 0;
+		nabwa_bam_batch_output(b, 0, 0, 0, &nb);
+		std::vector<uint8_t> o((size_t)(nb ? nb : 1));
+		if (nabwa_bam_batch_output(b, o.data(), nb, 0, &nb) != NABWA_OK) die("output", nabwa_last_error());
+		out.write(o.data(), (size_t)nb);
+		nabwa_bam_batch_destroy(b);
+	};
+	std::vector<uint8_t> buf; std::vector<int64_t> off(1, 0);
+	bool hold_mate = false;
+	auto flush = [&]() {
+		const long n_rec = (long)off.size() - 1;
+		if (n_rec <= 0) return;
+		nabwa_bam_batch_t *b = 0;
+		if (nabwa_bam_batch_create(ix, &go, &po, (int)n_rec, buf.data(), off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
+		if (nabwa_bam_batch_pass1(b, &rng, tab) != NABWA_OK) die("pass 1", nabwa_last_error());
+		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
+		tot_seqs += nr;
+		fprintf(stderr, "[nabwa_bam2bam] pass 1: %ld sequences processed\n", tot_seqs);
+		/* a batch of singletons needs no insert-size estimate: it is finished now, and written now unless pairs came before it */
+		if (nr == nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
+		if (nr == nl && !any_pairs) emit(b); else waiting.push_back(b);
+		buf.clear(); off.assign(1, 0);
+	};
+	for (;;) {
+		uint32_t bs = 0;
+		const int r = gzread(in, &bs, 4);
+		if (r == 0) break;
+		if (r != 4 || bs < 32) die(argv[optind], "truncated record");
+		const size_t at = buf.size();
+		buf.resize(at + 4 + bs); memcpy(&buf[at], &bs, 4);
+		if (!rd(&buf[at + 4], bs)) die(argv[optind], "truncated record");
+		uint32_t z; memcpy(&z, &buf[at + 16], 4);
+		const bool paired = (z >> 16) & 1;
+		off.push_back((int64_t)buf.size());
+		hold_mate = paired ? !hold_mate : false;              /* a paired read waits for the record after it */
+		any_pairs |= paired;
+		if ((long)off.size() - 1 >= BATCH && !hold_mate) flush();
+	}
+	flush();
+	gzclose(in);
+	/* ---- the barrier (infer_all_isizes), then pass 2 in input order */
+	nabwa_isize_table_infer_all(tab);
+	for (nabwa_bam_batch_t *b : waiting) {
+		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
+		if (nr != nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
+		emit(b);
+	}
+	fprintf(stderr, "[nabwa_bam2bam] %ld sequences processed\n[nabwa_bam2bam] finished cleanly, shutting down.\n"
+			"[bwa_paired_sw] %lld out of %lld Q%d singletons are mated.\n[bwa_paired_sw] %lld out of %lld Q%d discordant pairs are fixed.\n",
+			tot_seqs, (long long)n_mapped[1], (long long)n_tot[1], 17, (long long)n_mapped[0], (long long)n_tot[0], 17);
+	out.close();
+	nabwa_isize_table_destroy(tab);
+	nabwa_index_destroy(ix);
+	/* final_rename (utils.c:159-173): "out.bam_" becomes "out.bam" once it is complete */
+	if (ofile) { const size_t l = strlen(ofile); if (l > 1 && ofile[l - 1] == '_') { std::string to(ofile, l - 1); if (rename(ofile, to.c_str()) != 0) die(ofile, "cannot rename"); } }
+	return 0;
+}

@@ -323,6 +323,24 @@ extern "C" int nabwa_index_set_reference(nabwa_index_t *ix, int64_t l_pac, uint3
 	return NABWA_OK;
 }
 
+extern "C" int nabwa_index_n_contigs(const nabwa_index_t *ix) { return ix && ix->ref ? (int)ix->ref->anns.size() : 0; }
+extern "C" int nabwa_index_contig(const nabwa_index_t *ix, int i, char *name, int name_cap, int64_t *offset, int32_t *len)
+{
+	if (!ix || !ix->ref || i < 0 || i >= (int)ix->ref->anns.size()) return nabwa_fail(NABWA_EINVAL, "no such contig");
+	const nabwa_ann &a = ix->ref->anns[i];
+	if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", a.name.c_str());
+	if (offset) *offset = a.offset;
+	if (len) *len = a.len;
+	return NABWA_OK;
+}
+extern "C" int nabwa_index_reference_info(const nabwa_index_t *ix, int64_t *l_pac, uint32_t *seed)
+{
+	if (!ix || !ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached");
+	if (l_pac) *l_pac = ix->ref->l_pac;
+	if (seed) *seed = ix->ref->seed;
+	return NABWA_OK;
+}
+
 /* ------------------------------------------------------------------ the chain */
 
 /* host threads of the finishing chains: slices of independent records */
