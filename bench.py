@@ -47,6 +47,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--adna", action="store_true", help="SURVEY 8d config C5 instead of the headline workload: reads of 50-76 bases with "
                     "terminal deamination (5' C>T, 3' G>A, 30 %% decaying by 0.7 per base) + 1 %% substitutions, searched with -n 0.01 -o 2 -l 16500")
+    ap.add_argument("--pe", action="store_true", help="BASELINE config 3 instead of the headline workload: 2 x 150 bp pairs at 2 %% substitutions, 10 %% of the reads with "
+                    "a 1-base indel, inserts ~ N(400, 40): FM search of both ends + posn_pair + insert-size estimate + finish_pair; value = pairs/s")
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("NABWA_BENCH_PAIRS", 1_000_000)))
+    ap.add_argument("--no-e2e", action="store_true", help="skip the BAM-records-in -> BAM-records-out leg of the headline run")
+    ap.add_argument("--e2e-reads", type=int, default=1_000_000)
     ap.add_argument("--pipeline", action="store_true", help="steps alternate between two device-resident batches on two streams (not the headline mode)")
     args = ap.parse_args()
 
@@ -83,13 +88,31 @@ def main():
     if rank == 0:
         log("index: %d bp x2 FM-indexes built on GPU + re-packed in %.1f s (%.2f GB in HBM)"
             % (n, time.time() - t0, ix.device_bytes() / 1e9))
-    host_bwt = None
+    host_bwt = host_sa = None
     want_cpu = rank == 0 and not args.no_cpu
     if want_cpu:
         host_bwt = [p[0].to_host(np.uint32, p[1]) for p in parts]
+    want_e2e = rank == 0 and not args.no_e2e and not args.adna and not quick_env()
+    if want_cpu and (args.pe or want_e2e):
+        host_sa = [p[2].to_host(np.uint32, p[3]) for p in parts]
     for p in parts:
         p[0].free()
         p[2].free()
+    pac = None
+    if args.pe or want_e2e:
+        # the finishing chains read the packed reference (.pac layout) and one contig's annotation from the host
+        pac = pack_text(d_text, n)
+        ix.set_reference(n, 11, pac)
+    if args.pe:
+        out = pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backend, host_bwt, host_sa, pac, want_cpu)
+        d_text.free()
+        ix.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
 
     # reads: this rank's shard (seeded by rank)
     if args.adna:
@@ -164,6 +187,9 @@ def main():
         elapsed = float(t.item())
     checksum, n_rows = batch.checksum()
 
+    e2e = None
+    if want_e2e:
+        e2e = e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, want_cpu)
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (fm_search, first pass): algorithmic bytes / event time
@@ -221,7 +247,7 @@ def main():
                           "bit_exact_vs_cpu_sample": bit_exact,
                           "pcie_inclusive_reads_per_s": round(n_pc / t_pcie, 1),
                           "pcie_inclusive_first_call_reads_per_s": round(n_pc / t_pcie_first, 1)},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e}
     for b in batches:
         b.close()
     ix.close()
@@ -230,6 +256,288 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def quick_env():
+    return os.environ.get("NABWA_BENCH_QUICK") == "1"
+
+
+def pack_text(d_text, n):
+    """the synthetic genome as .pac bytes (4 bases per byte, first base in the top bits; reference bwtaln.h:33)"""
+    t = d_text.to_host(np.uint8)[:n]
+    pad = (-n) % 4
+    if pad:
+        t = np.concatenate([t, np.zeros(pad, np.uint8)])
+    t = t.reshape(-1, 4)
+    return np.ascontiguousarray((t[:, 0] << 6) | (t[:, 1] << 4) | (t[:, 2] << 2) | t[:, 3]).astype(np.uint8)
+
+
+def ref_full_index(T, host_bwt, host_sa, pac, n):
+    """the compiled reference's index structures around the arrays the GPU builder made (oracle/ref_harness.c)"""
+    ref = T.load_ref()
+    if ref is None:
+        return None, None
+    ref.ref_index_wrap_full.restype = C.c_void_p
+    ref.ref_index_wrap_full.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_int]
+    rix = C.c_void_p(ref.ref_index_wrap_full(T.ptr(host_bwt[0]), len(host_bwt[0]), T.ptr(host_bwt[1]), len(host_bwt[1]),
+                                             T.ptr(host_sa[0]), T.ptr(host_sa[1]), T.ptr(pac), n, 11, 16))
+    return ref, rix
+
+
+def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, want_cpu):
+    """End to end on the first e2e_reads reads of the batch: unaligned BAM records in host memory -> the library's batch front-end
+    (record parsing, tag erase, bam1_to_seq, FM search, posn_singleton on the drand48 stream, bwt_sa batch, refinement, MD/NM,
+    bwa_update_bam1) -> aligned BAM records in host memory.  No BGZF on either side (the reference's bgzf.c is host I/O).
+    A sample is checked against the reference's own bwa_aln2seq_core / bwa_cal_pac_pos_core on the reference's search rows."""
+    import struct
+    n_e = min(args.e2e_reads, len(off) - 1)
+    L = args.read_len
+    rec_len = 36 + 10 + (L + 1) // 2 + L
+    rec = np.zeros((n_e, rec_len), np.uint8)
+    rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec_len - 4), np.uint8)
+    core = struct.pack("<iiIIiiii", -1, -1, (4680 << 16) | 10, 4 << 16, L, -1, -1, 0)
+    rec[:, 4:36] = np.frombuffer(core, np.uint8)
+    names = np.char.zfill(np.arange(n_e).astype("U8"), 8)
+    rec[:, 36] = ord("r")
+    rec[:, 37:45] = np.frombuffer("".join(names).encode(), np.uint8).reshape(n_e, 8)
+    fwd = seq[:n_e * L].reshape(n_e, L)[:, ::-1]                       # bwa_seq_t.seq is the read reversed
+    code16 = np.array([1, 2, 4, 8, 15], np.uint8)[fwd]
+    if L % 2:
+        code16 = np.concatenate([code16, np.zeros((n_e, 1), np.uint8)], axis=1)
+    rec[:, 46:46 + (L + 1) // 2] = (code16[:, 0::2] << 4) | code16[:, 1::2]
+    rec[:, 46 + (L + 1) // 2:] = 40
+    buf = np.ascontiguousarray(rec).reshape(-1)
+    boff = np.arange(n_e + 1, dtype=np.int64) * rec_len
+    Lb = nabwa.lib()
+    P = C.c_void_p
+    Lb.nabwa_isize_table_create.restype = P
+    Lb.nabwa_isize_table_create.argtypes = [C.c_double, C.c_int64]
+    Lb.nabwa_bam_batch_create.argtypes = [P, P, P, C.c_int, P, P, P]
+    Lb.nabwa_bam_batch_pass1.argtypes = [P, P, P]
+    Lb.nabwa_bam_batch_pass2.argtypes = [P, P, P, P]
+    Lb.nabwa_bam_batch_output.argtypes = [P, P, C.c_int64, P, P]
+    Lb.nabwa_bam_batch_destroy.argtypes = [P]
+    Lb.nabwa_isize_table_destroy.argtypes = [P]
+    po = nabwa.pe_opt_default()
+    tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
+    st = C.c_uint64(nabwa.srand48_state(11))
+    h = P()
+    t = [time.time()]
+    assert Lb.nabwa_bam_batch_create(ix._h, C.byref(opt), C.byref(po), n_e, T.ptr(buf), T.ptr(boff), C.byref(h)) == 0, Lb.nabwa_last_error()
+    t.append(time.time())
+    assert Lb.nabwa_bam_batch_pass1(h, C.byref(st), tab) == 0, Lb.nabwa_last_error()
+    t.append(time.time())
+    tot, mp = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+    assert Lb.nabwa_bam_batch_pass2(h, tab, tot, mp) == 0, Lb.nabwa_last_error()
+    t.append(time.time())
+    nb = C.c_int64()
+    oo = np.zeros(n_e + 1, np.int64)
+    Lb.nabwa_bam_batch_output(h, None, 0, T.ptr(oo), C.byref(nb))
+    ob = np.zeros(max(nb.value, 1), np.uint8)
+    assert Lb.nabwa_bam_batch_output(h, T.ptr(ob), nb.value, T.ptr(oo), C.byref(nb)) == 0
+    t.append(time.time())
+    Lb.nabwa_bam_batch_destroy(h)
+    Lb.nabwa_isize_table_destroy(tab)
+    dt = np.diff(t)
+    exact, n_chk = None, 0
+    if want_cpu:
+        ref, rix = ref_full_index(T, host_bwt, host_sa, pac, n)
+        if ref is not None:
+            import bamlib
+            n_chk = min(n_e, 20000)
+            copt = T.GapOpt()
+            C.memmove(C.byref(copt), C.byref(opt), 64)
+            ref.ref_cal_sa_reg_gap_mt.restype = C.c_long
+            ref.ref_cal_sa_reg_gap_mt.argtypes = [P, P, C.c_int, P, P, P, C.c_int, P, P, C.c_long]
+            ref.ref_aln2pos_se.argtypes = [P, P, C.c_int, C.c_int, P, C.c_int, P, P]
+            na = np.zeros(n_chk, np.int32)
+            rows = np.zeros(64 * n_chk + 4096, T.ALN_DT)
+            o = np.ascontiguousarray(off[:n_chk + 1])
+            assert ref.ref_cal_sa_reg_gap_mt(rix, C.byref(copt), n_chk, T.ptr(o), T.ptr(seq), T.ptr(rseq), 16, T.ptr(na), T.ptr(rows), len(rows)) >= 0
+            bnd = np.concatenate([[0], np.cumsum(na)])
+            dec = bamlib.decode(ob, oo[:n_chk + 1], ["synth%d" % (k + 1) for k in range(16)])
+            ref.ref_seed48(11)
+            f, mu = np.zeros(12, np.int64), np.zeros(64, np.int64)
+            exact = True
+            for i in range(n_chk):
+                r = np.ascontiguousarray(rows[bnd[i]:bnd[i + 1]])
+                ref.ref_aln2pos_se(rix, C.byref(copt), L, len(r), T.ptr(r), po.max_occ_se, T.ptr(f), T.ptr(mu))
+                g = dec[i]
+                if f[0] == 0:
+                    ok = bool(g["flag"] & 4) and g["rname"] == "*"
+                else:
+                    tg = g["tags"]
+                    cid = int(g["rname"][5:]) - 1
+                    ok = (g["pos"] + n * cid // 16 == f[9] + 1 and bool(g["flag"] & 16) == bool(f[1]) and (g["mapq"] == f[10] or bool(g["flag"] & 4))
+                          and tg["X0"] == f[7] and tg.get("X1", f[8]) == f[8] and tg["XM"] == f[2] and tg["XO"] == f[3])
+                exact = exact and bool(ok)
+    return {"what": "unaligned BAM records in host memory -> aligned BAM records in host memory (nabwa_bam_batch_*: the whole of bam2bam's two passes for single-end records, without BGZF)",
+            "reads": n_e, "reads_per_s": round(n_e / dt.sum(), 1), "bam_bytes_out": int(nb.value),
+            "stage_ms": {"parse + erase tags + bam1_to_seq": round(dt[0] * 1e3, 1), "pass 1: search (upload, kernels W / S / D, rows back) + posn_singleton": round(dt[1] * 1e3, 1),
+                         "pass 2: bwa_refine_gapped + MD/NM + bwa_update_bam1": round(dt[2] * 1e3, 1), "records out": round(dt[3] * 1e3, 1)},
+            "bit_exact_vs_reference_sample": exact, "sample_reads": n_chk}
+
+
+def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backend, host_bwt, host_sa, pac, want_cpu):
+    """BASELINE config 3: the paired-end path.  One step = both ends searched (kernels W / S / D on 2 N reads, resident), the
+    rows fetched, posn_pair on the host's drand48 stream + bwt_sa batch, the insert-size estimate from the histogram
+    (infer_isize_hist), finish_pair (pairing, mate rescue and gap refinement as GPU batches).  value = pairs/s."""
+    import torch
+    N, L = args.pairs, 150
+    seq, rseq, off = synth.synth_pairs(d_text, n, N, L, 20000, 100000, 400.0, 40.0, 3 + 1000 * rank, device=dev)
+    opt = nabwa.gap_init_opt()
+    po = nabwa.pe_opt_default()
+    full = np.full(2 * N, L, np.int32)
+    batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        t = [time.time()]
+        batch.run()
+        n2 = batch.sync()
+        t.append(time.time())
+        n_aln, rows, _ = batch.fetch_flat()
+        t.append(time.time())
+        recs, _ = ix.pe_posn_flat(opt, off, full, n_aln, rows, nabwa.srand48_state(11))
+        t.append(time.time())
+        h = np.zeros(100000, np.uint16)
+        L_ = nabwa.lib()
+        v = np.frombuffer(recs, np.uint8).reshape(2 * N, C.sizeof(nabwa.PeRec))
+        se = nabwa.PeRec.se.offset
+        f = lambda name: v[:, se + getattr(nabwa.SeRec, name).offset: se + getattr(nabwa.SeRec, name).offset + 4].copy().view(np.int32)[:, 0]
+        tp, mq, pos, ln = f("type"), f("mapQ"), f("pos").view(np.uint32), f("len")
+        a, b = slice(0, 2 * N, 2), slice(1, 2 * N, 2)
+        ok = (mq[a] >= 20) & (mq[b] >= 20)              # improve_isize_est (insert_size.c:141-165), vectorised
+        p0, p1 = pos[a].astype(np.int64), pos[b].astype(np.int64)
+        d = np.where(p0 < p1, p1 + ln[b] - p0, p0 + ln[a] - p1)
+        d = d[ok & (d >= 0) & (d < 100000)]
+        np.add.at(h, d, 1)
+        rc, ii = nabwa.isize_infer(h, po.ap_prior, n)
+        t.append(time.time())
+        tot, mp = ix.pe_finish_flat(opt, po, ii, seq, rseq, off, n_aln, rows, recs)
+        t.append(time.time())
+        return recs, ii, n2, (n_aln, rows), np.diff(t), (tot, mp), (batch.last_kernel_ms(), batch.last_width_ms(), batch.last_deep_ms())
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t1 = time.time()
+    splits, kms = [], []
+    for _ in range(args.steps):
+        recs, ii, n2, hits, dt, sw, km = step()
+        splits.append(dt)
+        kms.append(km)
+    barrier()
+    elapsed = time.time() - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        batch.close()
+        return None
+    sp = np.mean(splits, axis=0) * 1e3
+    t_search, t_width = (0, 0) if quick_env() else batch.count_touches()
+    s_ms, w_ms, d_ms = [float(x) for x in np.mean(kms, axis=0)]
+    checksum, n_rows = batch.checksum()
+    bytes_alg = 48 * t_search + N * L + 16 * n_rows
+    k_ms = s_ms + d_ms
+    roofline = {"bound": "hbm", "achieved": round(bytes_alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "fm_search_kernel<false,false> + fm_deep_kernel (bwt_match_gap of both ends)", "kernel_ms": round(k_ms, 3),
+                "search_kernel_ms": round(s_ms, 3), "deep_kernel_ms": round(d_ms, 3), "width_kernel_ms": round(w_ms, 3),
+                "bytes_per_read": round(bytes_alg / (2 * N), 1), "bucket_touches_per_read": round(t_search / (2 * N), 1),
+                "note": "the FM search is the dominant GPU kernel of the step; the finishing chain is host-bound (stage_ms)"}
+    cpu, exact = None, None
+    if want_cpu:
+        cpu, exact = pe_cpu_baseline(args, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, off, hits, recs, ii, L)
+    tp = np.frombuffer(recs, np.uint8).reshape(2 * N, C.sizeof(nabwa.PeRec))[:, nabwa.PeRec.se.offset + nabwa.SeRec.type.offset]
+    out = {"metric": "aligned pairs/s to GRCh38 (2 x 150 bp PE at 2%% error), search + posn_pair + insert-size estimate + finish_pair%s"
+                     % (", bit-exact vs CPU" if exact else (", CPU sample DIFFERS" if exact is False else ", CPU comparison not run")),
+           "value": round(N * world * args.steps / elapsed, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32", "data": "synthetic",
+           "config": {"workload": "GRCh38-sized synthetic genome (%d bp), %d pairs/GPU of 2 x %d bp, 2%% substitutions, 10%% of the reads with a 1-base indel, "
+                                  "inserts ~ N(400, 40), default gap_opt_t / pe_opt_t (BASELINE config 3 at %d of its 10 M pairs per step)" % (n, N, L, N),
+                      "pairs_per_gpu": N, "read_len": L, "genome_len": n, "parallelism": "pairs sharded x%d, index replicated" % world,
+                      "stage_ms": {"search (kernels W, S, D)": round(float(sp[0]), 1), "rows to the host": round(float(sp[1]), 1),
+                                   "posn_pair (host RNG + bwt_sa batch)": round(float(sp[2]), 1), "insert-size estimate": round(float(sp[3]), 1),
+                                   "finish_pair (pairing, mate rescue, refinement, MD)": round(float(sp[4]), 1)},
+                      "isize": [ii.avg, ii.std, ii.low, ii.high, ii.high_bayesian], "mate_rescued": int(sw[1][0]), "rescue_attempts": int(sw[0][0]),
+                      "mapped_ends": int((tp != 0).sum()), "second_pass_reads": n2, "hits": n_rows, "checksum": "%016x" % checksum,
+                      "bit_exact_vs_cpu_sample": exact},
+           "roofline": roofline, "cpu_baseline": cpu}
+    batch.close()
+    return out
+
+
+def pe_cpu_baseline(args, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, off, hits, recs, ii, L):
+    """the reference's own functions on a bounded sample of the same pairs: bwa_cal_sa_reg_gap of both ends on all host threads
+    (ref_cal_sa_reg_gap_mt), then posn_pair serially and finish_pair on all threads (ref_pe_chain_mt); the GPU records of the
+    sample are compared field for field"""
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("NABWA_BENCH_CPU_THREADS", "16")))
+    ref, rix = ref_full_index(T, host_bwt, host_sa, pac, n)
+    if ref is None:
+        return None, None
+    copt = T.GapOpt()
+    C.memmove(C.byref(copt), C.byref(opt), 64)
+    ref.ref_cal_sa_reg_gap_mt.restype = C.c_long
+    ref.ref_cal_sa_reg_gap_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    ref.ref_pe_new.restype = C.c_void_p
+    ref.ref_pe_new.argtypes = [C.c_int]
+    ref.ref_pe_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ref.ref_pe_chain_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ref.ref_pe_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+    ref.ref_pe_free.argtypes = [C.c_void_p]
+
+    def search(n_s):
+        o = np.ascontiguousarray(off[:2 * n_s + 1])
+        na = np.zeros(2 * n_s, np.int32)
+        cap = 128 * n_s + 4096
+        rows = np.zeros(cap, T.ALN_DT)
+        t = time.time()
+        tot = ref.ref_cal_sa_reg_gap_mt(rix, C.byref(copt), 2 * n_s, T.ptr(o), T.ptr(seq), T.ptr(rseq), cores, T.ptr(na), T.ptr(rows), cap)
+        assert tot >= 0
+        return time.time() - t, na, rows[:tot]
+
+    pilot = 64 * cores
+    dt, _, _ = search(pilot)
+    n_s = int(min(args.pairs, max(pilot, pilot / max(dt, 1e-3) * args.cpu_seconds * 0.7)))
+    t_search, na, rows = search(n_s)
+    g_na, g_rows = hits
+    b0 = np.concatenate([[0], np.cumsum(na)])
+    gb = np.concatenate([[0], np.cumsum(g_na[:2 * n_s])])
+    exact = bool(np.array_equal(na, g_na[:2 * n_s]) and rows.tobytes() == g_rows[:gb[-1]].tobytes())
+    b = C.c_void_p(ref.ref_pe_new(n_s))
+    for i in range(2 * n_s):
+        r = np.ascontiguousarray(rows[b0[i]:b0[i + 1]])
+        ref.ref_pe_set(b, i // 2, i % 2, L, T.ptr(np.ascontiguousarray(seq[off[i]:off[i + 1]])), T.ptr(np.ascontiguousarray(rseq[off[i]:off[i + 1]])), len(r), T.ptr(r))
+    ref.ref_seed48(11)
+    iiv = (C.c_double * 6)(ii.avg, ii.std, ii.ap_prior, ii.low, ii.high, ii.high_bayesian)
+    secs = (C.c_double * 2)()
+    ref.ref_pe_chain_mt(b, rix, C.byref(copt), iiv, cores, secs)
+    f = np.zeros(17, np.int64); cg = np.zeros(256, np.uint16); mdb = C.create_string_buffer(1024); mu = np.zeros(21 * 16, np.int64)
+    for i in range(2 * n_s):
+        ref.ref_pe_get(b, i // 2, i % 2, T.ptr(f), T.ptr(cg), mdb, 1024, T.ptr(mu))
+        g = recs[i]; s = g.se
+        if f[0] == 0:
+            exact = exact and s.type == 0
+            continue
+        bridging = bool(s.flag & 4)
+        got = [s.type, s.strand, s.n_mm, s.n_gapo, s.n_gape, s.score, s.sa, s.c1, s.c2, s.pos, s.mapQ if not bridging else int(f[10]), s.seQ]
+        same = got == [int(x) for x in f[:12]] and s.n_cigar == f[13] and list(s.cigar[:s.n_cigar]) == list(cg[:s.n_cigar]) and s.nm == f[14] \
+            and s.md == mdb.value and s.n_multi == f[15] and (g.extra_flag & 0xff) == (f[12] & 0xff)
+        exact = exact and bool(same)
+    ref.ref_pe_free(b)
+    t_all = t_search + secs[0] + secs[1]
+    log("cpu baseline (reference): %d pairs on %d threads: search %.2f s, posn_pair %.2f s (serial, as in the reference), finish_pair %.2f s" % (n_s, cores, t_search, secs[0], secs[1]))
+    return {"value": round(n_s / t_all, 1), "unit": "pairs/s", "cores": cores, "kind": "reference",
+            "sample": "first %d pairs of the same batch: bwa_cal_sa_reg_gap of both ends on %d threads (%.1f s), posn_pair serial (%.1f s), finish_pair on %d threads (%.1f s)"
+                      % (n_s, cores, t_search, secs[0], cores, secs[1])}, exact
 
 
 def adna_profile(seq, n_reads, L, seed):

@@ -316,6 +316,37 @@ class Index:
         """.ann/.amb/.pac of the index (reference bns_restore + bwt_restore_pac)"""
         _chk(lib().nabwa_index_attach_reference(self._h, prefix.encode()))
 
+    def set_reference(self, l_pac, seed, pac, n_contigs=16, name="synth"):
+        """nabwa_index_set_reference: n_contigs equal contigs "synth1".. over the reference (a contig's length is an int32 in the
+        reference's bntann1_t), no ambiguity holes, .pac bytes from memory.  Returns the contig (names, offsets, lengths)."""
+        L = lib()
+        L.nabwa_index_set_reference.argtypes = [_P, C.c_int64, C.c_uint32, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, _P]
+        offs = np.array([l_pac * i // n_contigs for i in range(n_contigs)], np.int64)
+        lens = np.diff(np.append(offs, l_pac)).astype(np.int32)
+        nm = ["%s%d" % (name, i + 1) for i in range(n_contigs)]
+        names = (C.c_char_p * n_contigs)(*[x.encode() for x in nm])
+        pac = np.ascontiguousarray(pac, np.uint8)
+        _chk(L.nabwa_index_set_reference(self._h, int(l_pac), int(seed), n_contigs, names, _ptr(offs), _ptr(lens), 0, None, None, None, _ptr(pac)))
+        return nm, offs, lens
+
+    def pe_posn_flat(self, opt, off, full_len, n_aln, rows, rng_state):
+        """nabwa_pe_posn on flat arrays (n_aln per read, rows back to back) -> (PeRec array, new rng state)"""
+        n = len(off) - 1
+        out = (PeRec * max(n, 1))()
+        st = C.c_uint64(rng_state)
+        _chk(lib().nabwa_pe_posn(self._h, C.byref(opt), n // 2, _ptr(np.ascontiguousarray(off, np.int64)), _ptr(np.ascontiguousarray(full_len, np.int32)),
+                                 _ptr(np.ascontiguousarray(n_aln, np.int32)), _ptr(np.ascontiguousarray(rows)), C.byref(st), out))
+        return out, st.value
+
+    def pe_finish_flat(self, opt, popt, ii, seq, rseq, off, n_aln, rows, recs):
+        """nabwa_pe_finish on flat arrays; recs (from pe_posn_flat) are updated in place -> (n_tot, n_mapped)"""
+        n = len(off) - 1
+        tot, mp = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        _chk(lib().nabwa_pe_finish(self._h, C.byref(opt), C.byref(popt), C.byref(ii), n // 2, _ptr(np.ascontiguousarray(off, np.int64)),
+                                   _ptr(np.ascontiguousarray(seq, np.uint8)), _ptr(np.ascontiguousarray(rseq, np.uint8)),
+                                   _ptr(np.ascontiguousarray(n_aln, np.int32)), _ptr(np.ascontiguousarray(rows)), recs, tot, mp))
+        return list(tot), list(mp)
+
     def se_finish(self, opt, seq, rseq, off, full_len, hits, n_occ, rng_state):
         """aln2seq + positions + mapQ + gap refinement + MD/NM for a batch, in record order.
         hits: per-read arrays of bwt_aln1_t rows.  Returns (array of SeRec, new rng state)."""
@@ -476,6 +507,19 @@ class Batch:
         n_aln = n_aln[:self.n]
         bounds = np.concatenate([[0], np.cumsum(n_aln)])
         return [buf[bounds[i]:bounds[i + 1]] for i in range(self.n)], maxe[:self.n]
+
+    def fetch_flat(self):
+        """-> (n_aln per read, all rows back to back, max_entries per read)"""
+        n_aln = np.zeros(max(self.n, 1), np.int32)
+        maxe = np.zeros(max(self.n, 1), np.int32)
+        rows = C.c_int64()
+        rc = lib().nabwa_batch_fetch(self._h, _ptr(n_aln), None, 0, C.byref(rows), _ptr(maxe))
+        if rc not in (OK, ECAP):
+            _chk(rc)
+        buf = np.zeros(max(rows.value, 1), ALN_DT)
+        if rows.value:
+            _chk(lib().nabwa_batch_fetch(self._h, _ptr(n_aln), _ptr(buf), rows.value, C.byref(rows), _ptr(maxe)))
+        return n_aln[:self.n], buf[:rows.value], maxe[:self.n]
 
     def close(self):
         if self._h:

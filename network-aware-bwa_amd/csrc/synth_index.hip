@@ -65,34 +65,37 @@ extern "C" int nabwa_synth_text(int device, uint64_t n, uint64_t seed, int n_dup
 	return 0;
 }
 
-// reads sampled from the text with substitutions; written as bwa_seq_t.seq (read reversed) and
-// .rseq (reverse complement) codes, fixed length, plus int64 offsets
+// one read of `len` bases from the window that starts at p (rev: its reverse complement), with substitutions and at most one
+// 1-base indel; written as bwa_seq_t.seq (read reversed) and .rseq (reverse complement) codes (bwaseqio.c:294-297)
+__device__ void gen_read(const uint8_t *t, size_t p, bool rev, uint64_t h, int len, uint32_t sub_ppm, uint32_t indel_ppm, uint8_t *s, uint8_t *q)
+{
+	const bool has_indel = (splitmix(h ^ 0x1234) % 1000000u) < indel_ppm;
+	const int ipos = 15 + (int)(splitmix(h ^ 0x77) % (uint64_t)(len - 30));
+	const bool is_del = splitmix(h ^ 0x99) & 1;
+	for (int j = 0; j < len; ++j) {
+		// read base j in read orientation
+		int jj = rev ? len - 1 - j : j;              // position along the sampled window
+		size_t src = p + jj;
+		if (has_indel && jj >= ipos) src += is_del ? 1 : 0;
+		uint8_t c = t[src];
+		if (has_indel && !is_del && jj == ipos) c = (uint8_t)(splitmix(h ^ 0xabc) & 3);
+		else if (has_indel && !is_del && jj > ipos) c = t[src - 1];
+		if ((splitmix(h + 31 * (uint64_t)jj + 17) % 1000000u) < sub_ppm) c = (c + 1 + splitmix(h ^ jj) % 3) & 3;
+		if (rev) c = 3 - c;
+		s[len - 1 - j] = c;
+		q[len - 1 - j] = 3 - c;
+	}
+}
+
+// reads sampled from the text, fixed length, plus int64 offsets
 __global__ void reads_kernel(const uint8_t *t, size_t n, int n_reads, int len, uint32_t sub_ppm, uint32_t indel_ppm, uint64_t seed,
 							 uint8_t *seq, uint8_t *rseq, int64_t *off)
 {
 	FOR_ALL(r, (size_t)n_reads) {
 		const uint64_t h = splitmix(seed ^ (uint64_t)r * 0x9E3779B97F4A7C15ULL);
 		const size_t p = h % (n - len - 2);
-		const bool rev = h >> 63;
-		const bool has_indel = (splitmix(h ^ 0x1234) % 1000000u) < indel_ppm;
-		const int ipos = 15 + (int)(splitmix(h ^ 0x77) % (uint64_t)(len - 30));
-		const bool is_del = splitmix(h ^ 0x99) & 1;
-		uint8_t *s = seq + (size_t)r * len, *q = rseq + (size_t)r * len;
 		off[r] = (int64_t)r * len;
-		for (int j = 0; j < len; ++j) {
-			// read base j in read orientation
-			int jj = rev ? len - 1 - j : j;              // position along the sampled window
-			size_t src = p + jj;
-			if (has_indel && jj >= ipos) src += is_del ? 1 : 0;
-			uint8_t c = t[src];
-			if (has_indel && !is_del && jj == ipos) c = (uint8_t)(splitmix(h ^ 0xabc) & 3);
-			else if (has_indel && !is_del && jj > ipos) c = t[src - 1];
-			if ((splitmix(h + 31 * (uint64_t)jj + 17) % 1000000u) < sub_ppm) c = (c + 1 + splitmix(h ^ jj) % 3) & 3;
-			if (rev) c = 3 - c;
-			// seq = read reversed, rseq = complement of seq (bwaseqio.c:294-297)
-			s[len - 1 - j] = c;
-			q[len - 1 - j] = 3 - c;
-		}
+		gen_read(t, p, h >> 63, h, len, sub_ppm, indel_ppm, seq + (size_t)r * len, rseq + (size_t)r * len);
 		if (r == (size_t)n_reads - 1) off[n_reads] = (int64_t)n_reads * len;
 	}
 }
@@ -102,6 +105,40 @@ extern "C" int nabwa_synth_reads(int device, const uint8_t *d_text, uint64_t n, 
 {
 	SCHK(hipSetDevice(device));
 	hipLaunchKernelGGL(reads_kernel, GRID((size_t)n_reads), 0, 0, d_text, (size_t)n, n_reads, len, sub_ppm, indel_ppm, seed,
+					   d_seq, d_rseq, d_off);
+	SCHK(hipGetLastError());
+	SCHK(hipDeviceSynchronize());
+	return 0;
+}
+
+// pairs: fragments of length ~ N(isize_mean, isize_sd) from either strand, read 1 from the fragment's start, read 2
+// the reverse complement of its end (FR); reads interleaved, index 2 * pair + end
+__global__ void pairs_kernel(const uint8_t *t, size_t n, int n_pairs, int len, uint32_t sub_ppm, uint32_t indel_ppm, float isize_mean, float isize_sd,
+							 uint64_t seed, uint8_t *seq, uint8_t *rseq, int64_t *off)
+{
+	FOR_ALL(r, (size_t)n_pairs) {
+		const uint64_t h = splitmix(seed ^ (uint64_t)r * 0x9E3779B97F4A7C15ULL);
+		const float u1 = ((splitmix(h ^ 0x51) >> 11) + 1) * (1.0f / 9007199254740993.0f), u2 = (splitmix(h ^ 0x52) >> 11) * (1.0f / 9007199254740992.0f);
+		int ins = (int)(isize_mean + isize_sd * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) + 0.5f);
+		if (ins < len) ins = len;
+		if (ins > 60000) ins = 60000;
+		const size_t p = h % (n - (size_t)ins - 4);
+		const bool flip = h >> 63;                       // the fragment comes from the reverse strand: read 1 is its far end
+		for (int e = 0; e < 2; ++e) {
+			const size_t rd = 2 * r + e;
+			const bool far = (e == 1) != flip;               // this end covers the fragment's right end, reverse-complemented
+			off[rd] = (int64_t)rd * len;
+			gen_read(t, far ? p + ins - len - 1 : p, far, splitmix(h + 77 * (e + 1)), len, sub_ppm, indel_ppm, seq + rd * len, rseq + rd * len);
+		}
+		if (r == (size_t)n_pairs - 1) off[2 * (size_t)n_pairs] = (int64_t)2 * n_pairs * len;
+	}
+}
+
+extern "C" int nabwa_synth_pairs(int device, const uint8_t *d_text, uint64_t n, int n_pairs, int len, uint32_t sub_ppm, uint32_t indel_ppm,
+								 float isize_mean, float isize_sd, uint64_t seed, uint8_t *d_seq, uint8_t *d_rseq, int64_t *d_off)
+{
+	SCHK(hipSetDevice(device));
+	hipLaunchKernelGGL(pairs_kernel, GRID((size_t)n_pairs), 0, 0, d_text, (size_t)n, n_pairs, len, sub_ppm, indel_ppm, isize_mean, isize_sd, seed,
 					   d_seq, d_rseq, d_off);
 	SCHK(hipGetLastError());
 	SCHK(hipDeviceSynchronize());

@@ -110,3 +110,19 @@ def gather_ceiling(table_bytes=2 << 30, bytes_per_access=64, chains=1, n_blocks=
     _chk(lib().nabwa_synth_gather_bench(device, int(table_bytes), int(bytes_per_access), int(chains), int(n_blocks),
                                         int(steps), C.byref(g), C.byref(m)))
     return g.value, m.value
+
+
+def synth_pairs(d_text, n, n_pairs, length, sub_ppm, indel_ppm, isize_mean, isize_sd, seed, device=0):
+    """pairs sampled from the text (FR, insert ~ N(mean, sd)), reads interleaved 2*pair + end -> host arrays (seq, rseq, off)"""
+    m = 2 * n_pairs
+    ds = DevArray.empty(m * length, device)
+    dr = DevArray.empty(m * length, device)
+    do = DevArray.empty((m + 1) * 8, device)
+    lib().nabwa_synth_pairs.argtypes = [C.c_int, _P, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_uint64, _P, _P, _P]
+    _chk(lib().nabwa_synth_pairs(device, _P(d_text.ptr), int(n), int(n_pairs), int(length), int(sub_ppm), int(indel_ppm),
+                                 float(isize_mean), float(isize_sd), int(seed), _P(ds.ptr), _P(dr.ptr), _P(do.ptr)))
+    seq, rseq, off = ds.to_host(np.uint8), dr.to_host(np.uint8), do.to_host(np.int64)
+    ds.free()
+    dr.free()
+    do.free()
+    return seq, rseq, off

@@ -497,3 +497,60 @@ void ref_pe_records(ref_index_t *ix, const gap_opt_t *opt, const double *iiv, in
 	ref_pe_posn(&b, ix, opt);
 	ref_pe_finish(&b, ix, opt, iiv);
 }
+
+/* ------------------------------------------------------------------ bench.py's CPU legs on a synthetic genome held in memory */
+/* ref_index_wrap plus the suffix-array samples (content of .sa / .rsa: 7 header words, then the samples; bwtio.c:161-182), the
+ * packed reference and a bntseq_t of n_contigs equal contigs (what bns_restore builds from .ann / .amb, bntseq.c:88-139). */
+ref_index_t *ref_index_wrap_full(const uint32_t *bwt0, uint64_t nw0, const uint32_t *bwt1, uint64_t nw1,
+								 const uint32_t *sa0, const uint32_t *sa1, const uint8_t *pac, int64_t l_pac, uint32_t seed, int n_contigs)
+{
+	ref_index_t *ix = ref_index_wrap(bwt0, nw0, bwt1, nw1);
+	const uint32_t *sa[2] = { sa0, sa1 }; int t;
+	for (t = 0; t < 2; ++t) {
+		bwt_t *b = ix->bwt[t];
+		b->sa_intv = sa[t][5];
+		b->n_sa = (b->seq_len + b->sa_intv) / b->sa_intv;
+		b->sa = (bwtint_t*)calloc(b->n_sa, sizeof(bwtint_t));
+		b->sa[0] = (bwtint_t)-1;
+		memcpy(b->sa + 1, sa[t] + 7, sizeof(bwtint_t) * (b->n_sa - 1));
+	}
+	ix->bns = (bntseq_t*)calloc(1, sizeof(bntseq_t));
+	ix->bns->l_pac = l_pac; ix->bns->n_seqs = n_contigs; ix->bns->seed = seed;
+	ix->bns->anns = (bntann1_t*)calloc(n_contigs, sizeof(bntann1_t));
+	for (t = 0; t < n_contigs; ++t) {       /* equal contigs "synth1".. (a contig's length is an int32) */
+		char nm[32]; snprintf(nm, sizeof nm, "synth%d", t + 1);
+		ix->bns->anns[t].offset = l_pac * t / n_contigs; ix->bns->anns[t].len = (int32_t)(l_pac * (t + 1) / n_contigs - l_pac * t / n_contigs);
+		ix->bns->anns[t].name = strdup(nm); ix->bns->anns[t].anno = strdup("");
+	}
+	ix->bns->n_holes = 0; ix->bns->ambs = 0;
+	ix->pac = (ubyte_t*)pac;
+	bwase_initialize();
+	return ix;
+}
+
+/* The paired-end chain of bam2bam after the search, per pair: posn_pair in order on one drand48 stream (it is serial in the
+ * reference too), then finish_pair (pairing, multi lists, bwa_paired_sw1, bwa_refine_gapped) on n_threads threads over
+ * contiguous shares of the pairs -- pass 2 draws no random numbers.  Returns the seconds of (posn, finish). */
+typedef struct { ref_pe_batch_t b; ref_index_t *ix; const gap_opt_t *opt; const double *iiv; } ref_pe_job_t;
+static void *ref_pe_job(void *a) { ref_pe_job_t *J = (ref_pe_job_t*)a; ref_pe_finish(&J->b, J->ix, J->opt, J->iiv); return 0; }
+#include <sys/time.h>
+static double ref_now(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+void ref_pe_chain_mt(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv, int n_threads, double *secs)
+{
+	int t;
+	double t0 = ref_now();
+	ref_pe_posn(b, ix, opt);
+	secs[0] = ref_now() - t0; t0 = ref_now();
+	{
+		ref_pe_job_t *jobs = (ref_pe_job_t*)calloc(n_threads, sizeof(*jobs));
+		pthread_t *tid = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+		for (t = 0; t < n_threads; ++t) {
+			const int lo = (int)((long)b->n * t / n_threads), hi = (int)((long)b->n * (t + 1) / n_threads);
+			jobs[t].b.n = hi - lo; jobs[t].b.s = b->s + 2 * (size_t)lo; jobs[t].ix = ix; jobs[t].opt = opt; jobs[t].iiv = iiv;
+			pthread_create(&tid[t], 0, ref_pe_job, jobs + t);
+		}
+		for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+		free(jobs); free(tid);
+	}
+	secs[1] = ref_now() - t0;
+}
