@@ -319,26 +319,30 @@ def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, 
     Lb.nabwa_bam_batch_destroy.argtypes = [P]
     Lb.nabwa_isize_table_destroy.argtypes = [P]
     po = nabwa.pe_opt_default()
-    tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
-    st = C.c_uint64(nabwa.srand48_state(11))
-    h = P()
-    t = [time.time()]
-    assert Lb.nabwa_bam_batch_create(ix._h, C.byref(opt), C.byref(po), n_e, T.ptr(buf), T.ptr(boff), C.byref(h)) == 0, Lb.nabwa_last_error()
-    t.append(time.time())
-    assert Lb.nabwa_bam_batch_pass1(h, C.byref(st), tab) == 0, Lb.nabwa_last_error()
-    t.append(time.time())
-    tot, mp = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
-    assert Lb.nabwa_bam_batch_pass2(h, tab, tot, mp) == 0, Lb.nabwa_last_error()
-    t.append(time.time())
-    nb = C.c_int64()
-    oo = np.zeros(n_e + 1, np.int64)
-    Lb.nabwa_bam_batch_output(h, None, 0, T.ptr(oo), C.byref(nb))
-    ob = np.zeros(max(nb.value, 1), np.uint8)
-    assert Lb.nabwa_bam_batch_output(h, T.ptr(ob), nb.value, T.ptr(oo), C.byref(nb)) == 0
-    t.append(time.time())
-    Lb.nabwa_bam_batch_destroy(h)
-    Lb.nabwa_isize_table_destroy(tab)
-    dt = np.diff(t)
+    def once():
+        tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
+        st = C.c_uint64(nabwa.srand48_state(11))
+        h = P()
+        t = [time.time()]
+        assert Lb.nabwa_bam_batch_create(ix._h, C.byref(opt), C.byref(po), n_e, T.ptr(buf), T.ptr(boff), C.byref(h)) == 0, Lb.nabwa_last_error()
+        t.append(time.time())
+        assert Lb.nabwa_bam_batch_pass1(h, C.byref(st), tab) == 0, Lb.nabwa_last_error()
+        t.append(time.time())
+        tot, mp = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        assert Lb.nabwa_bam_batch_pass2(h, tab, tot, mp) == 0, Lb.nabwa_last_error()
+        t.append(time.time())
+        nb = C.c_int64()
+        oo = np.zeros(n_e + 1, np.int64)
+        Lb.nabwa_bam_batch_output(h, None, 0, T.ptr(oo), C.byref(nb))
+        ob = np.zeros(max(nb.value, 1), np.uint8)
+        assert Lb.nabwa_bam_batch_output(h, T.ptr(ob), nb.value, T.ptr(oo), C.byref(nb)) == 0
+        t.append(time.time())
+        Lb.nabwa_bam_batch_destroy(h)
+        Lb.nabwa_isize_table_destroy(tab)
+        return np.diff(t), ob, oo, nb
+
+    dt_first, _, _, _ = once()              # the first batch of a size pays for its working buffers (device pool, host records)
+    dt, ob, oo, nb = once()                 # what a streaming caller sees from then on
     exact, n_chk = None, 0
     if want_cpu:
         ref, rix = ref_full_index(T, host_bwt, host_sa, pac, n)
@@ -372,7 +376,7 @@ def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, 
                           and tg["X0"] == f[7] and tg.get("X1", f[8]) == f[8] and tg["XM"] == f[2] and tg["XO"] == f[3])
                 exact = exact and bool(ok)
     return {"what": "unaligned BAM records in host memory -> aligned BAM records in host memory (nabwa_bam_batch_*: the whole of bam2bam's two passes for single-end records, without BGZF)",
-            "reads": n_e, "reads_per_s": round(n_e / dt.sum(), 1), "bam_bytes_out": int(nb.value),
+            "reads": n_e, "reads_per_s": round(n_e / dt.sum(), 1), "first_batch_reads_per_s": round(n_e / dt_first.sum(), 1), "bam_bytes_out": int(nb.value),
             "stage_ms": {"parse + erase tags + bam1_to_seq": round(dt[0] * 1e3, 1), "pass 1: search (upload, kernels W / S / D, rows back) + posn_singleton": round(dt[1] * 1e3, 1),
                          "pass 2: bwa_refine_gapped + MD/NM + bwa_update_bam1": round(dt[2] * 1e3, 1), "records out": round(dt[3] * 1e3, 1)},
             "bit_exact_vs_reference_sample": exact, "sample_reads": n_chk}

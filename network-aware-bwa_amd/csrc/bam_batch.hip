@@ -18,12 +18,39 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
 #include "finish_common.hpp"
+
+/* the single-end chain on records of any stride whose head is a nabwa_se_t (se_finish.hip): this file works in place */
+int nabwa_se_posn_strided(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+						  const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride);
+int nabwa_se_refine_strided(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, void *out_base, size_t stride);
+
+/* slices of independent records on the host's threads */
+static int bam_threads(size_t n)
+{
+	int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+	if (getenv("NABWA_HOST_THREADS")) nt = atoi(getenv("NABWA_HOST_THREADS")) > 0 ? atoi(getenv("NABWA_HOST_THREADS")) : 1;
+	if (n < 8192) nt = 1;
+	return nt;
+}
+static double bam_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void bam_parallel(size_t n, const std::function<void(int, size_t, size_t)> &f)
+{
+	const int nt = bam_threads(n);
+	if (nt == 1) { f(0, 0, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; ++t) th.emplace_back(f, t, n * t / nt, n * (t + 1) / nt);
+	for (auto &x : th) x.join();
+}
 
 #define F_PD 1
 #define F_PP 2
@@ -151,6 +178,7 @@ static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r)
 	memcpy(&r.tid, p + 4, 4); memcpy(&r.pos, p + 8, 4); memcpy(&y, p + 12, 4); memcpy(&z, p + 16, 4);
 	memcpy(&r.l_qseq, p + 20, 4); memcpy(&r.mtid, p + 24, 4); memcpy(&r.mpos, p + 28, 4); memcpy(&r.isize, p + 32, 4);
 	r.bin = y >> 16; r.mapq = y >> 8 & 0xff; r.l_qname = y & 0xff; r.flag = z >> 16; r.n_cigar = z & 0xffff;
+	r.data.reserve((size_t)(len - 36) + 160);      /* room for the tags and the CIGAR pass 2 adds: no regrowth there */
 	r.data.assign(p + 36, p + len);
 	if (r.l_qseq < 0 || r.off_aux() > r.data.size() || r.l_qname == 0) return false;
 	return true;
@@ -229,7 +257,9 @@ static void revcom_rec(BamRec &r)
 	r.flag ^= F_SR;
 	const int L = r.l_qseq;
 	uint8_t *s = r.data.data() + r.off_seq(), *q = r.data.data() + r.off_qual();
-	std::vector<uint8_t> codes(L);
+	uint8_t small[512]; std::vector<uint8_t> big;
+	uint8_t *codes = small;
+	if (L > (int)sizeof(small)) { big.resize(L); codes = big.data(); }
 	for (int i = 0; i < L; ++i) codes[i] = (uint8_t)(s[i >> 1] >> ((~i & 1) << 2) & 15);
 	memset(s, 0, ((size_t)L + 1) / 2);
 	for (int i = 0; i < L; ++i) s[i >> 1] |= (uint8_t)(nib4(codes[L - 1 - i]) << ((~i & 1) << 2));
@@ -253,11 +283,10 @@ static void push_str(BamRec &r, char u, char v, const char *s) { const uint8_t b
 
 static void set_cigar(BamRec &r, int n, const uint32_t *c)       /* bam_resize_cigar + the copy (bam2bam.c:411-420,467-477) */
 {
-	const size_t at = r.off_cigar();
-	std::vector<uint8_t> nc(4 * (size_t)n);
-	if (n) memcpy(nc.data(), c, 4 * (size_t)n);
-	r.data.erase(r.data.begin() + at, r.data.begin() + at + 4 * (size_t)r.n_cigar);
-	r.data.insert(r.data.begin() + at, nc.begin(), nc.end());
+	const size_t at = r.off_cigar(), old_b = 4 * (size_t)r.n_cigar, new_b = 4 * (size_t)n, tail = r.data.size() - at - old_b;
+	if (new_b > old_b) { r.data.resize(r.data.size() + (new_b - old_b)); memmove(r.data.data() + at + new_b, r.data.data() + at + old_b, tail); }
+	else if (new_b < old_b) { memmove(r.data.data() + at + new_b, r.data.data() + at + old_b, tail); r.data.resize(r.data.size() - (old_b - new_b)); }
+	if (n) memcpy(r.data.data() + at, c, new_b);
 	r.n_cigar = (uint32_t)n;
 }
 
@@ -322,17 +351,51 @@ static void update_bam(BamRec &out, const nabwa_reference *R, const nabwa_se_t &
 	}
 }
 
-static void write_rec(const BamRec &r, std::vector<uint8_t> &o)
+static void write_rec(const BamRec &r, uint8_t *o)
 {
 	const uint32_t bs = 32 + (uint32_t)r.data.size();
 	const uint32_t y = r.bin << 16 | (r.mapq & 0xff) << 8 | (r.l_qname & 0xff), z = r.flag << 16 | (r.n_cigar & 0xffff);
 	uint8_t h[36];
 	memcpy(h, &bs, 4); memcpy(h + 4, &r.tid, 4); memcpy(h + 8, &r.pos, 4); memcpy(h + 12, &y, 4); memcpy(h + 16, &z, 4);
 	memcpy(h + 20, &r.l_qseq, 4); memcpy(h + 24, &r.mtid, 4); memcpy(h + 28, &r.mpos, 4); memcpy(h + 32, &r.isize, 4);
-	o.insert(o.end(), h, h + 36); o.insert(o.end(), r.data.begin(), r.data.end());
+	memcpy(o, h, 36); if (!r.data.empty()) memcpy(o + 36, r.data.data(), r.data.size());
 }
 
 /* ------------------------------------------------------------------ the batch */
+
+struct RawBytes {          /* bytes without the zero fill of std::vector (100 MB per million reads, written once by many threads) */
+	uint8_t *p; size_t n;
+	RawBytes() : p(0), n(0) {}
+	~RawBytes() { free(p); }
+	bool alloc(size_t m) { free(p); p = (uint8_t*)malloc(m ? m : 1); n = m; return p != 0; }
+	uint8_t *data() { return p; }
+	const uint8_t *data() const { return p; }
+	const uint8_t *begin() const { return p; }
+};
+
+/* The per-read records of a batch (3 KB each: they end in fixed CIGAR / MD / multi-hit arrays) are never filled whole, but fresh
+ * memory costs a page fault per record (0.4 s per million).  A streaming caller makes one batch after the other: the buffer of a
+ * destroyed batch is kept (up to 8 GB) and handed to the next one. */
+static std::mutex g_res_mu;
+static std::vector<std::pair<void*, size_t>> g_res_idle;
+static void *res_take(size_t bytes)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_res_mu);
+		for (size_t i = 0; i < g_res_idle.size(); ++i)
+			if (g_res_idle[i].second >= bytes && g_res_idle[i].second <= 2 * bytes + (1u << 20)) { void *p = g_res_idle[i].first; g_res_idle.erase(g_res_idle.begin() + i); return p; }
+	}
+	return malloc(bytes);
+}
+static void res_give(void *p, size_t bytes)
+{
+	if (!p) return;
+	std::lock_guard<std::mutex> lk(g_res_mu);
+	size_t tot = bytes;
+	for (auto &x : g_res_idle) tot += x.second;
+	if (tot > ((size_t)8 << 30) || g_res_idle.size() >= 4) { free(p); return; }
+	g_res_idle.push_back({ p, bytes });
+}
 
 struct nabwa_bam_batch {
 	nabwa_index *ix; nabwa_gap_opt_t opt; nabwa_pe_opt_t popt;
@@ -340,10 +403,13 @@ struct nabwa_bam_batch {
 	std::vector<int> kind;                         /* per logical record: 1 or 2 */
 	std::vector<int> first;                        /* per logical record: index of its first read */
 	std::vector<std::string> rg;                   /* per logical record */
-	std::vector<int64_t> off; std::vector<uint8_t> seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
+	std::vector<int64_t> off; RawBytes seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
 	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
-	std::vector<nabwa_pe_t> res;                   /* per read: the chain's record (singletons use .se only) */
+	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
+	size_t res_bytes;
+	nabwa_bam_batch() : res(0), phase(0), res_bytes(0) {}
+	~nabwa_bam_batch() { res_give(res, res_bytes); }
 };
 
 static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };      /* bam_nt16_nt4_table (bwaseqio.c:10) */
@@ -355,9 +421,17 @@ extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
 	nabwa_bam_batch *b = new nabwa_bam_batch();
 	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double tc0 = bam_now();
 	b->rec.resize(n_rec);
-	for (int i = 0; i < n_rec; ++i)
-		if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i])) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
+	{
+		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
+		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; ++i) if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i])) bad[t] = 1;
+		});
+		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
+	}
+	const double tc1 = bam_now();
 	/* logical records (read_bam_pair_core, bwaseqio.c:346-410): a paired read takes the next record as its mate -- same name,
 	 * flags read 1 / read 2 in either order; anything else is the reference's "lone mate" error (no broken-input mode here) */
 	for (int i = 0; i < n_rec; ) {
@@ -372,22 +446,60 @@ extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *
 			b->kind.push_back(2); b->first.push_back(i); i += 2;
 		} else { b->kind.push_back(1); b->first.push_back(i); i += 1; }
 	}
-	for (auto &r : b->rec) if (!erase_tags(r)) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed tags in a BAM record"); }
-	for (size_t k = 0; k < b->kind.size(); ++k) b->rg.push_back(get_rg(b->rec[b->first[k]]));
-	/* bam1_to_seq (bwaseqio.c:272-307) */
-	b->off.assign(n_rec + 1, 0); b->full_len.assign(n_rec ? n_rec : 1, 0);
-	std::vector<uint8_t> codes, quals, s, r;
-	for (int i = 0; i < n_rec; ++i) {
-		const BamRec &x = b->rec[i];
-		const int L = x.l_qseq;
-		codes.resize(L ? L : 1); quals.resize(L ? L : 1); s.resize(L ? L : 1); r.resize(L ? L : 1);
-		const uint8_t *sq = x.data.data() + x.off_seq(), *ql = x.data.data() + x.off_qual();
-		for (int j = 0; j < L; ++j) { codes[j] = nt16_nt4[sq[j >> 1] >> ((~j & 1) << 2) & 15]; quals[j] = ql[j] + 33 < 126 ? ql[j] : 93; }
-		const int len = nabwa_encode_read(L, codes.data(), quals.data(), (x.flag & F_SR) != 0, opt->trim_qual, 1, s.data(), r.data());
-		b->seq.insert(b->seq.end(), s.begin(), s.begin() + len); b->rseq.insert(b->rseq.end(), r.begin(), r.begin() + len);
-		b->off[i + 1] = b->off[i] + len; b->full_len[i] = L;
+	{
+		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
+		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (!erase_tags(b->rec[i])) bad[t] = 1; });
+		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed tags in a BAM record"); }
 	}
-	b->seq.push_back(0); b->rseq.push_back(0);
+	for (size_t k = 0; k < b->kind.size(); ++k) b->rg.push_back(get_rg(b->rec[b->first[k]]));
+	const double tc2 = bam_now();
+	/* bam1_to_seq (bwaseqio.c:272-307): the (trimmed) lengths first, then every thread encodes its slice of the reads in place */
+	b->off.assign(n_rec + 1, 0); b->full_len.assign(n_rec ? n_rec : 1, 0);
+	{
+		std::vector<int32_t> lens(n_rec ? n_rec : 1, 0);
+		bam_parallel((size_t)n_rec, [&](int, size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; ++i) {
+				const BamRec &x = b->rec[i];
+				const int L = x.l_qseq;
+				int len = L;
+				if (opt->trim_qual >= 1) {                    /* bwa_trim_read (bwaseqio.c:110-123) on phred + 33 capped at 126, in the read's own orientation */
+					const bool rev = (x.flag & F_SR) != 0;
+					const uint8_t *ql = x.data.data() + x.off_qual();
+					int sc = 0, mx = 0, max_l = L - 1;
+					for (int l = L - 1; l >= 35 - 1; --l) {
+						const int jj = rev ? L - 1 - l : l; const int q = ql[jj] + 33 < 126 ? ql[jj] : 93;
+						sc += opt->trim_qual - q;
+						if (sc < 0) break;
+						if (sc > mx) { mx = sc; max_l = l; }
+					}
+					len = max_l + 1;
+				}
+				lens[i] = len; b->full_len[i] = L;
+			}
+		});
+		for (int i = 0; i < n_rec; ++i) b->off[i + 1] = b->off[i] + lens[i];
+		if (!b->seq.alloc((size_t)b->off[n_rec] + 1) || !b->rseq.alloc((size_t)b->off[n_rec] + 1)) { delete b; return nabwa_fail(NABWA_ENOMEM, "out of memory for the reads"); }
+		bam_parallel((size_t)n_rec, [&](int, size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; ++i) {
+				const BamRec &x = b->rec[i];
+				const int L = x.l_qseq, len = lens[i];
+				const bool rev = (x.flag & F_SR) != 0;
+				const uint8_t *sq = x.data.data() + x.off_seq();
+				uint8_t *s = b->seq.data() + b->off[i], *r = b->rseq.data() + b->off[i];
+				/* base j of the read in its own orientation: a record that carries the reverse flag holds the reverse complement
+				 * (bwaseqio.c:288-291); seq = the (trimmed) read reversed, rseq = its complement (bwaseqio.c:294-297) */
+				for (int j = 0; j < len; ++j) {
+					const int k = len - 1 - j, jj = rev ? L - 1 - k : k;
+					uint8_t v = nt16_nt4[sq[jj >> 1] >> ((~jj & 1) << 2) & 15];
+					if (rev && v < 4) v = 3 - v;
+					s[j] = v; r[j] = v < 4 ? 3 - v : v;
+				}
+			}
+		});
+		b->seq.data()[b->off[n_rec]] = 0; b->rseq.data()[b->off[n_rec]] = 0;
+	}
+	if (timing) fprintf(stderr, "[nabwa] bam_batch_create %d records: parse %.3f s, pairing + tag erase + read groups %.3f s, bam1_to_seq %.3f s (%d threads)\n",
+						n_rec, tc1 - tc0, tc2 - tc1, bam_now() - tc2, bam_threads((size_t)n_rec));
 	*out = b;
 	return NABWA_OK;
 }
@@ -401,6 +513,8 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	if (b->phase != 0) return nabwa_fail(NABWA_EINVAL, "pass 1 already ran on this batch");
 	const int n = (int)b->rec.size();
 	b->n_aln.assign(n ? n : 1, 0); b->max_ent.assign(n ? n : 1, 0); b->row0.assign(n + 1, 0);
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double tp0 = bam_now();
 	/* bwa_cal_sa_reg_gap, one read per call in the reference (bam2bam.c:616,676) -> per_read = 1 */
 	int64_t n_rows = 0;
 	int rc;
@@ -424,11 +538,16 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	/* posn_singleton / posn_pair in record order: singletons list up to max_occ_se other hits, ends of pairs none */
 	std::vector<uint8_t> n_occ(n ? n : 1, 0);
 	for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) n_occ[b->first[k]] = (uint8_t)b->popt.max_occ_se;
-	std::vector<nabwa_se_t> se(n ? n : 1);
-	rc = nabwa_se_posn_v(b->ix, &b->opt, n, b->off.data(), b->full_len.data(), b->n_aln.data(), b->rows.data(), n_occ.data(), rng48, se.data());
+	res_give(b->res, b->res_bytes);
+	b->res_bytes = sizeof(nabwa_pe_t) * (size_t)(n ? n : 1);
+	b->res = (nabwa_pe_t*)res_take(b->res_bytes);
+	if (!b->res) return nabwa_fail(NABWA_ENOMEM, "out of memory for the batch's records");
+	const double tp1 = bam_now();
+	rc = nabwa_se_posn_strided(b->ix, &b->opt, n, b->off.data(), b->full_len.data(), b->n_aln.data(), b->rows.data(), n_occ.data(), rng48, b->res, sizeof(nabwa_pe_t));
 	if (rc != NABWA_OK) return rc;
-	b->res.assign(n ? n : 1, nabwa_pe_t());
-	for (int i = 0; i < n; ++i) { memset(&b->res[i], 0, offsetof(nabwa_pe_t, se)); b->res[i].se = se[i]; b->res[i].extra_flag = 0; b->res[i].m_seqid = 0; b->res[i].am = 0; b->res[i].pad = 0; b->res[i].m_rpos = 0; b->res[i].isize = 0; }
+	bam_parallel((size_t)n, [&](int, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) { nabwa_pe_t &r = b->res[i]; r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.pad = 0; r.m_rpos = 0; r.isize = 0; }
+	});
 	/* improve_isize_est (insert_size.c:141-165) */
 	for (size_t k = 0; k < b->kind.size(); ++k) {
 		const int i = b->first[k];
@@ -437,6 +556,7 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 		isize_add(tab, b->rg[k], nabwa_isize_bin(b->kind[k], s0.mapQ, s1.mapQ, s0.pos, s0.len, s1.pos, s1.len));
 	}
 	b->phase = 1;
+	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass1 %d records: search (upload, kernels, rows back) %.3f s, posn + insert-size bins %.3f s\n", n, tp1 - tp0, bam_now() - tp1);
 	return NABWA_OK;
 }
 
@@ -446,22 +566,27 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	if (!b || !tab) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (b->phase != 1) return nabwa_fail(NABWA_EINVAL, "pass 2 needs a batch that went through pass 1 once");
 	const nabwa_reference *R = b->ix->ref;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double tq0 = bam_now();
 	/* ---- singletons: bwa_refine_gapped + what bwa_update_bam1 derives */
 	{
 		std::vector<int> idx;
 		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) idx.push_back(b->first[k]);
-		if (!idx.empty()) {
+		if (idx.size() == b->rec.size() && !idx.empty()) {       /* a batch of singletons only: in place, no gathering */
+			int rc = nabwa_se_refine_strided(b->ix, (int)idx.size(), b->off.data(), b->seq.data(), b->rseq.data(), b->res, sizeof(nabwa_pe_t));
+			if (rc != NABWA_OK) return rc;
+		} else if (!idx.empty()) {
 			std::vector<int64_t> off(idx.size() + 1, 0); std::vector<uint8_t> sq, rq; std::vector<nabwa_se_t> se(idx.size());
 			for (size_t t = 0; t < idx.size(); ++t) {
 				const int i = idx[t]; const int64_t L = b->off[i + 1] - b->off[i];
 				sq.insert(sq.end(), b->seq.begin() + b->off[i], b->seq.begin() + b->off[i] + L);
 				rq.insert(rq.end(), b->rseq.begin() + b->off[i], b->rseq.begin() + b->off[i] + L);
-				off[t + 1] = off[t] + L; se[t] = b->res[i].se;
+				off[t + 1] = off[t] + L; memcpy(&se[t], &b->res[i].se, sizeof(nabwa_se_t));
 			}
 			sq.push_back(0); rq.push_back(0);
 			int rc = nabwa_se_refine(b->ix, (int)idx.size(), off.data(), sq.data(), rq.data(), se.data());
 			if (rc != NABWA_OK) return rc;
-			for (size_t t = 0; t < idx.size(); ++t) b->res[idx[t]].se = se[t];
+			for (size_t t = 0; t < idx.size(); ++t) memcpy(&b->res[idx[t]].se, &se[t], sizeof(nabwa_se_t));
 		}
 	}
 	/* ---- pairs, one read group at a time with that group's estimate (pass 2 draws no random numbers: its order is free) */
@@ -479,25 +604,29 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 				const int i = idx[t] + e; const int64_t L = b->off[i + 1] - b->off[i];
 				sq.insert(sq.end(), b->seq.begin() + b->off[i], b->seq.begin() + b->off[i] + L);
 				rq.insert(rq.end(), b->rseq.begin() + b->off[i], b->rseq.begin() + b->off[i] + L);
-				off[2 * t + e + 1] = off[2 * t + e] + L; pe[2 * t + e] = b->res[i]; na[2 * t + e] = b->n_aln[i];
+				off[2 * t + e + 1] = off[2 * t + e] + L; memcpy(&pe[2 * t + e], &b->res[i], sizeof(nabwa_pe_t)); na[2 * t + e] = b->n_aln[i];
 				rows.insert(rows.end(), b->rows.begin() + b->row0[i], b->rows.begin() + b->row0[i + 1]);
 			}
 			sq.push_back(0); rq.push_back(0); rows.push_back(nabwa_aln1_t());
 			int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows.data(), pe.data(), n_tot, n_mapped);
 			if (rc != NABWA_OK) return rc;
-			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) b->res[idx[t] + e] = pe[2 * t + e];
+			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) memcpy(&b->res[idx[t] + e], &pe[2 * t + e], sizeof(nabwa_pe_t));
 		}
 	}
 	/* ---- bwa_update_bam1 */
-	for (size_t k = 0; k < b->kind.size(); ++k) {
-		const int i = b->first[k];
-		if (b->kind[k] == 1) update_bam(b->rec[i], R, b->res[i].se, 0, 0, b->opt.mode, b->opt.max_top2);
-		else {
-			update_bam(b->rec[i], R, b->res[i].se, &b->res[i + 1].se, &b->res[i], b->opt.mode, b->opt.max_top2);
-			update_bam(b->rec[i + 1], R, b->res[i + 1].se, &b->res[i].se, &b->res[i + 1], b->opt.mode, b->opt.max_top2);
+	const double tq1 = bam_now();
+	bam_parallel(b->kind.size(), [&](int, size_t lo, size_t hi) {
+		for (size_t k = lo; k < hi; ++k) {
+			const int i = b->first[k];
+			if (b->kind[k] == 1) update_bam(b->rec[i], R, b->res[i].se, 0, 0, b->opt.mode, b->opt.max_top2);
+			else {
+				update_bam(b->rec[i], R, b->res[i].se, &b->res[i + 1].se, &b->res[i], b->opt.mode, b->opt.max_top2);
+				update_bam(b->rec[i + 1], R, b->res[i + 1].se, &b->res[i].se, &b->res[i + 1], b->opt.mode, b->opt.max_top2);
+			}
 		}
-	}
+	});
 	b->phase = 2;
+	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass2 %zu records: finishing chains %.3f s, bwa_update_bam1 %.3f s\n", b->rec.size(), tq1 - tq0, bam_now() - tq1);
 	return NABWA_OK;
 }
 
@@ -505,18 +634,13 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes)
 {
 	if (!b || !n_bytes) return nabwa_fail(NABWA_EINVAL, "null argument");
-	std::vector<uint8_t> o;
-	int64_t at = 0;
-	for (size_t i = 0; i < b->rec.size(); ++i) {
-		const size_t before = o.size();
-		write_rec(b->rec[i], o);
-		if (out_off) out_off[i] = at;
-		at += (int64_t)(o.size() - before);
-	}
-	if (out_off) out_off[b->rec.size()] = at;
-	*n_bytes = at;
-	if (!out || cap < at) return nabwa_fail(NABWA_ECAP, "output buffer too small");
-	if (at) memcpy(out, o.data(), (size_t)at);
+	const size_t n = b->rec.size();
+	std::vector<int64_t> at(n + 1, 0);
+	for (size_t i = 0; i < n; ++i) at[i + 1] = at[i] + 36 + (int64_t)b->rec[i].data.size();
+	if (out_off) memcpy(out_off, at.data(), sizeof(int64_t) * (n + 1));
+	*n_bytes = at[n];
+	if (!out || cap < at[n]) return nabwa_fail(NABWA_ECAP, "output buffer too small");
+	bam_parallel(n, [&](int, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) write_rec(b->rec[i], out + at[i]); });
 	return NABWA_OK;
 }
 

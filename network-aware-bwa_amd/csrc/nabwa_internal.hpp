@@ -28,3 +28,4 @@ struct nabwa_index {
 };
 
 int nabwa_fail(int code, const char *fmt, const char *a = "");
+

@@ -362,12 +362,12 @@ static void in_threads(int nt, size_t count, const std::function<void(size_t, si
 /* posn_singleton (bam2bam.c:622-641) for n reads in record order: bwa_aln2seq_core with the caller's drand48 stream, all
  * bwt_sa walks of the batch (main hits and multi hits) as one GPU batch, bwa_approx_mapQ */
 static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
-						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out);
+						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride);
 
 extern "C" int nabwa_se_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
 							 const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, uint64_t *rng48, nabwa_se_t *out)
 {
-	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, n_occ, 0, rng48, out);
+	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, n_occ, 0, rng48, out, sizeof(nabwa_se_t));
 }
 
 /* the same with a bound per read: a file that mixes singletons (max_occ_se other hits listed, bam2bam.c:629) and ends of pairs
@@ -376,13 +376,21 @@ extern "C" int nabwa_se_posn_v(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, in
 							   const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out)
 {
 	if (n && !n_occ_v) return nabwa_fail(NABWA_EINVAL, "null argument");
-	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, 0, n_occ_v, rng48, out);
+	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, 0, n_occ_v, rng48, out, sizeof(nabwa_se_t));
+}
+
+/* records of any stride whose head is a nabwa_se_t (nabwa_pe_t starts with one): the batch front-end works in place */
+int nabwa_se_posn_strided(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+						  const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride)
+{
+	return se_posn_impl(ix, opt, n, off, full_len, n_aln, aln, 0, n_occ_v, rng48, out_base, stride);
 }
 
 static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
-						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, nabwa_se_t *out)
+						const int32_t *n_aln, const nabwa_aln1_t *aln, int n_occ, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride)
 {
-	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (!ix || !opt || !rng48 || n < 0 || (n && (!off || !n_aln || !out_base))) return nabwa_fail(NABWA_EINVAL, "null argument");
+#define out_at(i_) (*rec_at(out_base, stride, (int)(i_)))
 	if (n_occ < 0 || n_occ + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
 	if (n_occ_v) for (int i = 0; i < n; ++i) if (n_occ_v[i] + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_occ outside 0..15");
 	const uint32_t rlen = ix->bwt[1].seq_len;
@@ -395,7 +403,7 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 	which.reserve((size_t)n + n / 4); rows.reserve((size_t)n + n / 4); look_rec.reserve((size_t)n + n / 4); look_multi.reserve((size_t)n + n / 4);
 	size_t a0 = 0;
 	for (int i = 0; i < n; ++i) {
-		nabwa_se_t &s = out[i];
+		nabwa_se_t &s = out_at(i);
 		memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
 		s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
 		const int len = (int)(off[i + 1] - off[i]);
@@ -421,19 +429,19 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 	/* positions (bwase.c:146-151, bam2bam.c:635-636): every looked-up row belongs to one record field, so slices are independent */
 	in_threads(nt, rows.size(), [&](size_t lo, size_t hi) {
 		for (size_t t = lo; t < hi; ++t) {
-			nabwa_se_t &s = out[look_rec[t]];
+			nabwa_se_t &s = out_at(look_rec[t]);
 			const uint32_t p = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
 			if (look_multi[t] < 0) s.pos = p; else s.multi[look_multi[t]].pos = p;
 		}
 	});
 	/* bwa_approx_mapQ (bwase.c:113-122); max_diff of a read follows from its length: one table instead of a Poisson sum per read */
 	int longest = 0;
-	for (int i = 0; i < n; ++i) if (out[i].len > longest) longest = out[i].len;
+	for (int i = 0; i < n; ++i) if (out_at(i).len > longest) longest = out_at(i).len;
 	std::vector<int> md_of(longest + 1, opt->max_diff);
 	if (opt->fnr > 0.0f) for (int L = 0; L <= longest; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
 	in_threads(nt, (size_t)n, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
-			nabwa_se_t &s = out[i];
+			nabwa_se_t &s = out_at(i);
 			if (s.type == 0) continue;
 			const int q = approx_mapq(s, md_of[s.len]);
 			s.mapQ = s.seQ = q;
@@ -442,13 +450,20 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 	if (timing) fprintf(stderr, "[nabwa] se_posn %d reads: hit choice %.3f s, bwt_sa batch (%zu rows) + positions + mapQ %.3f s\n", n, t1 - t0, rows.size(), now() - t1);
 	return NABWA_OK;
 }
+#undef out_at
 
 /* The non-BAM part of finish_singleton (bam2bam.c:643-651) for n positioned records: bwa_refine_gapped (bwase.c:356-423 --
  * refine_gapped_core of every gapped hit as ONE GPU batch of banded global alignments, bwa_cal_md1, bwa_correct_trimmed), then
  * the flag / contig / XT logic bwa_update_bam1 applies to a single-end record (bam2bam.c:430-525). */
+int nabwa_se_refine_strided(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, void *out_base, size_t stride);
 extern "C" int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, nabwa_se_t *out)
 {
-	if (!ix || n < 0 || (n && (!off || !seq || !rseq || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	return nabwa_se_refine_strided(ix, n, off, seq, rseq, out, sizeof(nabwa_se_t));
+}
+
+int nabwa_se_refine_strided(nabwa_index_t *ix, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, void *out_base, size_t stride)
+{
+	if (!ix || n < 0 || (n && (!off || !seq || !rseq || !out_base))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
 	const nabwa_reference *R = ix->ref;
 	const bool timing = getenv("NABWA_TIMING") != 0;
@@ -456,7 +471,7 @@ extern "C" int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, con
 	const double t2 = now();
 	size_t n_jobs = 0;
 	{
-		int r = refine_batch(ix, out, sizeof(nabwa_se_t), n, off, seq, rseq, &n_jobs);
+		int r = refine_batch(ix, out_base, stride, n, off, seq, rseq, &n_jobs);
 		if (r != NABWA_OK) return r;
 	}
 	const double t3 = now();
@@ -465,7 +480,7 @@ extern "C" int nabwa_se_refine(nabwa_index_t *ix, int n, const int64_t *off, con
 	auto phase4 = [&](int lo, int hi) {
 		std::vector<uint8_t> fwd;
 		for (int i = lo; i < hi; ++i) {
-			nabwa_se_t &s = out[i];
+			nabwa_se_t &s = *rec_at(out_base, stride, i);
 			if (s.type == 0) { s.flag = 4; continue; }
 			if (!md_and_trim(R, s, seq + off[i], rseq + off[i], fwd)) md_over = 1;
 			int64_t end = s.pos;
