@@ -51,8 +51,12 @@
 #define STATE_D 2
 #define STATE_GROUP 3   // arena only: the gap children of one expansion, see fm_search_kernel
 #define GRP_EXT 0x100u
-#define TXM 0xffffffffu   // l of an interval carried in text form (k = text position)
-#define KEYM 0xfffffffeu  // l of an interval carried in key form (k = path key: the reference symbols matched so far as base-4 digits)
+// Markers in the `l` word of a stack entry.  A key at depth T = 16 uses all 32 bits (TTTTTTTTTTTTTTTT = 0xffffffff), and the generic
+// child test is "k' <= l'": KEYM must therefore be the largest value.  (With KEYM = 0xfffffffe the all-T child of the last table
+// level failed that test and reads from poly-T stretches lost a hit -- found on the repeat-model genome, round 2.)  Text positions
+// stay below 0xfffffff0 (text_ok).
+#define TXM 0xfffffffeu   // l of an interval carried in text form (k = text position)
+#define KEYM 0xffffffffu  // l of an interval carried in key form (k = path key: the reference symbols matched so far as base-4 digits)
 #define LVO(t_) ((size_t)((((uint64_t)1 << (2 * (t_))) - 4ull) / 3ull))   /* offset of level t in the interval table */
 #ifndef NABWA_W_WAVES
 #define NABWA_W_WAVES 5   // kernel W: waves per SIMD the register budget is bounded for (102 VGPRs)

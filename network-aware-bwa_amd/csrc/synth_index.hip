@@ -65,6 +65,69 @@ extern "C" int nabwa_synth_text(int device, uint64_t n, uint64_t seed, int n_dup
 	return 0;
 }
 
+// ---------------------------------------------------------------- a genome with GRCh38-like repeat structure (bench.py --repeats)
+// Uniform random text is the friendliest genome there is: every 16-mer is unique, one hit per read.  Real genomes are half
+// repeats.  This model plants, deterministically (every family's copies sit in slots given by a bijection, families are
+// written one after the other):
+//   LINE-like : one 6 kb consensus, 60 000 copies truncated from the 5' end (500 .. 6000 bp kept), 3 .. 20 % divergence each
+//   Alu-like  : one 300 bp consensus, 1 000 000 copies at 10 .. 15 % divergence, every tenth from a young subfamily at 1 .. 3 %
+//   tandem    : 200 000 loci of a 1 .. 6 bp unit repeated over 30 .. 300 bp
+// -- about 17 % of the genome; either strand.  Reads from young copies have several near-identical placements (hit lists,
+// repeat mapQ, XA), reads from old ones make the search wade through partial matches.
+__device__ __forceinline__ uint8_t mutate(uint8_t c, uint64_t h, uint32_t div_ppm)
+{
+	return (h % 1000000u) < div_ppm ? (uint8_t)((c + 1 + (h >> 32) % 3) & 3) : c;
+}
+
+__global__ void family_kernel(uint8_t *t, size_t n, uint64_t seed, int kind, size_t n_copies, size_t n_slots, size_t slot_bytes, uint64_t mult)
+{
+	FOR_ALL(c, n_copies) {
+		const uint64_t h = splitmix(seed ^ (uint64_t)c * 0xD6E8FEB86659FD93ULL);
+		const size_t slot = (size_t)(((uint64_t)c * mult + (uint64_t)kind * 7919u) % n_slots);      /* a bijection on the slots: mult is a prime that does not divide n_slots */
+		const size_t dst = slot * slot_bytes + (kind == 2 ? slot_bytes / 2 : 0);
+		const bool rev = h >> 63;
+		if (kind == 2) {                        // tandem repeat: a unit of 1..6 bases over 30..300 bp
+			const int unit = 1 + (int)(splitmix(h ^ 1) % 6), len = 30 + (int)(splitmix(h ^ 2) % 271);
+			const uint64_t u = splitmix(h ^ 3);
+			for (int j = 0; j < len && dst + j < n; ++j) t[dst + j] = (uint8_t)(u >> (2 * (j % unit)) & 3);
+			continue;
+		}
+		const int cons_len = kind == 0 ? 6000 : 300;
+		int keep = cons_len; uint32_t div;
+		if (kind == 0) { keep = 500 + (int)(splitmix(h ^ 4) % 5501); div = 30000 + (uint32_t)(splitmix(h ^ 5) % 170001); }
+		else div = (c % 10 == 0) ? 10000 + (uint32_t)(splitmix(h ^ 6) % 20001) : 100000 + (uint32_t)(splitmix(h ^ 6) % 50001);
+		for (int j = 0; j < keep; ++j) {
+			const int cj = cons_len - keep + j;                                   // truncated from the 5' end
+			uint8_t b = (uint8_t)(splitmix(seed * 31 + (uint64_t)kind * 1000003u + (uint64_t)cj) >> 40 & 3);      // the family's consensus
+			b = mutate(b, splitmix(h + 977 * (uint64_t)j), div);
+			const size_t at = dst + (rev ? (size_t)(keep - 1 - j) : (size_t)j);
+			if (at < n) t[at] = rev ? (uint8_t)(3 - b) : b;
+		}
+	}
+}
+
+extern "C" int nabwa_synth_text_repeats(int device, uint64_t n, uint64_t seed, uint8_t **d_text)
+{
+	SCHK(hipSetDevice(device));
+	SCHK(hipMalloc(d_text, n + 64));
+	SCHK(hipMemset(*d_text, 0, n + 64));
+	hipLaunchKernelGGL(text_kernel, GRID(n), 0, 0, *d_text, (size_t)n, seed);
+	if (n >= (1ull << 24)) {
+		const double scale = (double)n / 3099734149.0;            // copy numbers of the GRCh38-sized genome, scaled
+		const size_t n_line = (size_t)(60000 * scale), n_alu = (size_t)(1000000 * scale), n_tr = (size_t)(200000 * scale);
+		size_t s8 = n / 8192, s1 = n / 1024;
+		const uint64_t P = 1000003ull;
+		if (s8 % P == 0) --s8;
+		if (s1 % P == 0) --s1;
+		if (n_line && n_line <= s8) hipLaunchKernelGGL(family_kernel, GRID(n_line), 0, 0, *d_text, (size_t)n, seed + 101, 0, n_line, s8, (size_t)8192, P);
+		if (n_alu && n_alu <= s1) hipLaunchKernelGGL(family_kernel, GRID(n_alu), 0, 0, *d_text, (size_t)n, seed + 202, 1, n_alu, s1, (size_t)1024, P);
+		if (n_tr && n_tr <= s1) hipLaunchKernelGGL(family_kernel, GRID(n_tr), 0, 0, *d_text, (size_t)n, seed + 303, 2, n_tr, s1, (size_t)1024, P);
+	}
+	SCHK(hipGetLastError());
+	SCHK(hipDeviceSynchronize());
+	return 0;
+}
+
 // one read of `len` bases from the window that starts at p (rev: its reverse complement), with substitutions and at most one
 // 1-base indel; written as bwa_seq_t.seq (read reversed) and .rseq (reverse complement) codes (bwaseqio.c:294-297)
 __device__ void gen_read(const uint8_t *t, size_t p, bool rev, uint64_t h, int len, uint32_t sub_ppm, uint32_t indel_ppm, uint8_t *s, uint8_t *q)

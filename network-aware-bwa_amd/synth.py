@@ -79,6 +79,14 @@ def synth_text(n, seed, n_dup=0, dup_len=0, device=0):
     return DevArray(p.value, int(n), device)
 
 
+def synth_text_repeats(n, seed, device=0):
+    """random ACGT with planted repeat families (LINE-like, Alu-like with a young subfamily, tandem repeats; synth_index.hip)"""
+    p = _P()
+    lib().nabwa_synth_text_repeats.argtypes = [C.c_int, C.c_uint64, C.c_uint64, _P]
+    _chk(lib().nabwa_synth_text_repeats(device, int(n), int(seed), C.byref(p)))
+    return DevArray(p.value, int(n), device)
+
+
 def build_index(d_text, n, reverse, sa_intv=32, with_sa=True, device=0, verbose=False):
     """-> (bwt_words DevArray, n_words, sa_words DevArray|None, n_sa_words): content of .bwt/.sa files"""
     bw, sw = _P(), _P()

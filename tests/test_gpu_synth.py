@@ -74,3 +74,46 @@ def test_synthetic_genome_end_to_end_vs_oracle():
     for p in parts:
         p[0].free()
         p[2].free()
+
+
+def test_repeat_genome_with_the_deepest_interval_table(monkeypatch):
+    """A genome with the repeat families of `bench.py --repeats` (homopolymer and short-unit tandem repeats among them), searched
+    with the interval table at its full depth T = 16, where a path key uses all 32 bits: the all-T key 0xffffffff must survive the
+    "interval not empty" test of the key-form expansion (round 2: it did not -- reads from poly-T stretches lost a hit; the uniform
+    genome has no such reads, and smaller genomes pick a smaller T).  Rows and max_entries against the oracle."""
+    monkeypatch.setenv("NABWA_KMER_T", "16")
+    n = 40_000_003
+    d_text = synth.synth_text_repeats(n, 7)
+    text = d_text.to_host(np.uint8, n)
+    run = np.flatnonzero(np.convolve((text == 3).astype(np.int32), np.ones(16, np.int32), "valid") == 16)
+    assert len(run) > 100, "the genome must hold poly-T stretches"
+    parts = [synth.build_index(d_text, n, rev, 32, True) for rev in (0, 1)]
+    ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]),
+                                 (parts[0][2].ptr, parts[0][3]), (parts[1][2].ptr, parts[1][3]), device_ptrs=True)
+    assert ix.export(0, 4, 0, 1)[0] == 16
+    seq, rseq, off = synth.synth_reads(d_text, n, 60000, 100, 3000, 0, 9)
+    # plus reads cut straight out of homopolymer loci (both strands end up starting with sixteen T)
+    extra = []
+    for p in run[:: max(1, len(run) // 400)][:400]:
+        w = text[max(0, p - 50):max(0, p - 50) + 100]
+        if len(w) == 100:
+            extra.append(w[::-1].copy())                      # bwa_seq_t.seq: the read reversed
+    es = np.concatenate(extra)
+    seq = np.concatenate([seq, es]); rseq = np.concatenate([rseq, (3 - es).astype(np.uint8)])
+    off = np.concatenate([off, off[-1] + 100 * np.arange(1, len(extra) + 1)]).astype(np.int64)
+    opt = nabwa.gap_init_opt()
+    got, gmax = ix.cal_sa_reg_gap(opt, seq, rseq, off)
+    h0 = parts[0][0].to_host(np.uint32, parts[0][1])
+    h1 = parts[1][0].to_host(np.uint32, parts[1][1])
+    olib = T.load_oracle()
+    oh = olib.orc_index_wrap(T.ptr(h0), len(h0), T.ptr(h1), len(h1))
+    want, wmax = T.oracle_cal_sa_reg_gap(olib, oh, T.default_opt(), seq, rseq, off, n_threads=16)
+    bad = [i for i in range(len(got)) if got[i].tobytes() != want[i].tobytes()]
+    assert not bad, "%d reads differ, first %d" % (len(bad), bad[0])
+    assert np.array_equal(gmax, wmax)
+    assert sum(len(w) > 1 for w in want) > 200              # repeats: reads with several hit rows
+    ix.close()
+    d_text.free()
+    for p in parts:
+        p[0].free()
+        p[2].free()
