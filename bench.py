@@ -216,7 +216,8 @@ def main():
         bytes_w = 48 * t_width + half_reads
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic() if headline else None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": pmc_traffic() if headline else (pmc_traffic(True) if (args.adna and n == GRCH38_LEN and args.reads == 1_000_000) else None),
                     "kernel": ("fm_deep_kernel (one search per wavefront) + fm_search_kernel<false,false> before it" if deep else
                                "fm_search_kernel<false,false> (one read per lane) + fm_deep_kernel for the searches it hands on"),
                     "kernel_ms": round(k_ms, 3), "search_kernel_ms": round(s_ms, 3), "deep_kernel_ms": round(d_ms, 3),
@@ -402,6 +403,7 @@ def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backen
     po = nabwa.pe_opt_default()
     full = np.full(2 * N, L, np.int32)
     batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
+    rec_buf = (nabwa.PeRec * (2 * N))()          # the per-end records (3 KB each), allocated once as a streaming caller would
 
     def barrier():
         if dist is not None:
@@ -415,7 +417,7 @@ def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backen
         t.append(time.time())
         n_aln, rows, _ = batch.fetch_flat()
         t.append(time.time())
-        recs, _ = ix.pe_posn_flat(opt, off, full, n_aln, rows, nabwa.srand48_state(11))
+        recs, _ = ix.pe_posn_flat(opt, off, full, n_aln, rows, nabwa.srand48_state(11), out=rec_buf)
         t.append(time.time())
         h = np.zeros(100000, np.uint16)
         L_ = nabwa.lib()
@@ -585,14 +587,14 @@ def adna_profile(seq, n_reads, L, seed):
     return np.ascontiguousarray(s), np.ascontiguousarray(r), off
 
 
-def pmc_traffic():
+def pmc_traffic(adna=False):
     """HBM bytes of one search-kernel launch from the committed counter pass of this kernel version (profiles/:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc.sh; both are 64-byte fabric requests
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc.sh -> profiles/r02_pmc.json; both are 64-byte fabric requests
     for this kernel's 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when the
     file is missing -- counters cannot be collected from inside the timed run."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v9_pmc.json")
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_adna.json" if adna else "r02_pmc.json")
     try:
-        d = json.load(open(f))["S"]
+        d = json.load(open(f))["D" if adna else "S"]        # the dominant kernel: S on the headline workload, D on the ancient-DNA one
         return round((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, 0)
     except Exception:
         return None

@@ -107,6 +107,9 @@ float nabwa_batch_last_deep_ms(nabwa_batch_t *b);
 int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, uint64_t *n_bucket_width);
 int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t *aln_out, int64_t aln_cap, int64_t *n_rows,
 					  int32_t *max_entries);
+/* tests: what kernel W computes (the four bwt_cal_width passes, bwtaln.c:52-76,123-130) for reads [first, first + n): rows of
+ * max_len + 1 widths and bound bytes (min(bid, 127) | (w[p-1] == w[p]) << 7) per read and strand; seed bounds seed_len + 1 wide */
+int nabwa_batch_width_records(nabwa_batch_t *b, int first, int n, uint32_t *w_out, uint8_t *bid_out, uint8_t *seed_bid_out);
 /* order-independent 64-bit checksum of (read id, row index, row) over all hits, computed on the device */
 int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_rows);
 void nabwa_batch_destroy(nabwa_batch_t *b);

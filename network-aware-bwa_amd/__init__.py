@@ -329,10 +329,11 @@ class Index:
         _chk(L.nabwa_index_set_reference(self._h, int(l_pac), int(seed), n_contigs, names, _ptr(offs), _ptr(lens), 0, None, None, None, _ptr(pac)))
         return nm, offs, lens
 
-    def pe_posn_flat(self, opt, off, full_len, n_aln, rows, rng_state):
+    def pe_posn_flat(self, opt, off, full_len, n_aln, rows, rng_state, out=None):
         """nabwa_pe_posn on flat arrays (n_aln per read, rows back to back) -> (PeRec array, new rng state)"""
         n = len(off) - 1
-        out = (PeRec * max(n, 1))()
+        if out is None:
+            out = (PeRec * max(n, 1))()
         st = C.c_uint64(rng_state)
         _chk(lib().nabwa_pe_posn(self._h, C.byref(opt), n // 2, _ptr(np.ascontiguousarray(off, np.int64)), _ptr(np.ascontiguousarray(full_len, np.int32)),
                                  _ptr(np.ascontiguousarray(n_aln, np.int32)), _ptr(np.ascontiguousarray(rows)), C.byref(st), out))

@@ -1150,25 +1150,28 @@ __global__ __launch_bounds__(256) void collect_kernel(int n, const uint8_t *__re
 
 // The same, in the order kernel D should start them: its launch ends with its longest search, so the searches that look
 // longest go first.  Key = max_diff - (the lower bound of the read's differences from kernel W: the smaller restart count of
-// its two strands): the more differences the bounds leave open, the larger the tree.  One pass per key value, largest first.
+// its two strands): the more differences the bounds leave open, the larger the tree; reads that filled the first pass's hit list
+// (repeat families: hundreds of hit rows, every one-difference variant walked to the end) go before everything else.  One pass per
+// key value, largest first.
 __global__ __launch_bounds__(256) void collect_keyed_kernel(int n, const uint8_t *__restrict__ status, int32_t *__restrict__ ids,
 															unsigned int *__restrict__ count, int which, const uint8_t *__restrict__ cls,
-															const uint8_t *__restrict__ md, int lo, int hi)
+															const uint8_t *__restrict__ md, int lo, int hi, const int32_t *__restrict__ n_aln, int aln_cap, int max_key)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n || status[i] != which) return;
 	const int c0 = cls[2 * (size_t)i], c1 = cls[2 * (size_t)i + 1];
-	const int k = (int)md[i] - (c0 < c1 ? c0 : c1);
+	int k = (int)md[i] - (c0 < c1 ? c0 : c1);
+	if (n_aln[i] >= aln_cap) k = max_key;          // the first pass filled its hit list: a read from a repeat family, the longest searches there are
 	if (k >= lo && k <= hi) ids[atomicAdd(count, 1u)] = i;
 }
 
 extern "C" void nabwa_launch_collect_keyed(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which,
-										   const uint8_t *cls, const uint8_t *md, int max_key, hipStream_t s)
+										   const uint8_t *cls, const uint8_t *md, int max_key, const int32_t *n_aln, int aln_cap, hipStream_t s)
 {
 	if (n <= 0) return;
 	for (int key = max_key; key >= 0; --key)
 		hipLaunchKernelGGL(collect_keyed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, status, ids, count, which, cls, md,
-						   key ? key : -0x7fffffff, key == max_key ? 0x7fffffff : key);
+						   key ? key : -0x7fffffff, key == max_key ? 0x7fffffff : key, n_aln, aln_cap, max_key);
 }
 
 // ids of the reads whose status is `which` (NABWA_ST_OVERFLOW after kernel S, NABWA_ST_POOL / NABWA_ST_HITCAP after kernel D)

@@ -33,7 +33,7 @@ void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int al
 void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which, hipStream_t s);
 void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s);
 void nabwa_launch_collect_keyed(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which,
-								const uint8_t *cls, const uint8_t *md, int max_key, hipStream_t s);
+								const uint8_t *cls, const uint8_t *md, int max_key, const int32_t *n_aln, int aln_cap, hipStream_t s);
 int nabwa_deep_occupancy(int ns, int lds_rd);
 void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s);
 void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
@@ -686,7 +686,7 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	}
 	HIPCHK(hipEventRecord(b->ev1, b->stream));
 	/* the reads the first pass hands on, in the order kernel D should start them (largest-looking searches first) */
-	if (b->class_sort && env_int("NABWA_DEEP_ORDER", 1)) nabwa_launch_collect_keyed(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->d_cls, b->d_md, 6, b->stream);
+	if (b->class_sort && env_int("NABWA_DEEP_ORDER", 1)) nabwa_launch_collect_keyed(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->d_cls, b->d_md, 7, b->d_naln, b->P.aln_cap, b->stream);
 	else nabwa_launch_collect(b->n, b->d_status, b->d_ovf_ids, b->d_novf, NABWA_ST_OVERFLOW, b->stream);
 	HIPCHK(hipGetLastError());
 	return NABWA_OK;
@@ -921,6 +921,33 @@ extern "C" int nabwa_batch_count_touches(nabwa_batch_t *b, uint64_t *n_bucket, u
 				t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15]);
 		fprintf(stderr, "[nabwa] the %llu reads over 8000 trips: %llu trips = expansions key-form %llu, rows two-bucket %llu, rows one-bucket %llu, text %llu (of all: %llu with gaps); pops %llu, tail steps %llu, jumps %llu\n",
 				t[16], t[17], t[18], t[19], t[20], t[21], t[25], t[22], t[23], t[24]);
+	}
+	return NABWA_OK;
+}
+
+/* Tests: the records kernel W writes for reads [first, first + n), unpacked: per read and strand the len + 1 interval widths
+ * and lower bounds of the full pass (bwt_cal_width, bwtaln.c:52-76, 123-124) and the seed_len + 1 bounds of the seed pass
+ * (:126-130; only for reads longer than the seed).  Runs kernel W alone on a fresh record.  Rows are max_len + 1 wide. */
+extern "C" int nabwa_batch_width_records(nabwa_batch_t *b, int first, int n, uint32_t *w_out, uint8_t *bid_out, uint8_t *seed_bid_out)
+{
+	if (!b || first < 0 || n < 0 || first + n > b->n || (n && (!w_out || !bid_out))) return fail(NABWA_EINVAL, "bad argument");
+	if (n == 0) return NABWA_OK;
+	HIPCHK(hipSetDevice(b->ix->device));
+	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
+	SearchParams PW = b->P; PW.ids = 0; PW.rd_cls = 0; PW.touch_counter = 0;
+	nabwa_launch_fm_width(&PW, b->n_blocks_w, b->stream);
+	HIPCHK(hipGetLastError());
+	std::vector<uint8_t> rec((size_t)n * b->P.wstride);
+	HIPCHK(hipMemcpyAsync(rec.data(), b->d_wdata + (size_t)first * b->P.wstride, rec.size(), hipMemcpyDeviceToHost, b->stream));
+	HIPCHK(hipStreamSynchronize(b->stream));
+	const int W = b->max_len + 1, SW = b->opt.seed_len + 1;
+	for (int i = 0; i < n; ++i) {
+		const uint8_t *r = rec.data() + (size_t)i * b->P.wstride;
+		for (int x = 0; x < 2; ++x) {
+			memcpy(w_out + ((size_t)i * 2 + x) * W, (const uint32_t*)r + x * b->P.WL, 4 * (size_t)W);
+			memcpy(bid_out + ((size_t)i * 2 + x) * W, r + b->P.woff_bid + x * b->P.WLB, (size_t)W);
+			if (seed_bid_out && b->max_len > b->opt.seed_len && SW <= (int)b->P.SLB) memcpy(seed_bid_out + ((size_t)i * 2 + x) * SW, r + b->P.woff_sbid + x * b->P.SLB, (size_t)SW);
+		}
 	}
 	return NABWA_OK;
 }

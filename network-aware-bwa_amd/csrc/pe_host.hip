@@ -13,52 +13,52 @@
 #define MAX_ISIZE 100000          /* insert_size.c:47 */
 #define OUTLIER_BOUND 2.0         /* bwape.h:34 */
 
-/* infer_isize_hist (insert_size.c:50-139): quartiles of the histogram -> outlier bounds -> mean / sigma of the
- * inliers -> the upper bound beyond which a pair is more likely chimeric than just long (erfc scan in steps of
- * 0.01 sigma).  Quirk kept: the sum of squares starts from the -1.0 the field was initialised with (:60,:106).
- * Returns 0 when usable, -1 otherwise (fields then as the reference leaves them). */
+/* infer_isize_hist (insert_size.c:50-139) on a histogram of outer distances: the quartiles give outlier bounds, the inliers a
+ * mean and a standard deviation, and a scan over multiples of sigma gives the distance beyond which a pair is more likely
+ * chimeric than merely long.  The doubles must come out bit for bit (they are thresholds of pairing and of the rescue windows),
+ * so the arithmetic keeps the reference's types and order where a result depends on it:
+ *   - the quartile of fraction f is the bin whose cumulative count first exceeds tot * f + 0.5;
+ *   - the inlier sum adds hist[i] * i as a 32-bit int product (it wraps for bins the reference could not have filled either);
+ *   - the sum of squared deviations starts from the -1.0 the field is initialised with (insert_size.c:60,106);
+ *   - the scan steps y by 0.01 in double, from 1.0, and stops below 10.0.
+ * The reference's skewness and kurtosis only go to its log line and are not computed.  0 = usable, -1 = not (fields as the
+ * reference leaves them: avg = std = -1, bounds 0). */
 extern "C" int nabwa_isize_infer(const uint16_t *hist, double ap_prior, int64_t L, nabwa_isize_t *ii)
 {
 	if (!hist || !ii) return nabwa_fail(NABWA_EINVAL, "null argument");
-	int tot = 0, cum = 0, p25 = 0, p50 = 0, p75 = 0, n = 0;
-	uint64_t x = 0, n_ap = 0;
-	double skewness = 0.0, kurtosis = 0.0, y;
 	ii->avg = ii->std = -1.0;
 	ii->low = ii->high = ii->high_bayesian = 0;
-	for (int i = 0; i != MAX_ISIZE; ++i) tot += hist[i];
+	int tot = 0;
+	for (int i = 0; i < MAX_ISIZE; ++i) tot += hist[i];
 	if (tot < 20) return -1;                                   /* too few good pairs; ap_prior untouched */
-	for (int i = 0; i != MAX_ISIZE; ++i) {
-		const int cum2 = cum + hist[i];
-		if (cum <= tot * 0.25 + 0.5 && cum2 > tot * 0.25 + 0.5) p25 = i;
-		if (cum <= tot * 0.50 + 0.5 && cum2 > tot * 0.50 + 0.5) p50 = i;
-		if (cum <= tot * 0.75 + 0.5 && cum2 > tot * 0.75 + 0.5) p75 = i;
-		cum = cum2;
-	}
-	(void)p50;
-	const int tmp = (int)(p25 - OUTLIER_BOUND * (p75 - p25) + .499);
-	ii->low = tmp > 1 ? (uint32_t)tmp : 1u;
-	ii->high = (uint32_t)(int)(p75 + OUTLIER_BOUND * (p75 - p25) + .499);
-	for (int i = 0; i < MAX_ISIZE; ++i)
-		if ((uint32_t)i >= ii->low && (uint32_t)i <= ii->high) { n += hist[i]; x += (uint64_t)(int64_t)(int32_t)((uint32_t)hist[i] * (uint32_t)i); }   /* int product, as in the reference */
-	ii->avg = (double)x / n;
-	for (int i = 0; i < MAX_ISIZE; ++i)
-		if ((uint32_t)i >= ii->low && (uint32_t)i <= ii->high) {
-			const double t = (i - ii->avg) * (i - ii->avg);
-			ii->std += t * hist[i];
-			skewness += t * (i - ii->avg) * hist[i];
-			kurtosis += t * t * hist[i];
+	int q25 = 0, q75 = 0;
+	{
+		const double t25 = tot * 0.25 + 0.5, t75 = tot * 0.75 + 0.5;
+		int below = 0;
+		for (int i = 0; i < MAX_ISIZE; ++i) {
+			const int upto = below + hist[i];
+			if (below <= t25 && upto > t25) q25 = i;
+			if (below <= t75 && upto > t75) q75 = i;
+			below = upto;
 		}
-	kurtosis = kurtosis / n / (ii->std / n * ii->std / n) - 3;
-	ii->std = sqrt(ii->std / n);
-	skewness = skewness / n / (ii->std * ii->std * ii->std);
-	(void)skewness; (void)kurtosis;
-	for (y = 1.0; y < 10.0; y += 0.01)
-		if (.5 * erfc(y / M_SQRT2) < ap_prior / L * (y * ii->std + ii->avg)) break;
+	}
+	const int lo = (int)(q25 - OUTLIER_BOUND * (q75 - q25) + .499);
+	ii->low = lo > 1 ? (uint32_t)lo : 1u;
+	ii->high = (uint32_t)(int)(q75 + OUTLIER_BOUND * (q75 - q25) + .499);
+	const uint32_t first = ii->low, last = ii->high < (uint32_t)(MAX_ISIZE - 1) ? ii->high : (uint32_t)(MAX_ISIZE - 1);
+	int n_in = 0; uint64_t sum = 0;
+	for (uint32_t i = first; i <= last; ++i) { n_in += hist[i]; sum += (uint64_t)(int64_t)(int32_t)((uint32_t)hist[i] * i); }
+	ii->avg = (double)sum / n_in;
+	for (uint32_t i = first; i <= last; ++i) { const double dev = (int)i - ii->avg; ii->std += dev * dev * hist[i]; }
+	ii->std = sqrt(ii->std / n_in);
+	double y = 1.0;
+	while (y < 10.0 && !(.5 * erfc(y / M_SQRT2) < ap_prior / L * (y * ii->std + ii->avg))) y += 0.01;
 	ii->high_bayesian = (uint32_t)(y * ii->std + ii->avg + .499);
-	for (int i = 0; i < MAX_ISIZE; ++i) if ((uint32_t)i > ii->high_bayesian) n_ap += hist[i];
-	ii->ap_prior = .01 * (n_ap + .01) / tot;
+	uint64_t beyond = 0;
+	for (uint32_t i = ii->high_bayesian + 1; i < (uint32_t)MAX_ISIZE; ++i) beyond += hist[i];
+	ii->ap_prior = .01 * (beyond + .01) / tot;
 	if (ii->ap_prior < ap_prior) ii->ap_prior = ap_prior;
-	if (isnan(ii->std) || p75 > MAX_ISIZE) {
+	if (isnan(ii->std) || q75 > MAX_ISIZE) {
 		ii->low = ii->high = ii->high_bayesian = 0; ii->avg = ii->std = -1.0;
 		return -1;
 	}

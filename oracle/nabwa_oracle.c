@@ -278,6 +278,15 @@ static void cal_width(const orc_bwt_t *rb, int len, const uint8_t *str, width_t 
 	width[len].bid = ++bid;
 }
 
+/* the same for the tests of kernel W: widths and bounds of one pass as two flat arrays of len + 1 entries */
+void orc_cal_width(const orc_bwt_t *rb, int len, const uint8_t *str, uint32_t *w_out, int32_t *bid_out)
+{
+	width_t *w = (width_t*)calloc(len + 1, sizeof(width_t)); int i;
+	cal_width(rb, len, str, w);
+	for (i = 0; i <= len; ++i) { w_out[i] = w[i].w; bid_out[i] = w[i].bid; }
+	free(w);
+}
+
 /* ------------------------------------------------------------------ priority stack */
 
 enum { ST_M = 0, ST_I = 1, ST_D = 2 };

@@ -80,6 +80,8 @@ uint32_t orc_occ(const orc_bwt_t *b, uint32_t k, int c);
 void orc_occ4(const orc_bwt_t *b, uint32_t k, uint32_t cnt[4]);
 void orc_2occ4(const orc_bwt_t *b, uint32_t k, uint32_t l, uint32_t ck[4], uint32_t cl[4]);
 uint32_t orc_sa(const orc_bwt_t *b, uint32_t k);
+/* bwt_cal_width (bwtaln.c:52-76) of one pass: w_out / bid_out get len + 1 entries */
+void orc_cal_width(const orc_bwt_t *rb, int len, const uint8_t *str, uint32_t *w_out, int32_t *bid_out);
 int orc_maxdiff(int l, double err, double thres);
 void orc_default_opt(orc_opt_t *o);
 

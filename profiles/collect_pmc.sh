@@ -15,7 +15,7 @@ GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_
 i=0
 for g in "${GROUPS_[@]}"; do
   d=$OUT/g$i; i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $g -d "$d" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu > "$d.json" 2> "$d.err" || echo "group '$g' failed (see $d.err)"
+  timeout -k 10 300 rocprofv3 --pmc $g -d "$d" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e > "$d.json" 2> "$d.err" || echo "group '$g' failed (see $d.err)"
 done
 python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"

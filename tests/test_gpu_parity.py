@@ -449,3 +449,35 @@ def test_sai_parity_in_every_index_configuration(monkeypatch, env):
             assert not bad, "%s: GPU differs from the reference .sai for %d reads, e.g. %s" % (name, len(bad), bad[:5])
     finally:
         ix.close()
+
+
+def test_width_kernel_output_matches_bwt_cal_width(gix, olib, oix):
+    """kernel W directly (not through the search's rows): interval widths, lower bounds and the "same width as before" flag of
+    the full passes, lower bounds of the seed passes, for both strands of reads of several lengths incl. N and reads shorter
+    than the seed -- against the oracle's bwt_cal_width (bwtaln.c:52-76)"""
+    rng = np.random.default_rng(31)
+    reads = random_reads(rng, 400, toy_genome(), lens=(20, 32, 33, 50, 76, 100), err=0.03)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    opt = T.default_opt()
+    b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+    n, W, SW = len(reads), 101, opt.seed_len + 1
+    w = np.zeros((n, 2, W), np.uint32); bid = np.zeros((n, 2, W), np.uint8); sbid = np.zeros((n, 2, SW), np.uint8)
+    L = nabwa.lib()
+    L.nabwa_batch_width_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.nabwa_batch_width_records(b._h, 0, n, T.ptr(w), T.ptr(bid), T.ptr(sbid)) == 0, L.nabwa_last_error()
+    olib.orc_cal_width.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    ow = np.zeros(W, np.uint32); ob = np.zeros(W, np.int32)
+    for i in range(n):
+        ln = int(off[i + 1] - off[i])
+        for x, arr in ((0, seq), (1, rseq)):
+            s = np.ascontiguousarray(arr[off[i]:off[i + 1]])
+            olib.orc_cal_width(oix.bwt(x), ln, T.ptr(s), T.ptr(ow), T.ptr(ob))
+            assert np.array_equal(w[i, x, :ln + 1], ow[:ln + 1]), (i, x)
+            assert np.array_equal(bid[i, x, :ln + 1] & 127, np.minimum(ob[:ln + 1], 127)), (i, x)
+            same = np.concatenate([[False], ow[1:ln + 1] == ow[:ln]])
+            assert np.array_equal(bid[i, x, :ln + 1] >> 7 != 0, same), (i, x)
+            if ln > opt.seed_len:
+                t = np.ascontiguousarray(s[ln - opt.seed_len:])
+                olib.orc_cal_width(oix.bwt(x), opt.seed_len, T.ptr(t), T.ptr(ow), T.ptr(ob))
+                assert np.array_equal(sbid[i, x, :SW] & 127, np.minimum(ob[:SW], 127)), (i, x)
+    b.close()
