@@ -593,6 +593,8 @@ def pmc_traffic(adna=False):
     for this kernel's 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when the
     file is missing -- counters cannot be collected from inside the timed run."""
     f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_adna.json" if adna else "r02_pmc.json")
+    if any(k in os.environ for k in ("NABWA_KMER_T", "NABWA_TEXT_MODE", "NABWA_TRIP_BUDGET")):
+        return None                                          # not the configuration the counter pass was taken on
     try:
         d = json.load(open(f))["D" if adna else "S"]        # the dominant kernel: S on the headline workload, D on the ancient-DNA one
         return round((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, 0)

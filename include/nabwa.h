@@ -253,7 +253,8 @@ void nabwa_pe_opt_default(nabwa_pe_opt_t *po);
  * se.flag is the final SAM flag; extra_flag is bwa_seq_t.extra_flag (paired / read1 / read2 / proper pair). */
 typedef struct {
 	nabwa_se_t se;
-	int32_t extra_flag, m_seqid, am, pad;
+	int32_t extra_flag, m_seqid, am;
+	int32_t mapQ_paired;                                   /* se.mapQ as pairing left it; se.mapQ itself is cleared when the hit bridges two contigs (bam2bam.c:453-458) */
 	int64_t m_rpos, isize;                                 /* mate position (1-based, on contig m_seqid), template length */
 } nabwa_pe_t;
 

@@ -73,7 +73,7 @@ class PeOpt(C.Structure):
 
 class PeRec(C.Structure):
     """nabwa_pe_t: one end of a finished pair"""
-    _fields_ = [("se", SeRec), ("extra_flag", C.c_int32), ("m_seqid", C.c_int32), ("am", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("se", SeRec), ("extra_flag", C.c_int32), ("m_seqid", C.c_int32), ("am", C.c_int32), ("mapQ_paired", C.c_int32),
                 ("m_rpos", C.c_int64), ("isize", C.c_int64)]
 
 

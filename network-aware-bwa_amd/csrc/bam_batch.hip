@@ -546,7 +546,7 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	rc = nabwa_se_posn_strided(b->ix, &b->opt, n, b->off.data(), b->full_len.data(), b->n_aln.data(), b->rows.data(), n_occ.data(), rng48, b->res, sizeof(nabwa_pe_t));
 	if (rc != NABWA_OK) return rc;
 	bam_parallel((size_t)n, [&](int, size_t lo, size_t hi) {
-		for (size_t i = lo; i < hi; ++i) { nabwa_pe_t &r = b->res[i]; r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.pad = 0; r.m_rpos = 0; r.isize = 0; }
+		for (size_t i = lo; i < hi; ++i) { nabwa_pe_t &r = b->res[i]; r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.mapQ_paired = 0; r.m_rpos = 0; r.isize = 0; }
 	});
 	/* improve_isize_est (insert_size.c:141-165) */
 	for (size_t k = 0; k < b->kind.size(); ++k) {

@@ -267,7 +267,7 @@ extern "C" int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt
 	for (int i = 0; i < n; ++i) {
 		memset(&recs[i], 0, offsetof(nabwa_pe_t, se) + offsetof(nabwa_se_t, cigar));
 		se_from_seq(seqs[i], recs[i].se);
-		recs[i].extra_flag = (int)(seqs[i].bits0 >> 24); recs[i].m_seqid = 0; recs[i].am = 0; recs[i].pad = 0; recs[i].m_rpos = 0; recs[i].isize = 0;
+		recs[i].extra_flag = (int)(seqs[i].bits0 >> 24); recs[i].m_seqid = 0; recs[i].am = 0; recs[i].mapQ_paired = 0; recs[i].m_rpos = 0; recs[i].isize = 0;
 	}
 	rc = nabwa_pe_finish(ix, opt, popt, ii, n_pairs, F.off.data(), F.seq.data(), F.rseq.data(), F.n_aln.data(), F.aln.data(), recs.data(), n_tot, n_mapped);
 	if (rc != NABWA_OK) return rc;
@@ -275,6 +275,7 @@ extern "C" int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt
 		nabwa_bwa_seq_t &q = seqs[i];
 		const int L = (int)(q.bits0 & 0xfffffu);
 		for (int a = 0, b = L - 1; a < b; ++a, --b) { const uint8_t t = q.seq[a]; q.seq[a] = q.seq[b]; q.seq[b] = t; }
+		recs[i].se.mapQ = recs[i].mapQ_paired;                       /* the bridging rule is bwa_update_bam1's, not this phase's */
 		seq_scalars_from_se(recs[i].se, q, recs[i].extra_flag);
 		seq_multi_from_se(recs[i].se, q);
 		seq_alignment_from_se(recs[i].se, q);

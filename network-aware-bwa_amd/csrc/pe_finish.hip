@@ -332,6 +332,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 			for (int j = 0; j < 2; ++j) {                              /* end 0 first, as bam2bam.c:804-805 */
 				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &p = r.se;
 				const nabwa_se_t &mate = PE(out, pr, 1 - j).se;
+				r.mapQ_paired = p.mapQ;
 				if (p.type == 0 && mate.type == 0) {
 					p.flag = (r.extra_flag & ~(F_PP | F_MU)) | F_SU | F_MU;
 					p.seqid = -1; p.rpos = 0; p.nn = 0; p.xt = 0; r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0;

@@ -145,3 +145,110 @@ def test_pe_phases_on_reference_records(ref):
                 b = {k: b[k] for k in ("n_multi", "cigar", "md")}
             assert a == b, (reads[i][0], iiv[0], {k: (a[k], b[k]) for k in a if a[k] != b[k]})
     ix.close()
+
+
+def make_150bp_pairs(n_pairs, seed):
+    """2 x 150 bp pairs off the toy genome the way BASELINE config 3 describes them: inserts ~ N(400, 40), 2 % substitutions, 10 % of
+    the reads with a 1-base indel >= 15 bp from the ends, FR orientation from either strand; a quarter of the pairs discordant (the
+    mate from somewhere else, in the wrong orientation, or with too many differences for the search) so that pairing fails and
+    mate rescue (bwa_paired_sw1) is tried"""
+    from test_gpu_parity import toy_genome
+    rng = np.random.default_rng(seed)
+    genome = toy_genome()
+    comp = str.maketrans("ACGTN", "TGCAN")
+
+    def mutate(s):
+        s = list(s)
+        for j in range(len(s)):
+            if rng.random() < 0.02:
+                s[j] = "ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.10:
+            q = int(rng.integers(15, len(s) - 15))
+            if rng.random() < 0.5:
+                del s[q]
+                s.append("A")
+            else:
+                s.insert(q, "ACGT"[int(rng.integers(0, 4))])
+                s.pop()
+        return "".join(s)
+    r1, r2 = [], []
+    for i in range(n_pairs):
+        ins = max(160, int(rng.normal(400, 40)))
+        p = int(rng.integers(0, len(genome) - ins - 200))
+        frag = genome[p:p + ins + 2]
+        a, b = frag[:150], frag[ins - 150:ins][::-1].translate(comp)
+        if i % 8 == 3:                               # discordant: the mate comes from elsewhere
+            q = int(rng.integers(0, len(genome) - 200))
+            b = genome[q:q + 150]
+        elif i % 8 == 5:                             # too many differences for the search (max_diff 5 at 150 bp): only mate rescue finds it
+            b = list(b)
+            for q in rng.choice(150, 11, replace=False):
+                b[q] = "ACGT"[("ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) % 4]
+            b = "".join(b)
+        elif i % 8 == 7:                             # wrong orientation
+            b = b[::-1].translate(comp)
+        if rng.random() < 0.5:
+            a, b = b, a
+        r1.append(("p%d" % i, mutate(a), "I" * 150))
+        r2.append(("p%d" % i, mutate(b), "I" * 150))
+    return r1, r2
+
+
+def test_pe_chain_at_150bp_with_indels_and_discordant_pairs(ref):
+    """BASELINE config 3's read shape (2 x 150 bp, 2 % error, indel reads, discordant pairs): the search of both ends against the
+    reference's bwa_cal_sa_reg_gap, then posn_pair / finish_pair on the reference's own records against its own functions
+    (pairing, bwa_paired_sw1 with accepted rescues, bwa_refine_gapped), every field"""
+    rlib, rix = ref
+    r1, r2 = make_150bp_pairs(600, 77)
+    n_pairs = len(r1)
+    reads = [r for pr in zip(r1, r2) for r in pr]
+    seq, rseq, off, full = T.encode_reads(reads)
+    opt = T.default_opt()
+    g = nabwa.GapOpt()
+    C.memmove(C.byref(g), C.byref(opt), 64)
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    hits, _ = ix.cal_sa_reg_gap(g, seq, rseq, off, per_read=True)
+    # the reference's own search of the same reads, one read per call as bam2bam does
+    na = np.zeros(len(reads), np.int32); rows = np.zeros(512 * len(reads), T.ALN_DT); maxe = np.zeros(len(reads), np.int32)
+    tot = rlib.ref_cal_sa_reg_gap(rix, C.byref(opt), len(reads), T.ptr(off), T.ptr(seq), T.ptr(rseq), 1, T.ptr(na), T.ptr(rows), len(rows), T.ptr(maxe))
+    assert tot >= 0
+    bnd = np.concatenate([[0], np.cumsum(na)])
+    for i in range(len(reads)):
+        assert hits[i].tobytes() == rows[bnd[i]:bnd[i + 1]].tobytes(), reads[i][0]
+    extra = [1 | (64 if i % 2 == 0 else 128) for i in range(len(reads))]
+    L = nabwa.lib()
+    L.nabwa_bwa_posn_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.nabwa_bwa_finish_pe.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    attempts = 0
+    for iiv in ([400.0, 40.0, 1e-5, 250.0, 550.0, 640.0], [0.0] * 6):
+        want, k1 = make_records(reads, seq, rseq, off, hits, full, extra)
+        rlib.ref_seed48(11)
+        rlib.ref_pe_records(rix, C.byref(opt), (C.c_double * 6)(*iiv), n_pairs, want)
+        got, k2 = make_records(reads, seq, rseq, off, hits, full, extra)
+        st = C.c_uint64(nabwa.srand48_state(11))
+        assert L.nabwa_bwa_posn_pe(ix._h, C.byref(g), n_pairs, got, C.byref(st)) == 0, L.nabwa_last_error()
+        ii = nabwa.IsizeInfo(iiv[0], iiv[1], iiv[2], int(iiv[3]), int(iiv[4]), int(iiv[5]))
+        po = nabwa.pe_opt_default()
+        tot2, mapped = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        bad = []
+        assert L.nabwa_bwa_finish_pe(ix._h, C.byref(g), C.byref(po), C.byref(ii), n_pairs, got, tot2, mapped) == 0, L.nabwa_last_error()
+        for i in range(len(reads)):
+            a, b = record_fields(got[i], 150), record_fields(want[i], 150)
+            if (want[i].bits0 >> 21 & 3) == 0:
+                a = {k: a[k] for k in ("n_multi", "cigar", "md")}
+                b = {k: b[k] for k in ("n_multi", "cigar", "md")}
+            if a != b:
+                bad.append((reads[i][0], i & 1, iiv[0], {k: (a[k], b[k]) for k in a if a[k] != b[k] and k != "seq"},
+                            "types", want[i].bits0 >> 21 & 3, want[i ^ 1].bits0 >> 21 & 3, "pos", want[i].pos, want[i ^ 1].pos,
+                            "n_aln", want[i].n_aln, want[i ^ 1].n_aln, "seQ", want[i].bits1 >> 24, want[i].c1c2seq))
+        if bad:
+            os.makedirs(os.path.join(T.ROOT, 'gpurun_out'), exist_ok=True)
+            open(os.path.join(T.ROOT, 'gpurun_out', 'pe150_bad.txt'), 'w').write('\n'.join(repr(x) for x in bad))
+        assert not bad, (len(bad), bad[:6])
+        if iiv[0]:
+            attempts = int(tot2[0] + tot2[1])
+    # bwa_paired_sw1 in this fork leaves a singleton's mate alone (bwape.c:566 returns where stock bwa continues), so an accepted
+    # rescue needs both ends mapped apart; tests/golden's PE set has 27 of those, here the window search itself is what runs often
+    assert attempts >= 40, attempts
+    assert sum(1 for i in range(len(reads)) if want[i].n_cigar > 1) >= 20          # gapped reads went through bwa_refine_gapped
+    ix.close()
