@@ -420,17 +420,7 @@ def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backen
         recs, _ = ix.pe_posn_flat(opt, off, full, n_aln, rows, nabwa.srand48_state(11), out=rec_buf)
         t.append(time.time())
         h = np.zeros(100000, np.uint16)
-        L_ = nabwa.lib()
-        v = np.frombuffer(recs, np.uint8).reshape(2 * N, C.sizeof(nabwa.PeRec))
-        se = nabwa.PeRec.se.offset
-        f = lambda name: v[:, se + getattr(nabwa.SeRec, name).offset: se + getattr(nabwa.SeRec, name).offset + 4].copy().view(np.int32)[:, 0]
-        tp, mq, pos, ln = f("type"), f("mapQ"), f("pos").view(np.uint32), f("len")
-        a, b = slice(0, 2 * N, 2), slice(1, 2 * N, 2)
-        ok = (mq[a] >= 20) & (mq[b] >= 20)              # improve_isize_est (insert_size.c:141-165), vectorised
-        p0, p1 = pos[a].astype(np.int64), pos[b].astype(np.int64)
-        d = np.where(p0 < p1, p1 + ln[b] - p0, p0 + ln[a] - p1)
-        d = d[ok & (d >= 0) & (d < 100000)]
-        np.add.at(h, d, 1)
+        nabwa.isize_add_pairs(recs, N, h)                # improve_isize_est (insert_size.c:141-165)
         rc, ii = nabwa.isize_infer(h, po.ap_prior, n)
         t.append(time.time())
         tot, mp = ix.pe_finish_flat(opt, po, ii, seq, rseq, off, n_aln, rows, recs)

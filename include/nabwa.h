@@ -270,6 +270,9 @@ int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, co
  * bwa_refine_gapped on both ends (global alignments as one GPU batch), MD / NM, flags and mate fields.
  * ii: the read group's insert-size estimate; all zeros = none (null_ii, bam2bam.c:715).
  * n_tot / n_mapped (may be NULL): the counters of bwa_paired_sw1, [0] discordant pairs, [1] singletons. */
+/* improve_isize_est (insert_size.c:141-165) for the positioned pairs of one batch: hist = 100000 uint16_t bins, wrapping as the
+ * reference's do; call between nabwa_pe_posn and nabwa_isize_infer */
+int nabwa_isize_add_pairs(int n_pairs, const nabwa_pe_t *recs, uint16_t *hist);
 int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 					int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
 					const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2]);

@@ -92,6 +92,13 @@ def isize_infer(hist, ap_prior, L):
     return rc, ii
 
 
+def isize_add_pairs(recs, n_pairs, hist):
+    """improve_isize_est (reference insert_size.c:141-165) over a batch of positioned pairs; hist: 100000 uint16 bins"""
+    assert hist.dtype == np.uint16 and hist.flags.c_contiguous
+    lib().nabwa_isize_add_pairs.argtypes = [C.c_int, _P, _P]
+    _chk(lib().nabwa_isize_add_pairs(int(n_pairs), C.cast(recs, _P), _ptr(hist)))
+
+
 def pairing(ends, hits, rows0, rows1, max_isize, s_mm, ii):
     """pairing (reference bwape.c:180-293); ends: (PeEnd * 2), modified in place; returns cnt_chg"""
     hits = np.ascontiguousarray(hits, np.uint64)

@@ -5,7 +5,9 @@
 #include "fm_deep_body.hpp"
 
 #ifndef NABWA_DEEP_WAVES
-#define NABWA_DEEP_WAVES 4    // waves per SIMD the register budget is bounded for (128 VGPRs): 16 searches per CU
+#define NABWA_DEEP_WAVES 3    // waves per SIMD the register budget is bounded for (168 VGPRs, 13 spilled dwords): 12 searches per CU.  Measured on
+                              // the aDNA workload (1 M reads): 2 / 3 / 4 / 5 waves -> 1074 / 1488 / 2383 / 4611 wave-seconds in all, i.e. 0.52 / 0.48 / 0.58 /
+                              // 0.90 s of work per wave: every spilled dword is a scratch access in the same in-order queue as the gathers
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];

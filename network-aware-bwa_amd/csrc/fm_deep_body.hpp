@@ -102,7 +102,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	uint32_t n_own = 0, n_free = 0;
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
-	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;      // the longest single read of this wave: time, rounds; time in reads altogether
+	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
+	unsigned long long ph_pop = 0, ph_chain = 0, ph_tail = 0, ph_commit = 0, ph_hit = 0, st_tailit = 0;      // (statistics) time per phase of a round
+	const bool prof = P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
 	const unsigned long long clk_start = DEEP_CLOCK();
 	// text mode (nabwa_dev.hpp): an exact tail that has narrowed to ONE row is finished by comparing the read with the text
 	const bool text_ok = (S.text_mode & 2) && S.bwt[0].sa_full && S.bwt[1].sa_full && S.bwt[0].isa && S.bwt[1].isa && S.bwt[0].text && S.bwt[1].text;
@@ -208,6 +210,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					if (mk) { cur = base + (uint32_t)deep_ctz64(mk); found = true; }
 				}
 				if (!found) break;     // only children that were counted but never stored are left: the reference pops one of them and stops (bwtgap.c:144)
+				const unsigned long long pc0 = prof ? DEEP_CLOCK() : 0ull;
 				const int s = (int)cur;
 				if (!nonstop && n_aln > 0 && s > best_score + S.s_mm) break;      // bwtgap.c:144
 				const uint32_t cs = WUNI(s_cnt[s]);
@@ -228,6 +231,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				}
 				++st_rounds; st_run += W; if (careful) ++st_careful;
 
+				unsigned long long pc1 = 0; if (prof) { LANES { L(tu) = L(e).k; } (void)WUNI(WBCAST(tu, 0)); pc1 = DEEP_CLOCK(); ph_pop += pc1 - pc0; }
 				// ---------------------------------------------------------------- the chains
 				while (WBALLOT(L(act)) != 0ull) {
 					++st_steps;
@@ -349,8 +353,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// has several rows; once ONE row is left (text mode, nabwa_dev.hpp) its suffix's text position, then the comparison
 				// of the i symbols still to match with the text right in front of it (str[j] against text[pos - i + j], 16 per
 				// word pair, both packed low bits first), then the row of the extended suffix from the inverse suffix array
+				unsigned long long pc2 = 0; if (prof) { pc2 = DEEP_CLOCK(); ph_chain += pc2 - pc1; }
 				LANES { L(ts) = L(flag) == DF_TAIL ? ((text_ok && L(e).k == L(e).l) ? 1 : 0) : -1; }
 				while (WBALLOT(L(ts) >= 0) != 0ull) {
+					++st_tailit;
 					LANES { if (L(ts) >= 0) {
 						DeepLane &E = L(e);
 						const bool q1 = E.a == 0;
@@ -404,6 +410,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					} }
 				}
 
+				unsigned long long pc3 = 0; if (prof) { pc3 = DEEP_CLOCK(); ph_tail += pc3 - pc2; }
 				// ---------------------------------------------------------------- commit, in the reference's order
 				const uint64_t stopm = WBALLOT(L(flag) != DF_NONE && (uint32_t)ln < W);
 				int jl = stopm ? deep_ctz64(stopm) : (int)W - 1;            // the last lane whose chain counts
@@ -411,7 +418,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				LANES { L(nst) = n_entries + (int)L(off); }                  // live entries before this lane's first pop
 				const uint64_t over = WBALLOT(ln <= jl && (int64_t)L(nst) + L(peak) > (int64_t)S.max_entries);
 				if (over) { careful = true; jl = deep_ctz64(over) - 1; }   // the cut-off (bwtgap.c:140) falls into that lane's chain
-				if (jl < 0) continue;
+				if (jl < 0) { if (prof) ph_commit += DEEP_CLOCK() - pc3; continue; }
 				{
 					int64_t mx = 0;
 					WMAX_I64(mx, ln <= jl ? (int64_t)L(nst) + L(peak) : (int64_t)0);
@@ -495,6 +502,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					}
 				}
 				if (pool_fail) { status = NABWA_ST_POOL; ++st_pool; break; }
+				unsigned long long pc4 = 0; if (prof) { pc4 = DEEP_CLOCK(); ph_commit += pc4 - pc3; }
 				if (!over && fl == DF_HIT) {
 					// ---- hit bookkeeping (bwtgap.c:166-199), the wave together
 					LANES { L(tu) = L(e).k; } const uint32_t hk = WUNI(WBCAST(tu, jl));
@@ -551,6 +559,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							WAVE_SYNC();
 						}
 					}
+					if (prof) ph_hit += DEEP_CLOCK() - pc4;
 				}
 			}
 		}
@@ -569,6 +578,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
+			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit);
 			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}

@@ -826,7 +826,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			b->d_deep_stage = 0; b->deep_stage_ent = 0;
 			HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_stage, stage_ent * 16)); b->deep_stage_ent = stage_ent;
 		}
-		if (!b->d_deep_ctr) HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_ctr, 128));
+		if (!b->d_deep_ctr) HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_ctr, 256));
 		DeepParams D;
 		memset(&D, 0, sizeof(D));
 		D.S = b->P;
@@ -853,7 +853,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			D.S.n = (int)todo; D.own_cap = (uint32_t)own_cap;
 			rebuild_widths(D.S, todo);
 			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 128, b->stream));
+			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 256, b->stream));
 			D.S.work_counter = b->d_counter;
 			if (pass == 0) HIPCHK(hipEventRecord(b->evd0, b->stream));
 			nabwa_launch_fm_deep(&D, (int)waves, b->stream);
@@ -864,10 +864,12 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			int r = recollect(NABWA_ST_POOL, &n_pool);
 			if (r != NABWA_OK) return r;
 			if (timing) {
-				unsigned long long st[16];
-				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 128, hipMemcpyDeviceToHost));
+				unsigned long long st[32];
+				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 256, hipMemcpyDeviceToHost));
 				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text; longest read %.3f s / %llu rounds, all reads %.1f wave-s, longest wave %.3f s\n",
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
+				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f\n",
+						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8);
 			}
 			todo = n_pool;
 		}

@@ -76,6 +76,20 @@ extern "C" int nabwa_isize_bin(int kind, int mapq0, int mapq1, uint32_t pos0, in
 	return len;
 }
 
+/* improve_isize_est over the positioned pairs of a batch (records interleaved 2 * pair + end, as nabwa_pe_posn leaves them):
+ * every pair whose two ends have mapQ >= 20 adds one to the bin of its outer distance; bins are the reference's uint16_t and
+ * wrap as they do there (insert_size.c:157). */
+extern "C" int nabwa_isize_add_pairs(int n_pairs, const nabwa_pe_t *recs, uint16_t *hist)
+{
+	if (n_pairs < 0 || (n_pairs && !recs) || !hist) return nabwa_fail(NABWA_EINVAL, "null argument");
+	for (int i = 0; i < n_pairs; ++i) {
+		const nabwa_se_t &a = recs[2 * (size_t)i].se, &b = recs[2 * (size_t)i + 1].se;
+		const int bin = nabwa_isize_bin(2, a.mapQ, b.mapQ, a.pos, a.len, b.pos, b.len);
+		if (bin >= 0) ++hist[bin];
+	}
+	return NABWA_OK;
+}
+
 extern "C" void nabwa_pe_opt_default(nabwa_pe_opt_t *po)            /* bwa_init_pe_opt, bwape.c:27-41 */
 {
 	if (!po) return;
@@ -90,81 +104,116 @@ static inline uint64_t mix_u64(uint64_t key)       /* the tie-breaking hash of p
 	return key;
 }
 
-static int log_n(int n) { return n > 0 ? (int)(4.343 * log((double)n) + 0.5) : 0; }     /* g_log_n, bwase.c:613-617 */
+/* ---- pairing (bwape.c:180-293) ----------------------------------------------------------------------------------------
+ * Input: every text position of every hit row of both ends, tagged pos << 32 | row << 1 | end (what finish_pair collects,
+ * bam2bam.c:737-767), and the two bwt_aln1_t arrays.  The candidates are walked in position order; a reverse-strand hit is
+ * the right end of a possible FR pair and is tried against the two most recent forward-strand hits of the other end.  A pair
+ * is ranked by (10 x summed alignment scores + insert-size penalty, then a hash of the two positions); the best pair moves
+ * the ends, the runner-up and the number of equally / less good pairs give the pair's mapping quality. */
+namespace {
 
-/* pairing (bwape.c:180-293).  hits: every text position of every hit row of both ends as
- * pos << 32 | row << 1 | end (what finish_pair collects, bam2bam.c:737-767); rows: the two bwt_aln1_t arrays.
- * Sweep the sorted positions: a reverse-strand hit pairs with the last two forward-strand hits of the other
- * end; keep the best (and second best) pair by 10*(score sum) + insert-size penalty, ties broken by the hash.
- * Then derive the paired mapping qualities and move the ends that the best pair places elsewhere. */
+struct PairRank {                       /* smaller is better; `none` = no pair seen */
+	uint32_t cost, tie; bool none;
+	bool better_than(const PairRank &o) const { return o.none || (!none && (cost < o.cost || (cost == o.cost && tie < o.tie))); }
+};
+
+struct PairSweep {
+	const nabwa_pe_end_t *end; const nabwa_aln1_t *const *rows; const nabwa_isize_t *ii;
+	uint32_t longest_read; int max_isize;
+	uint64_t recent[2][2];              /* per end: the last two forward-strand candidates, [1] the newer */
+	bool have[2][2];
+	PairRank best, second; uint64_t best_of_end[2];
+	int n_best, n_worse;                /* pairs at the best cost / at any higher cost */
+
+	const nabwa_aln1_t &row(uint64_t c) const { return rows[c & 1][(uint32_t)c >> 1]; }
+	static uint32_t where(uint64_t c) { return (uint32_t)(c >> 32); }
+	bool reverse(uint64_t c) const { return (row(c).info >> 24 & 1) != 0; }
+
+	void forward_seen(uint64_t c) { const int e = (int)(c & 1); recent[e][0] = recent[e][1]; have[e][0] = have[e][1]; recent[e][1] = c; have[e][1] = true; }
+
+	void try_pair(bool present, uint64_t left, uint64_t right)
+	{
+		if (!present || where(right) <= where(left)) return;
+		const uint32_t span = where(right) + (uint32_t)end[right & 1].len - where(left);      /* outer distance, 32-bit as bwtint_t */
+		if (span < longest_read) return;
+		const bool fits = ii->high ? span <= ii->high_bayesian : span <= (uint32_t)max_isize;
+		if (!fits) return;
+		uint64_t c = (uint64_t)(row(right).score + row(left).score);
+		c *= 10;
+		if (ii->high) c += (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * fabs(span - ii->avg) / ii->std)) + .499);
+		PairRank r; r.cost = (uint32_t)c; r.tie = (uint32_t)mix_u64((uint64_t)where(left) << 32 | where(right)); r.none = false;
+		if (!best.none && r.cost == best.cost) ++n_best;
+		else if (best.none || r.cost < best.cost) { n_worse += n_best; n_best = 1; }
+		else ++n_worse;
+		if (r.better_than(best)) { second = best; best = r; best_of_end[left & 1] = left; best_of_end[right & 1] = right; }
+		else if (r.better_than(second)) second = r;
+	}
+
+	void reverse_seen(uint64_t c) { const int mate = 1 - (int)(c & 1); try_pair(have[mate][1], recent[mate][1], c); try_pair(have[mate][0], recent[mate][0], c); }
+
+	/* the most a moved end's mapping quality can be */
+	int moved_end_quality(int s_mm) const
+	{
+		if (n_best != 1) return 0;
+		if (second.none) return 29;
+		/* the reference subtracts the upper words of two 64-bit keys; with "none" out of the way that is cost - cost */
+		const uint64_t gap = (uint64_t)second.cost - (uint64_t)best.cost;
+		if (gap > (uint64_t)(s_mm * 10)) return 23;
+		const int n = n_worse > 255 ? 255 : n_worse;
+		const int lg = n > 0 ? (int)(4.343 * log((double)n) + 0.5) : 0;          /* g_log_n[n], bwase.c:613-617 */
+		const int q = (int)(gap / 2) - lg;
+		return q < 0 ? 0 : q;
+	}
+};
+
+}
+
 extern "C" int nabwa_pairing(nabwa_pe_end_t p[2], int n_hits, uint64_t *hits, const nabwa_aln1_t *rows0, const nabwa_aln1_t *rows1,
 							 int max_isize, int s_mm, const nabwa_isize_t *ii)
 {
 	const nabwa_aln1_t *rows[2] = { rows0, rows1 };
-	int o_n = 0, subo_n = 0, cnt_chg = 0;
-	uint64_t last_pos[2][2], o_pos[2] = { 0, 0 }, subo_score = ~0ull, o_score = ~0ull;
-	int max_len = p[0].full_len; if (max_len < p[1].full_len) max_len = p[1].full_len;
-	auto rowof = [&](uint64_t v) -> const nabwa_aln1_t& { return rows[v & 1][(uint32_t)v >> 1]; };
-	auto consider = [&](uint64_t u, uint64_t v) {            /* v: reverse-strand hit; u: earlier forward hit of the mate */
-		const uint32_t l = (uint32_t)((v >> 32) + (uint32_t)p[v & 1].len - (u >> 32));
-		if (u != ~0ull && (v >> 32) > (u >> 32) && l >= (uint32_t)max_len
-			&& ((ii->high && l <= ii->high_bayesian) || (ii->high == 0 && l <= (uint32_t)max_isize))) {
-			uint64_t s = (uint64_t)(rowof(v).score + rowof(u).score);
-			s *= 10;
-			if (ii->high) s += (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + .499);
-			s = s << 32 | (uint32_t)mix_u64((u >> 32) << 32 | (v >> 32));
-			if (s >> 32 == o_score >> 32) ++o_n;
-			else if (s >> 32 < o_score >> 32) { subo_n += o_n; o_n = 1; }
-			else ++subo_n;
-			if (s < o_score) { subo_score = o_score; o_score = s; o_pos[u & 1] = u; o_pos[v & 1] = v; }
-			else if (s < subo_score) subo_score = s;
-		}
-	};
+	PairSweep sw;
+	sw.end = p; sw.rows = rows; sw.ii = ii; sw.max_isize = max_isize;
+	sw.longest_read = (uint32_t)(p[0].full_len > p[1].full_len ? p[0].full_len : p[1].full_len);
+	for (int e = 0; e < 2; ++e) { sw.have[e][0] = sw.have[e][1] = false; sw.recent[e][0] = sw.recent[e][1] = 0; sw.best_of_end[e] = 0; }
+	sw.best.none = sw.second.none = true; sw.best.cost = sw.best.tie = sw.second.cost = sw.second.tie = 0;
+	sw.n_best = sw.n_worse = 0;
 	std::sort(hits, hits + n_hits);
-	for (int j = 0; j < 2; ++j) last_pos[j][0] = last_pos[j][1] = ~0ull;
 	for (int i = 0; i < n_hits; ++i) {
-		const uint64_t x = hits[i];
-		if ((rowof(x).info >> 24 & 1) == 1) {                /* reverse strand: check against the mate's forward hits */
-			const int y = 1 - (int)(x & 1);
-			consider(last_pos[y][1], x);
-			consider(last_pos[y][0], x);
-		} else { last_pos[x & 1][0] = last_pos[x & 1][1]; last_pos[x & 1][1] = x; }
+		if (sw.reverse(hits[i])) sw.reverse_seen(hits[i]);
+		else sw.forward_seen(hits[i]);
 	}
-	if (o_score != ~0ull) {
-		int mapQ_p = 0, rr[2];
-		if (o_n == 1) {
-			if (subo_score == ~0ull) mapQ_p = 29;
-			else if ((subo_score >> 32) - (o_score >> 32) > (uint64_t)(s_mm * 10)) mapQ_p = 23;
-			else {
-				const int n = subo_n > 255 ? 255 : subo_n;
-				mapQ_p = (int)(((subo_score >> 32) - (o_score >> 32)) / 2) - log_n(n);
-				if (mapQ_p < 0) mapQ_p = 0;
-			}
+	if (sw.best.none) return 0;
+
+	const int cap = sw.moved_end_quality(s_mm);
+	bool stays[2];
+	for (int e = 0; e < 2; ++e) stays[e] = p[e].pos == PairSweep::where(sw.best_of_end[e]) && p[e].strand == (int)sw.reverse(sw.best_of_end[e]);
+	if (stays[0] && stays[1]) {
+		if (p[0].mapQ > 0 && p[1].mapQ > 0) {
+			const int sum = p[0].mapQ + p[1].mapQ;
+			p[0].mapQ = p[1].mapQ = sum > 60 ? 60 : sum;
+		} else {                                              /* end 0 first: end 1 then sees end 0's new value, as in the reference */
+			for (int e = 0; e < 2; ++e)
+				if (p[e].mapQ == 0) p[e].mapQ = cap + 7 < p[1 - e].mapQ ? cap + 7 : p[1 - e].mapQ;
 		}
-		rr[0] = rowof(o_pos[0]).info >> 24 & 1; rr[1] = rowof(o_pos[1]).info >> 24 & 1;
-		const bool same0 = p[0].pos == (uint32_t)(o_pos[0] >> 32) && p[0].strand == rr[0];
-		const bool same1 = p[1].pos == (uint32_t)(o_pos[1] >> 32) && p[1].strand == rr[1];
-		if (same0 && same1) {
-			if (p[0].mapQ > 0 && p[1].mapQ > 0) {
-				int mapQ = p[0].mapQ + p[1].mapQ; if (mapQ > 60) mapQ = 60;
-				p[0].mapQ = p[1].mapQ = mapQ;
-			} else {
-				if (p[0].mapQ == 0) p[0].mapQ = (mapQ_p + 7 < p[1].mapQ) ? mapQ_p + 7 : p[1].mapQ;
-				if (p[1].mapQ == 0) p[1].mapQ = (mapQ_p + 7 < p[0].mapQ) ? mapQ_p + 7 : p[0].mapQ;
-			}
-		} else if (same0) { p[1].seQ = 0; p[1].mapQ = p[0].mapQ; if (p[1].mapQ > mapQ_p) p[1].mapQ = mapQ_p; }
-		else if (same1) { p[0].seQ = 0; p[0].mapQ = p[1].mapQ; if (p[0].mapQ > mapQ_p) p[0].mapQ = mapQ_p; }
-		else { p[0].seQ = p[1].seQ = 0; mapQ_p -= 20; if (mapQ_p < 0) mapQ_p = 0; p[0].mapQ = p[1].mapQ = mapQ_p; }
-		for (int e = 0; e < 2; ++e) {                          /* __pairing_aux2 */
-			const nabwa_aln1_t &r = rowof(o_pos[e]);
-			nabwa_pe_end_t &q = p[e];
-			q.extra_flag |= 2;                                 /* SAM_FPP */
-			if (q.pos != (uint32_t)(o_pos[e] >> 32) || q.strand != (int)(r.info >> 24 & 1)) {
-				q.n_mm = r.info & 0xff; q.n_gapo = r.info >> 8 & 0xff; q.n_gape = r.info >> 16 & 0xff; q.strand = r.info >> 24 & 1;
-				q.score = r.score; q.pos = (uint32_t)(o_pos[e] >> 32);
-				if (q.mapQ > 0) ++cnt_chg;
-			}
-		}
+	} else if (stays[0] || stays[1]) {
+		const int fixed = stays[0] ? 0 : 1, moved = 1 - fixed;
+		p[moved].seQ = 0;
+		p[moved].mapQ = p[fixed].mapQ > cap ? cap : p[fixed].mapQ;
+	} else {
+		const int q = cap - 20 < 0 ? 0 : cap - 20;
+		p[0].seQ = p[1].seQ = 0;
+		p[0].mapQ = p[1].mapQ = q;
 	}
-	return cnt_chg;
+	int n_moved_with_quality = 0;
+	for (int e = 0; e < 2; ++e) {                              /* the ends take the pair's places */
+		const nabwa_aln1_t &r = sw.row(sw.best_of_end[e]);
+		nabwa_pe_end_t &q = p[e];
+		q.extra_flag |= 2;                                     /* SAM_FPP */
+		if (stays[e]) continue;
+		q.n_mm = r.info & 0xff; q.n_gapo = r.info >> 8 & 0xff; q.n_gape = r.info >> 16 & 0xff; q.strand = r.info >> 24 & 1;
+		q.score = r.score; q.pos = PairSweep::where(sw.best_of_end[e]);
+		if (q.mapQ > 0) ++n_moved_with_quality;
+	}
+	return n_moved_with_quality;
 }
