@@ -80,6 +80,9 @@ DEEP_FN int deep_ctz64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; 
 DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u ? a[0] : (c == 1u ? a[1] : (c == 2u ? a[2] : a[3])); }
 
 // One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
+// PROF: the statistics (rounds, chains, phase clocks) cost scalar and vector registers, so the build without them is the one that runs
+// unless NABWA_TIMING / NABWA_DEEP_STATS ask for them
+template <bool PROF>
 DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #ifndef NABWA_EMU
 							, const int ln
@@ -103,8 +106,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
 	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
+	unsigned long long st_lanesteps = 0;
 	unsigned long long ph_pop = 0, ph_chain = 0, ph_tail = 0, ph_commit = 0, ph_hit = 0, st_tailit = 0;      // (statistics) time per phase of a round
-	const bool prof = P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
+	const bool prof = PROF && P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
 	const unsigned long long clk_start = DEEP_CLOCK();
 	// text mode (nabwa_dev.hpp): an exact tail that has narrowed to ONE row is finished by comparing the read with the text
 	const bool text_ok = (S.text_mode & 2) && S.bwt[0].sa_full && S.bwt[1].sa_full && S.bwt[0].isa && S.bwt[1].isa && S.bwt[0].text && S.bwt[1].text;
@@ -162,7 +166,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 		uint4 *const out = S.aln + (size_t)item * S.aln_cap;
 		int n_aln = 0, max_ent = 0, status = NABWA_ST_OK;
 		unsigned long long rd_touch = 0;
-		const unsigned long long clk0 = P.stats ? DEEP_CLOCK() : 0ull, rounds0 = st_rounds;
+		const unsigned long long clk0 = prof ? DEEP_CLOCK() : 0ull, rounds0 = st_rounds;
 
 		if (len > 0 && (int)S.rd_nN[rid] <= MD) {          // too many N: no search (bwtgap.c:118-123)
 			const bool seeded = len > S.seed_len;
@@ -187,7 +191,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			// roots (bwtgap.c:127-128): strand 0 is pushed first, strand 1 second, so strand 1 is popped first
 			bool got_page = false;
 			DEEP_ALLOC(1u, got_page);
-			if (!got_page) { status = NABWA_ST_POOL; done = true; ++st_pool; }
+			if (!got_page) { status = NABWA_ST_POOL; done = true; if (PROF) ++st_pool; }
 			else {
 				const uint32_t p0 = WUNI(s_newp[0]);
 				ONE_LANE {
@@ -229,12 +233,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						deep_unpack(P.pages[(size_t)pg * DEEP_PAGE + (p & (DEEP_PAGE - 1u))], L(e));
 					}
 				}
-				++st_rounds; st_run += W; if (careful) ++st_careful;
+				if (PROF) { ++st_rounds; st_run += W; if (careful) ++st_careful; }
 
 				unsigned long long pc1 = 0; if (prof) { LANES { L(tu) = L(e).k; } (void)WUNI(WBCAST(tu, 0)); pc1 = DEEP_CLOCK(); ph_pop += pc1 - pc0; }
 				// ---------------------------------------------------------------- the chains
 				while (WBALLOT(L(act)) != 0ull) {
-					++st_steps;
+					if (PROF) { ++st_steps; st_lanesteps += (unsigned)__popcll((unsigned long long)WBALLOT(L(act))); }
 					LANES { if (L(act)) {
 						DeepLane &E = L(e);
 						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
@@ -356,7 +360,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				unsigned long long pc2 = 0; if (prof) { pc2 = DEEP_CLOCK(); ph_chain += pc2 - pc1; }
 				LANES { L(ts) = L(flag) == DF_TAIL ? ((text_ok && L(e).k == L(e).l) ? 1 : 0) : -1; }
 				while (WBALLOT(L(ts) >= 0) != 0ull) {
-					++st_tailit;
+					if (PROF) ++st_tailit;
 					LANES { if (L(ts) >= 0) {
 						DeepLane &E = L(e);
 						const bool q1 = E.a == 0;
@@ -373,7 +377,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								deep_occ4_pair(B, E.k - 1u, E.l, ck, cl);
 								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, false);
 								E.k = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u; E.l = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
-								L(ntl) += 1;
+								if (PROF) L(ntl) += 1;
 								if (E.k > E.l) fail = true;
 								else if (--E.i == 0) hit = true;
 								else if (L(ts) == 0 && text_ok && E.k == E.l) L(ts) = 1;
@@ -399,7 +403,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								const uint32_t mask = nb >= 16 ? 0xffffffffu : (1u << (2 * nb)) - 1u;
 								if ((rd ^ tx) & mask) ok = false;
 							}
-							L(ntx) += 1;
+							if (PROF) L(ntx) += 1;
 							if (ok) L(ts) = 3; else fail = true;
 						} else {
 							E.k = E.l = (q1 ? S.bwt[1].isa : S.bwt[0].isa)[L(tpos) - (uint32_t)E.i];
@@ -426,7 +430,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				}
 				LANES { L(tu) = (uint32_t)(L(nst) + L(rel)); }
 				n_entries = (int)WUNI(WBCAST(tu, jl));
-				st_commit += (unsigned)(jl + 1);
+				if (PROF) st_commit += (unsigned)(jl + 1);
 				if (counting) { uint32_t tt = 0; LANES { L(d) = ln <= jl ? L(tch) : 0u; } WEXSCAN_U32(L(off), L(d), tt); rd_touch += tt; }
 				// the popped entries leave level s
 				const uint32_t newc = cs - (uint32_t)(jl + 1);
@@ -501,7 +505,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						WAVE_SYNC();
 					}
 				}
-				if (pool_fail) { status = NABWA_ST_POOL; ++st_pool; break; }
+				if (pool_fail) { status = NABWA_ST_POOL; if (PROF) ++st_pool; break; }
 				unsigned long long pc4 = 0; if (prof) { pc4 = DEEP_CLOCK(); ph_commit += pc4 - pc3; }
 				if (!over && fl == DF_HIT) {
 					// ---- hit bookkeeping (bwtgap.c:166-199), the wave together
@@ -564,10 +568,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			}
 		}
 		ONE_LANE { S.n_aln[item] = n_aln; S.max_ent[item] = max_ent; S.status[item] = (uint8_t)status; }
-		if (P.stats) { const unsigned long long dt = DEEP_CLOCK() - clk0; st_sumclk += dt; if (dt > st_maxclk) st_maxclk = dt; if (st_rounds - rounds0 > st_maxrounds) st_maxrounds = st_rounds - rounds0; }
+		if (prof) { const unsigned long long dt = DEEP_CLOCK() - clk0; st_sumclk += dt; if (dt > st_maxclk) st_maxclk = dt; if (st_rounds - rounds0 > st_maxrounds) st_maxrounds = st_rounds - rounds0; }
 		if (counting && status == NABWA_ST_OK) { ONE_LANE { DEEP_ATOMIC_ADD_U64(S.touch_counter, rd_touch); } }
 	}
-	if (P.stats) {
+	if (PROF && P.stats) {
 		uint32_t t6 = 0, t7 = 0;
 		LANES { L(d) = L(ntl); } WEXSCAN_U32(L(off), L(d), t6);
 		LANES { L(d) = L(ntx); } WEXSCAN_U32(L(off), L(d), t7);
@@ -578,7 +582,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
-			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit);
+			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit); atomicAdd(P.stats + 22, st_lanesteps);
 			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}

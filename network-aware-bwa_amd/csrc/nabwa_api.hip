@@ -838,6 +838,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		D.careful_all = env_int("NABWA_DEEP_CAREFUL", 0); D.max_lanes = env_int("NABWA_DEEP_LANES", 64);
 		if (D.max_lanes < 1) D.max_lanes = 1;
 		if (D.max_lanes > 64) D.max_lanes = 64;
+
 		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
 		// pass 1: as many waves as fit the CUs, pages on demand; pass 2 (only if the pool ran dry under some reads): as many
 		// waves as the pool can serve in the worst case
@@ -868,8 +869,8 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 256, hipMemcpyDeviceToHost));
 				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text; longest read %.3f s / %llu rounds, all reads %.1f wave-s, longest wave %.3f s\n",
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
-				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f\n",
-						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8);
+				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f; active lanes per chain step %.1f\n",
+						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
 			}
 			todo = n_pool;
 		}

@@ -1,0 +1,14 @@
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/ds
+for cfg in "256 240 80" "256 240 40" "128 240 120"; do
+set -- $cfg
+export NABWA_DEEP_SLOTS=$1 NABWA_DEEP_STAGE=$2 NABWA_DEEP_REFILL_ROOM=$3
+echo "== slots $1 stage $2 room $3"
+NABWA_TIMING=1 timeout -k 10 300 python3 bench.py --adna --reads 1000000 --steps 1 --warmup 0 --no-cpu --no-e2e > gpurun_out/ds/adna.json 2> gpurun_out/ds/adna.err || exit 1
+grep "kernel D" gpurun_out/ds/adna.err | sed -n 3,4p | cut -c1-420
+timeout -k 10 300 python3 bench.py --adna --reads 1000000 --steps 2 --warmup 1 --no-cpu --no-e2e > gpurun_out/ds/adna2.json 2> gpurun_out/ds/adna2.err || exit 1
+python3 -c "import json;d=json.load(open('gpurun_out/ds/adna2.json'));print('adna no-prof', d['value'], d['roofline']['deep_kernel_ms'], d['config']['checksum'])"
+NABWA_TIMING=1 timeout -k 10 300 python3 bench.py --pe --pairs 1000000 --steps 1 --warmup 0 --no-cpu > gpurun_out/ds/pe.json 2> gpurun_out/ds/pe.err || exit 1
+grep "kernel D" gpurun_out/ds/pe.err | sed -n 1,2p | cut -c1-420
+timeout -k 10 300 python3 bench.py --pe --pairs 1000000 --steps 2 --warmup 1 --no-cpu > gpurun_out/ds/pe2.json 2> gpurun_out/ds/pe2.err || exit 1
+python3 -c "import json;d=json.load(open('gpurun_out/ds/pe2.json'));print('pe no-prof', d['value'], d['roofline']['deep_kernel_ms'], d['config']['checksum'])"
+done
