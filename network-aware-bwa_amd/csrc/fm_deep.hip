@@ -5,9 +5,11 @@
 #include "fm_deep_body.hpp"
 
 #ifndef NABWA_DEEP_WAVES
-#define NABWA_DEEP_WAVES 3    // waves per SIMD the register budget is bounded for (168 VGPRs, 13 spilled dwords): 12 searches per CU.  Measured on
-                              // the aDNA workload (1 M reads): 2 / 3 / 4 / 5 waves -> 1074 / 1488 / 2383 / 4611 wave-seconds in all, i.e. 0.52 / 0.48 / 0.58 /
-                              // 0.90 s of work per wave: every spilled dword is a scratch access in the same in-order queue as the gathers
+#define NABWA_DEEP_WAVES 4    // waves per SIMD the register budget is bounded for: 128 VGPRs (22 spilled dwords), 16 searches per CU.  The trade-off was
+                              // measured twice.  With every child built and stored inside the chain step (about 180 live registers): 2 / 3 / 4 / 5 waves ->
+                              // 1074 / 1488 / 2383 / 4611 wave-seconds for 1 M aDNA reads, i.e. 0.52 / 0.48 / 0.58 / 0.90 s of work per wave -- three waves
+                              // won, every spilled dword being a scratch access in the same in-order queue as the gathers.  With records (165 registers
+                              // unbounded): four waves take 9 % off the paired-end workload's kernel time against three.
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];

@@ -5,8 +5,11 @@
 #define DEEP_PAGE_SH 8u
 #define DEEP_PAGE    (1u << DEEP_PAGE_SH)    /* entries per page */
 #define DEEP_NIL     0xffffffffu
-#define DEEP_NEWP    192u                      /* pages one commit can need at most: per child class 64 lanes x stage_k <= 240 entries / 256 + 1 <= 61 */
-#define DEEP_STAGE_MAX 240u
+#define DEEP_NEWP    192u                      /* pages one commit can need at most: 64 lanes x stage_k <= 48 records x <= 9 children / 256 + one partly filled page per class <= 111 */
+#define DEEP_STAGE_MAX 48u                      /* records a chain may file per round (64 B each): 64 lanes x 48 x 9 children stay within DEEP_NEWP pages */
+#define DRG_OPEN  1u                          /* a record's gap group: gap open = the insertion + the deletions; extension of an insertion; of a deletion */
+#define DRG_EXT_I 2u
+#define DRG_EXT_D 3u
 #define DST_M 0
 #define DST_I 1
 #define DST_D 2
@@ -18,7 +21,7 @@
 #define DCL_GO 1u
 #define DCL_GE 2u
 
-#define DEEP_LDS_WORDS(ns_, rd_) (2u * (((ns_) + 1u) & ~1u) + DEEP_NEWP + 64u + ((rd_) + 3u) / 4u)
+#define DEEP_LDS_WORDS(ns_, rd_) (2u * (((ns_) + 1u) & ~1u) + DEEP_NEWP + 256u + ((rd_) + 3u) / 4u)
 
 struct DeepParams {
 	SearchParams S;                  // index, reads, width records, options, outputs (n_aln / max_ent / status / aln by work item or res_slot)
@@ -28,7 +31,7 @@ struct DeepParams {
 	unsigned int *page_bump;         // pages handed out so far (a wave keeps what it took and re-uses it for its next reads)
 	uint32_t *own;                   // per wave 2 x own_cap ids: the pages it holds, and those of them that are free
 	uint32_t own_cap;
-	uint4 *stage;                    // per wave [3][64][stage_k]: the children of the running round, by class and lane
+	uint4 *stage;                    // per wave [64][stage_k] records of 64 bytes: what the chains of the running round push, lane by lane
 	uint32_t stage_k;
 	uint32_t NS;                     // score levels
 	uint32_t lds_rd, rd_pl;          // bytes of LDS for the read's own data (2 WLB + 2 SLB + 2 rd_pl; 0: it stays in global memory), stride of a strand's bases there

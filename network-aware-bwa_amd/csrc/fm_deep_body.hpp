@@ -95,12 +95,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	// own data -- bound bytes, seed bound bytes, bases of both strands -- copied in when the read starts
 	const uint32_t ns2 = (P.NS + 1u) & ~1u;
 	uint32_t *const s_cnt = lds, *const s_top = lds + ns2, *const s_newp = lds + 2 * ns2;
-	uint32_t *const s_off = s_newp + DEEP_NEWP;                           // 64 words: a class's slot offsets per lane (commit)
-	uint8_t *const s_bb = (uint8_t*)(s_off + 64), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
+	uint32_t *const s_off = s_newp + DEEP_NEWP;                           // 4 x 64 words: per lane the offsets of its records and of its children in the three classes (commit)
+	uint8_t *const s_bb = (uint8_t*)(s_off + 256), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
 	const bool lds_mode = P.lds_rd != 0u;
 	const uint32_t PL = P.rd_pl;
 	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
-	uint4 *const stage = P.stage + (size_t)wave * 3 * 64 * P.stage_k;     // [class][lane][stage_k]
+	uint4 *const stage = P.stage + (size_t)wave * 64 * P.stage_k * 4;     // [lane][stage_k] records of 64 bytes
 	const uint32_t K = P.stage_k;
 	uint32_t n_own = 0, n_free = 0;
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
@@ -120,7 +120,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(DeepLane, e);
 	LANE(bool, act);
 	LANE(int, flag);
-	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // children staged, per (canonical) class
+	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // children staged (through records), per (canonical) class
+	LANE(uint32_t, nrec);     // records this lane's chain has filed in this round
 	LANE(int, rel);           // live entries relative to the count before this lane's first pop
 	LANE(int, peak);          // the largest value `rel` had right before a pop
 	LANE(uint32_t, d); LANE(uint32_t, off);
@@ -222,11 +223,13 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				if (W > cs) W = cs;
 				const int T0 = s + S.s_mm, T1 = s + S.s_gapo, T2 = s + S.s_gape;
 				const uint32_t can1 = T1 == T0 ? 0u : 1u, can2 = T2 == T0 ? 0u : (T2 == T1 ? can1 : 2u);
+				const bool keep_all = nonstop || n_aln == 0;
+				const bool keep0 = keep_all || T0 <= best_score + S.s_mm, keep1 = keep_all || T1 <= best_score + S.s_mm, keep2 = keep_all || T2 <= best_score + S.s_mm;
 				const uint32_t topq = (cs - 1u) >> DEEP_PAGE_SH, top_pg = WUNI(s_top[s]);
 				uint32_t prev_pg = DEEP_NIL;
 				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = WUNI(P.page_prev[top_pg]);
 				LANES {
-					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(rel) = 0; L(peak) = 0;
+					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(nrec) = 0; L(rel) = 0; L(peak) = 0;
 					if (L(act)) {
 						const uint32_t p = cs - 1u - (uint32_t)ln;
 						const uint32_t pg = (p >> DEEP_PAGE_SH) == topq ? top_pg : prev_pg;
@@ -285,65 +288,55 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 										else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
 									}
 								}
-								uint4 *const stg = stage + (size_t)ln * K;
-								// a child of class cls: counted always, staged unless it can never be popped (after the first hit the
-								// loop ends at the first pop above best_score + s_mm, bwtgap.c:144).  (A macro, not a lambda: the closure
-								// of a by-reference lambda with this many captures is not dissolved by the compiler and drags every
-								// captured per-lane variable into scratch memory.)
-#define DEEP_CHILD(cls_, nk_, nl_, ni_, nmm_, ngo_, nge_, nstate_) do { \
-									L(rel) += 1; \
-									const int sc_ = (cls_) == DCL_MM ? T0 : ((cls_) == DCL_GO ? T1 : T2); \
-									if (nonstop || n_aln == 0 || sc_ <= best_score + S.s_mm) { \
-										const uint32_t cn_ = (cls_) == DCL_MM ? 0u : ((cls_) == DCL_GO ? can1 : can2); \
-										const uint32_t at_ = cn_ == 0u ? L(cc0) : (cn_ == 1u ? L(cc1) : L(cc2)); \
-										stg[(size_t)cn_ * 64u * K + at_] = deep_pack((nk_), (nl_), (ni_), (ni_), (nmm_), (ngo_), (nge_), (nstate_), E.a, 0u); \
-										if (cn_ == 0u) L(cc0) += 1; else if (cn_ == 1u) L(cc1) += 1; else L(cc2) += 1; \
-									} } while (0)
+								// ---- the children (bwtgap.c:206-259).  Deletions, mismatches and the match over symbol x all have the interval
+								// of "x in front of the suffixes": four intervals serve every child of this expansion.  The chain does not
+								// build the children: it files ONE 64-byte record -- the four intervals, the parent, which groups it pushes
+								// and where in their classes' sequences they go -- and the commit, where all 64 lanes work whatever the
+								// chains' lengths were, turns records into entries.  The counts are all the chain itself needs.
+								const uint32_t nk0 = B.L2[0] + ck.c[0] + 1u, nl0 = B.L2[0] + cl.c[0], nk1 = B.L2[1] + ck.c[1] + 1u, nl1 = B.L2[1] + cl.c[1];
+								const uint32_t nk2 = B.L2[2] + ck.c[2] + 1u, nl2 = B.L2[2] + cl.c[2], nk3 = B.L2[3] + ck.c[3] + 1u, nl3 = B.L2[3] + cl.c[3];
+								const uint32_t vm = (nk0 <= nl0 ? 1u : 0u) | (nk1 <= nl1 ? 2u : 0u) | (nk2 <= nl2 ? 4u : 0u) | (nk3 <= nl3 ? 8u : 0u);
+								const uint32_t nv = (uint32_t)__popc(vm);
 								int tmp = E.go + E.ge;
 								if (loggap) { const uint32_t v = (uint32_t)(E.ge + E.go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
+								uint32_t grp = 0, n_gap = 0, gcls = DCL_GO;      // DRG_* bits; children of the gap group; its class
 								if (allow_diff && i >= S.indel_end_skip + tmp && len - i >= S.indel_end_skip + tmp) {
-									if (E.state == DST_M) {                                      // gap open: the insertion, then the deletions
-										if (E.go < MG) {
-											DEEP_CHILD(DCL_GO, E.k, E.l, i, E.mm, E.go + 1, E.ge, DST_I);
-#pragma unroll
-											for (int j = 0; j < 4; ++j) {
-												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
-												if (nk <= nl) DEEP_CHILD(DCL_GO, nk, nl, i + 1, E.mm, E.go + 1, E.ge, DST_D);
-											}
-										}
-									} else if (E.state == DST_I) {
-										if (E.ge < S.max_gape) DEEP_CHILD(DCL_GE, E.k, E.l, i, E.mm, E.go, E.ge + 1, DST_I);
-									} else if (E.ge < S.max_gape) {
-										if (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ) {
-#pragma unroll
-											for (int j = 0; j < 4; ++j) {
-												const uint32_t nk = B.L2[j] + ck.c[j] + 1u, nl = B.L2[j] + cl.c[j];
-												if (nk <= nl) DEEP_CHILD(DCL_GE, nk, nl, i + 1, E.mm, E.go, E.ge + 1, DST_D);
-											}
-										}
-									}
+									if (E.state == DST_M) { if (E.go < MG) { grp = DRG_OPEN; n_gap = 1u + nv; } }                                 // the insertion, then the deletions
+									else if (E.state == DST_I) { if (E.ge < S.max_gape) { grp = DRG_EXT_I; n_gap = 1u; gcls = DCL_GE; } }
+									else if (E.ge < S.max_gape && (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
 								}
 								const uint32_t c = DEEP_RD(E.a, i);
-								bool match = false; uint32_t mk_ = 0, ml_ = 0;
-								if (allow_diff && allow_M) {
-#pragma unroll
-									for (int j = 1; j <= 4; ++j) {
-										const uint32_t x = (c + (uint32_t)j) & 3u;
-										const bool is_mm = j != 4 || c > 3u;
-										const uint32_t nk = deep_sel4(B.L2, x) + deep_sel4(ck.c, x) + 1u, nl = deep_sel4(B.L2, x) + deep_sel4(cl.c, x);
-										if (nk <= nl) {
-											if (is_mm) DEEP_CHILD(DCL_MM, nk, nl, i, E.mm + 1, E.go, E.ge, DST_M);
-											else { match = true; mk_ = nk; ml_ = nl; }
-										}
-									}
-								} else if (c < 4u) {
-									const uint32_t nk = deep_sel4(B.L2, c) + deep_sel4(ck.c, c) + 1u, nl = deep_sel4(B.L2, c) + deep_sel4(cl.c, c);
-									if (nk <= nl) { match = true; mk_ = nk; ml_ = nl; }
+								uint32_t mmv = 0;                                   // symbols with a mismatch child
+								bool match = false;
+								if (allow_diff && allow_M) { mmv = c > 3u ? vm : vm & ~(1u << c); match = c <= 3u && (vm >> c & 1u); }
+								else if (c < 4u) match = (vm >> c & 1u) != 0u;
+								const uint32_t n_mm = (uint32_t)__popc(mmv);
+								L(rel) += (int)(n_gap + n_mm);
+								// a class that can never be popped (after the first hit the loop ends at the first pop above best_score + s_mm,
+								// bwtgap.c:144) is counted, not stored
+								const bool keep_gap = gcls == DCL_GO ? keep1 : keep2;
+								if (!keep_gap) { grp = 0; n_gap = 0; }
+								if (!keep0) mmv = 0;
+								const uint32_t n_mm_st = keep0 ? n_mm : 0u;
+								if (n_gap + n_mm_st) {
+									const uint32_t gcn = gcls == DCL_GO ? can1 : can2;
+									const uint32_t at_gap = gcn == 0u ? L(cc0) : (gcn == 1u ? L(cc1) : L(cc2));
+									if (gcn == 0u) L(cc0) += n_gap; else if (gcn == 1u) L(cc1) += n_gap; else L(cc2) += n_gap;
+									const uint32_t at_mm = L(cc0);
+									L(cc0) += n_mm_st;
+									uint4 *const rp = stage + ((size_t)ln * K + L(nrec)) * 4u;
+									rp[0] = make_uint4(nk0, nk1, nk2, nk3);
+									rp[1] = make_uint4(nl0, nl1, nl2, nl3);
+									rp[2] = make_uint4(E.k, E.l, (uint32_t)i | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
+													   (uint32_t)E.mm | (uint32_t)E.go << 8 | (uint32_t)E.ge << 16 | (uint32_t)E.a << 26 | (c & 7u) << 27);
+									rp[3] = make_uint4(at_gap, at_mm, 0u, 0u);
+									L(nrec) += 1u;
 								}
+								const uint32_t mk_ = c == 0u ? nk0 : (c == 1u ? nk1 : (c == 2u ? nk2 : nk3)), ml_ = c == 0u ? nl0 : (c == 1u ? nl1 : (c == 2u ? nl2 : nl3));
 								// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
 								if (match) { L(rel) += 1; E.k = mk_; E.l = ml_; E.i = i; E.ldp = 0; E.state = DST_M; }
 								else L(act) = false;
-								if (L(act) && (careful || L(cc0) + 9u > K || L(cc1) + 9u > K || L(cc2) + 9u > K)) { L(flag) = DF_CONT; L(act) = false; }
+								if (L(act) && (careful || L(nrec) >= K)) { L(flag) = DF_CONT; L(act) = false; }      // no room for another record: the chain goes on in the next round
 							}
 						}
 					} }
@@ -470,24 +463,50 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						DEEP_LINK(tot2, T2, cT2, ot2, nn2, nb2)
 #undef DEEP_LINK
 					}
-					// the copy is spread evenly over the wave, whatever the lanes' chains staged: slot g of a class belongs to the
-					// lane j with off_j <= g < off_j + count_j (a search in the prefix sums, which sit in LDS for it)
-#define DEEP_COPY(c_, tot_, oc_, cT_, ot_, qn_, nb_) if (tot_) { \
-						LANES { s_off[ln] = ln <= jl ? L(oc_) : (tot_); } \
-						WAVE_SYNC(); \
-						LANES { for (uint32_t g = (uint32_t)ln; g < (tot_); g += 64u) { \
-							uint32_t j = 0; \
-							for (uint32_t stp = 32u; stp; stp >>= 1) if (s_off[j + stp] <= g) j += stp; \
-							const uint4 v = stage[((size_t)(c_) * 64u + j) * K + (g - s_off[j])]; \
-							const uint32_t w = (cT_) + g, q = w >> DEEP_PAGE_SH; \
-							const uint32_t pg = q < (qn_) ? (ot_) : s_newp[(nb_) + q - (qn_)]; \
-							P.pages[(size_t)pg * DEEP_PAGE + (w & (DEEP_PAGE - 1u))] = v; \
-						} } \
-						WAVE_SYNC(); }
-					DEEP_COPY(0u, tot0, o0, cT0, ot0, qn0, 0u)
-					DEEP_COPY(1u, tot1, o1, cT1, ot1, qn1, nb1)
-					DEEP_COPY(2u, tot2, o2, cT2, ot2, qn2, nb2)
-#undef DEEP_COPY
+					// the records become entries, the work spread evenly over the wave whatever the lanes' chains filed: record g of the
+					// round belongs to the lane j with off_j <= g < off_j + nrec_j (a search in the prefix sums, which sit in LDS for it
+					// together with the lanes' offsets in the three classes); a record's children go to consecutive places of their
+					// class, in the order the reference pushes them
+					uint32_t totr = 0;
+					LANE(uint32_t, orc);
+					LANES { L(d) = ln <= jl ? L(nrec) : 0u; } WEXSCAN_U32(L(orc), L(d), totr);
+					LANES { s_off[ln] = ln <= jl ? L(orc) : totr; s_off[64 + ln] = L(o0); s_off[128 + ln] = L(o1); s_off[192 + ln] = L(o2); }
+					WAVE_SYNC();
+#define DEEP_PUT(cT_, ot_, qn_, nb_, g_, v_) do { const uint32_t w_ = (cT_) + (g_), q_ = w_ >> DEEP_PAGE_SH; \
+						const uint32_t pg_ = q_ < (qn_) ? (ot_) : s_newp[(nb_) + q_ - (qn_)]; \
+						P.pages[(size_t)pg_ * DEEP_PAGE + (w_ & (DEEP_PAGE - 1u))] = (v_); } while (0)
+					LANES { for (uint32_t g = (uint32_t)ln; g < totr; g += 64u) {
+						uint32_t j = 0;
+						for (uint32_t stp = 32u; stp; stp >>= 1) if (s_off[j + stp] <= g) j += stp;
+						const uint4 *const rp = stage + ((size_t)j * K + (g - s_off[j])) * 4u;
+						const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+						const uint32_t nkv[4] = { r0.x, r0.y, r0.z, r0.w }, nlv[4] = { r1.x, r1.y, r1.z, r1.w };
+						const uint32_t ri = r2.z & 0xffffu, vm = r2.z >> 16 & 15u, grp = r2.z >> 20 & 15u, mmv = r2.z >> 24 & 15u, gcn = r2.z >> 28 & 3u;
+						const int pmm = (int)(r2.w & 0xffu), pgo = (int)(r2.w >> 8 & 0xffu), pge = (int)(r2.w >> 16 & 0xffu), pa = (int)(r2.w >> 26 & 1u);
+						const uint32_t c = r2.w >> 27 & 7u;
+						if (grp) {                                     // the gap group: [the insertion,] [the deletions over the symbols that occur]
+							const uint32_t gT = gcn == 0u ? cT0 : (gcn == 1u ? cT1 : cT2), gO = gcn == 0u ? ot0 : (gcn == 1u ? ot1 : ot2);
+							const uint32_t gQ = gcn == 0u ? qn0 : (gcn == 1u ? qn1 : qn2), gN = gcn == 0u ? 0u : (gcn == 1u ? nb1 : nb2);
+							uint32_t at = s_off[64u + 64u * gcn + j] + r3.x;
+							const int cgo = pgo + (grp == DRG_OPEN ? 1 : 0), cge = pge + (grp == DRG_OPEN ? 0 : 1);
+							if (grp != DRG_EXT_D) { DEEP_PUT(gT, gO, gQ, gN, at, deep_pack(r2.x, r2.y, (int)ri, (int)ri, pmm, cgo, cge, DST_I, pa, 0u)); ++at; }
+							if (grp != DRG_EXT_I) {
+#pragma unroll
+								for (int x = 0; x < 4; ++x)
+									if (vm >> x & 1u) { DEEP_PUT(gT, gO, gQ, gN, at, deep_pack(nkv[x], nlv[x], (int)ri + 1, (int)ri + 1, pmm, cgo, cge, DST_D, pa, 0u)); ++at; }
+							}
+						}
+						if (mmv) {                                     // the mismatches, in the reference's order: (c + 1) & 3, (c + 2) & 3, ...
+							uint32_t at = s_off[64u + j] + r3.y;
+#pragma unroll
+							for (uint32_t t = 1; t <= 4u; ++t) {
+								const uint32_t x = (c + t) & 3u;
+								if (mmv >> x & 1u) { DEEP_PUT(cT0, ot0, qn0, 0u, at, deep_pack(deep_sel4(nkv, x), deep_sel4(nlv, x), (int)ri, (int)ri, pmm + 1, pgo, pge, DST_M, pa, 0u)); ++at; }
+							}
+						}
+					} }
+					WAVE_SYNC();
+#undef DEEP_PUT
 				}
 				const int fl = WUNI(WBCAST(flag, jl));
 				if (!pool_fail && !over && fl == DF_CONT) {

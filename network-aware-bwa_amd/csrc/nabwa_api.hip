@@ -775,8 +775,8 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		if (!b->deep_cfg) {
 			hipDeviceProp_t prop;
 			HIPCHK(hipGetDeviceProperties(&prop, b->ix->device));
-			uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", 96);
-			if (K < 9u) K = 9u;
+			uint32_t K = (uint32_t)env_int("NABWA_DEEP_STAGE", (int)DEEP_STAGE_MAX);
+			if (K < 1u) K = 1u;
 			if (K > DEEP_STAGE_MAX) K = DEEP_STAGE_MAX;
 			// the read's own data (bound bytes, seed bound bytes, both strands' bases) sits in the wave's LDS when it is small enough
 			const uint32_t rd_pl = align_up((uint32_t)(b->max_len > 0 ? b->max_len : 1), 16);
@@ -800,7 +800,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			if (n_pages < 2) n_pages = 2;
 			// pages one search can hold at most: its live entries are bounded by the cut-off (bwtgap.c:140) plus one round's
 			// children, and every score level may have a partly filled page
-			uint64_t cap_pages = ((uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 3ull * 64ull * K + 2) / DEEP_PAGE + NS + 4;
+			uint64_t cap_pages = ((uint64_t)(b->opt.max_entries > 0 ? b->opt.max_entries : 0) + 9ull * 64ull * K + 2) / DEEP_PAGE + NS + 4;
 			if (cap_pages > n_pages) cap_pages = n_pages;
 			b->deep_K = K; b->deep_lds_rd = lds_rd; b->deep_rd_pl = rd_pl; b->deep_n_pages = n_pages; b->deep_cap_pages = cap_pages;
 			b->deep_waves_max = (long)prop.multiProcessorCount * occ;
@@ -815,7 +815,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			HIPCHK(pool_malloc(b->ix, (void**)&b->d_pages, n_pages * DEEP_PAGE * 16)); HIPCHK(pool_malloc(b->ix, (void**)&b->d_page_prev, n_pages * 4));
 			b->deep_pages = n_pages;
 		}
-		const size_t own_words = (size_t)n_waves * 2 * cap_pages, stage_ent = (size_t)n_waves * 3 * 64 * K;
+		const size_t own_words = (size_t)n_waves * 2 * cap_pages, stage_ent = (size_t)n_waves * 64 * K * 4;
 		if (b->deep_own_words < own_words) {
 			if (b->d_deep_own) HIPCHK(pool_free(b->ix, b->d_deep_own));
 			b->d_deep_own = 0; b->deep_own_words = 0;

@@ -1,8 +1,7 @@
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/ds
-for cfg in "256 240 80" "256 240 40" "128 240 120"; do
-set -- $cfg
-export NABWA_DEEP_SLOTS=$1 NABWA_DEEP_STAGE=$2 NABWA_DEEP_REFILL_ROOM=$3
-echo "== slots $1 stage $2 room $3"
+for cfg in "48" "24"; do
+export NABWA_DEEP_STAGE=$cfg
+echo "== records per chain and round $cfg"
 NABWA_TIMING=1 timeout -k 10 300 python3 bench.py --adna --reads 1000000 --steps 1 --warmup 0 --no-cpu --no-e2e > gpurun_out/ds/adna.json 2> gpurun_out/ds/adna.err || exit 1
 grep "kernel D" gpurun_out/ds/adna.err | sed -n 3,4p | cut -c1-420
 timeout -k 10 300 python3 bench.py --adna --reads 1000000 --steps 2 --warmup 1 --no-cpu --no-e2e > gpurun_out/ds/adna2.json 2> gpurun_out/ds/adna2.err || exit 1

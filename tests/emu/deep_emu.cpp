@@ -185,13 +185,13 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	unsigned int counter = 0, bump = 0;
 	S.work_counter = &counter;
 	S.touch_counter = &st;
-	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)knobs[2];
+	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)(knobs[2] < 1 ? 1 : (knobs[2] > (int)DEEP_STAGE_MAX ? (int)DEEP_STAGE_MAX : knobs[2]));
 	P.max_lanes = knobs[0]; P.careful_all = knobs[1]; P.NS = NS; P.stats = stats;
 	const int per_wave = knobs[5];
 	const int n_waves = per_wave > 0 ? (n + per_wave - 1) / per_wave : 1;
 	std::vector<uint4> pages((size_t)P.n_pages * DEEP_PAGE);
 	std::vector<uint32_t> prev(P.n_pages, 0), own((size_t)n_waves * 2 * P.own_cap, 0);
-	std::vector<uint4> stage((size_t)n_waves * 3 * 64 * P.stage_k);
+	std::vector<uint4> stage((size_t)n_waves * 64 * P.stage_k * 4);
 	P.rd_pl = align_up((uint32_t)(max_len > 0 ? max_len : 1), 16);
 	P.lds_rd = knobs[8] ? 2u * S.WLB + 2u * S.SLB + 2u * P.rd_pl : 0u;
 	std::vector<uint32_t> lds(DEEP_LDS_WORDS(NS, P.lds_rd) + 4);

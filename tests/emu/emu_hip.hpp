@@ -11,4 +11,5 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 #define __forceinline__ inline
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __popc(unsigned int v) { return __builtin_popcount(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

@@ -77,8 +77,8 @@ def deep_opt():
     return o
 
 
-@pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=9), dict(stage_k=12, max_lanes=64),
-                                   dict(stage_k=240, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1)])
+@pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=1), dict(stage_k=3, max_lanes=64),
+                                   dict(stage_k=48, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1)])
 def test_noisy_reads_vs_oracle(emu, words, orc, knobs):
     reads = noisy_reads(11, 150, (50, 63, 76, 100), 0.04)
     seq, rseq, off, _ = T.encode_reads(reads)
@@ -141,7 +141,7 @@ def test_under_address_sanitizer():
     code = ("import sys; sys.path.insert(0, %r); import numpy as np, nabwa_testlib as T, emu_deep as E, test_deep_emu as D\n"
             "lib = E.load(asan=True); words = E.toy_words(); o = T.load_oracle(); ox = T.OracleIndex(o)\n"
             "reads = D.noisy_reads(14, 40, (50, 76, 100), 0.04); seq, rseq, off, _ = T.encode_reads(reads)\n"
-            "for kn in (dict(), dict(stage_k=9), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=200)):\n"
+            "for kn in (dict(), dict(stage_k=2), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=48)):\n"
             "    opt = D.deep_opt(); want, wm = T.oracle_cal_sa_reg_gap(o, ox.h, opt, seq, rseq, off)\n"
             "    got, maxe, st, _ = E.run(lib, words, opt, seq, rseq, off, **kn)\n"
             "    assert all(st[i] == 3 or got[i].tobytes() == want[i].tobytes() for i in range(len(reads)))\n"

@@ -191,7 +191,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     {"NABWA_CAP1": "48"},                                                    # straight to kernel D (one search per wavefront)
     {"NABWA_CAP1": "48", "NABWA_TIER_A": "1"},                               # the first-pass kernel once more with its largest arena, kernel D for the rest
     {"NABWA_CAP1": "16", "NABWA_DEEP_LANES": "3"},                           # rounds of three chains
-    {"NABWA_CAP1": "16", "NABWA_DEEP_STAGE": "9"},                           # the smallest staging buffers: chains continue over rounds
+    {"NABWA_CAP1": "16", "NABWA_DEEP_STAGE": "1"},                           # the smallest staging buffers: chains continue over rounds
     {"NABWA_CAP1": "16", "NABWA_DEEP_CAREFUL": "1"},                         # one pop per round
     {"NABWA_CAP1": "16", "NABWA_DEEP_PAGES": "6000", "NABWA_DEEP_WAVES_PER_CU": "1"},   # a pool that runs dry: the guaranteed pass finishes them
     {"NABWA_CAP1": "48", "NABWA_ALNCAP1": "1"},                              # the first pass fails on the hit lists too
