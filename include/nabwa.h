@@ -176,6 +176,9 @@ int nabwa_global_align(int device, int n, const int64_t *ref_off, const uint8_t 
 					   const uint8_t *qry, int gap_open, int gap_ext, int gap_end, const int *matrix25, int band,
 					   int32_t *score, int32_t *n_cigar, uint32_t *cigar32, int max_cigar);
 
+/* The alignment entry points keep their device working memory (score rows, traceback matrices) between calls; this frees it. */
+void nabwa_dp_scratch_release(int device);
+
 /* Batch form of aln_extend_core (stdaln.c:862-1007): left-anchored extension seeded with G0[i], then the
  * path by global alignment of the two prefixes (gap_end = -1, band doubled until the scores agree or it
  * exceeds the prefix lengths).  score[i] as the reference returns it (<= 0: no extension, n_cigar 0). */

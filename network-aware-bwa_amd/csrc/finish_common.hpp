@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
@@ -170,64 +171,100 @@ static inline int64_t rec_pos_end(const nabwa_se_t &s)
 	return x;
 }
 
+/* host threads of the finishing chains: slices of independent records */
+static inline int fin_threads(size_t n)
+{
+	int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16;
+	if (getenv("NABWA_HOST_THREADS")) nt = std::max(1, atoi(getenv("NABWA_HOST_THREADS")));
+	if (n < 4096) nt = 1;
+	return nt;
+}
+template <class F> static inline void fin_parallel(int nt, size_t count, F f)       /* f(slice, lo, hi) */
+{
+	if (nt <= 1) { f(0, (size_t)0, count); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; ++t) th.emplace_back([=]() { f(t, count * t / nt, count * (t + 1) / nt); });
+	for (auto &x : th) x.join();
+}
+
 /* Gap refinement of every gapped hit of the batch (main hits and multi hits) as ONE batch of banded global
  * alignments on the GPU (refine_gapped_core, bwase.c:189-237; driver bwase.c:366-381: mate-rescued and
- * unmapped records are skipped). */
+ * unmapped records are skipped).  The host work around the kernel -- finding the jobs, cutting their reference windows out
+ * of the packed text, laying the reads out in alignment orientation, turning the paths into CIGARs -- runs on slices of the
+ * records / jobs in threads. */
 static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int n, const int64_t *off, const uint8_t *seq,
 							   const uint8_t *rseq, size_t *n_jobs)
 {
 	const nabwa_reference *R = ix->ref;
+	const int nt = fin_threads((size_t)n);
+	std::vector<std::vector<RefineJob>> part((size_t)nt);
+	fin_parallel(nt, (size_t)n, [&](int t, size_t lo, size_t hi) {
+		std::vector<RefineJob> &v = part[(size_t)t];
+		for (size_t i = lo; i < hi; ++i) {
+			const nabwa_se_t &s = *rec_at(base, stride, (int)i);
+			for (int j = 0; j < s.n_multi; ++j)
+				if (s.multi[j].gap) v.push_back({ (int)i, j, s.multi[j].strand, (s.multi[j].strand ? 1 : -1) * s.multi[j].gap, s.len, s.multi[j].pos, 0, 0 });
+			if (s.type != 0 && s.type != 3 && s.n_gapo) v.push_back({ (int)i, -1, s.strand, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape), s.len, s.pos, 0, 0 });
+		}
+	});
 	std::vector<RefineJob> jobs;
-	for (int i = 0; i < n; ++i) {
-		const nabwa_se_t &s = *rec_at(base, stride, i);
-		for (int j = 0; j < s.n_multi; ++j)
-			if (s.multi[j].gap) jobs.push_back({ i, j, s.multi[j].strand, (s.multi[j].strand ? 1 : -1) * s.multi[j].gap, s.len, s.multi[j].pos, 0, 0 });
-		if (s.type != 0 && s.type != 3 && s.n_gapo) jobs.push_back({ i, -1, s.strand, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape), s.len, s.pos, 0, 0 });
-	}
+	{ size_t tot = 0; for (auto &v : part) tot += v.size(); jobs.reserve(tot); for (auto &v : part) jobs.insert(jobs.end(), v.begin(), v.end()); }
 	if (n_jobs) *n_jobs = jobs.size();
 	if (jobs.empty()) return NABWA_OK;
 	static const int maq[25] = { 11,-19,-19,-19,-13, -19,11,-19,-19,-13, -19,-19,11,-19,-13, -19,-19,-19,11,-13, -13,-13,-13,-13,-13 };  /* aln_sm_maq */
-	std::vector<int64_t> ro(jobs.size() + 1, 0), qo(jobs.size() + 1, 0);
-	std::vector<uint8_t> rbuf, qbuf;
-	for (size_t t = 0; t < jobs.size(); ++t) {
+	const size_t nj = jobs.size();
+	const int ntj = fin_threads(nj);
+	std::vector<int64_t> ro(nj + 1, 0), qo(nj + 1, 0);
+	for (size_t t = 0; t < nj; ++t) {                      /* the windows' extents (bwase.c:197-209), then where each starts in the batch */
 		RefineJob &J = jobs[t];
 		const int ref_len = J.len + abs(J.ext);
-		int64_t p = (uint32_t)J.pos > R->l_pac ? (int64_t)(int32_t)(uint32_t)J.pos : (int64_t)(uint32_t)J.pos;   /* bwase.c:197 */
+		const int64_t p = (uint32_t)J.pos > R->l_pac ? (int64_t)(int32_t)(uint32_t)J.pos : (int64_t)(uint32_t)J.pos;   /* bwase.c:197 */
 		J.pos = p;
 		int64_t lo, hi;
 		if (J.ext > 0) { lo = std::max<int64_t>(p, 0); hi = std::min<int64_t>(p + ref_len, R->l_pac); }
 		else { const int64_t x = p + J.len; lo = x - ref_len > 0 ? x - ref_len : 0; hi = std::min<int64_t>(x, R->l_pac); }
-		for (int64_t k = lo; k < hi; ++k) rbuf.push_back((uint8_t)pac_at(R, k));
-		/* query in alignment orientation: reverse strand = rseq, forward = the read itself (seq is stored reversed) */
-		const uint8_t *src = (J.strand ? rseq : seq) + off[J.rec];
-		if (J.strand) qbuf.insert(qbuf.end(), src, src + J.len);
-		else for (int k = J.len - 1; k >= 0; --k) qbuf.push_back(src[k]);
-		ro[t + 1] = (int64_t)rbuf.size(); qo[t + 1] = (int64_t)qbuf.size();
+		J.win_lo = lo; J.win_n = hi > lo ? (int)(hi - lo) : 0;
+		ro[t + 1] = ro[t] + J.win_n; qo[t + 1] = qo[t] + J.len;
 	}
-	rbuf.push_back(0); qbuf.push_back(0);
+	std::vector<uint8_t> rbuf((size_t)ro[nj] + 1, 0), qbuf((size_t)qo[nj] + 1, 0);
+	fin_parallel(ntj, nj, [&](int, size_t lo_t, size_t hi_t) {
+		for (size_t t = lo_t; t < hi_t; ++t) {
+			const RefineJob &J = jobs[t];
+			uint8_t *rb = rbuf.data() + ro[t], *qb = qbuf.data() + qo[t];
+			for (int k = 0; k < J.win_n; ++k) rb[k] = (uint8_t)pac_at(R, J.win_lo + k);
+			/* query in alignment orientation: reverse strand = rseq, forward = the read itself (seq is stored reversed) */
+			const uint8_t *src = (J.strand ? rseq : seq) + off[J.rec];
+			if (J.strand) memcpy(qb, src, (size_t)J.len);
+			else for (int k = 0; k < J.len; ++k) qb[k] = src[J.len - 1 - k];
+		}
+	});
 	const int MAXC = NABWA_MAX_CIGAR;
-	std::vector<int32_t> sc(jobs.size()), nc(jobs.size()); std::vector<uint32_t> c32(jobs.size() * (size_t)MAXC);
-	int r = nabwa_global_align(ix->device, (int)jobs.size(), ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
+	std::vector<int32_t> sc(nj), nc(nj); std::vector<uint32_t> c32(nj * (size_t)MAXC);
+	int r = nabwa_global_align(ix->device, (int)nj, ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
 							   sc.data(), nc.data(), c32.data(), MAXC);                       /* aln_param_bwa, stdaln.c:227 */
 	if (r != NABWA_OK) return r;
-	for (size_t t = 0; t < jobs.size(); ++t) {
-		const RefineJob &J = jobs[t];
-		if (nc[t] > MAXC || nc[t] < 1) return nabwa_fail(NABWA_ECAP, "refined CIGAR longer than NABWA_MAX_CIGAR");
-		uint16_t cg[NABWA_MAX_CIGAR]; int m = nc[t]; int64_t p = J.pos;
-		for (int k = 0; k < m; ++k) cg[k] = CMAKE(c32[t * MAXC + k] & 0xf, c32[t * MAXC + k] >> 4);
-		if (J.ext < 0) {                       /* forward strand: the end was anchored, shift the start by the net indel */
-			int d = 0;
-			for (int k = 0; k < m; ++k) { if (COP(cg[k]) == 2) d -= CLEN(cg[k]); else if (COP(cg[k]) == 1) d += CLEN(cg[k]); }
-			p += d;
+	std::vector<int> bad((size_t)ntj, 0);
+	fin_parallel(ntj, nj, [&](int slice, size_t lo_t, size_t hi_t) {
+		for (size_t t = lo_t; t < hi_t; ++t) {
+			const RefineJob &J = jobs[t];
+			if (nc[t] > MAXC || nc[t] < 1) { bad[(size_t)slice] = 1; continue; }
+			uint16_t cg[NABWA_MAX_CIGAR]; int m = nc[t]; int64_t p = J.pos;
+			for (int k = 0; k < m; ++k) cg[k] = CMAKE(c32[t * MAXC + k] & 0xf, c32[t * MAXC + k] >> 4);
+			if (J.ext < 0) {                       /* forward strand: the end was anchored, shift the start by the net indel */
+				int d = 0;
+				for (int k = 0; k < m; ++k) { if (COP(cg[k]) == 2) d -= CLEN(cg[k]); else if (COP(cg[k]) == 1) d += CLEN(cg[k]); }
+				p += d;
+			}
+			if (COP(cg[0]) == 2) { p += CLEN(cg[0]); for (int k = 0; k + 1 < m; ++k) cg[k] = cg[k + 1]; --m; }
+			if (COP(cg[m - 1]) == 2) --m;
+			if (COP(cg[m - 1]) == 1) cg[m - 1] = CMAKE(3, CLEN(cg[m - 1]));
+			if (COP(cg[0]) == 1) cg[0] = CMAKE(3, CLEN(cg[0]));
+			nabwa_se_t &s = *rec_at(base, stride, J.rec);         /* (a record's main hit and its multi hits are different fields: no two jobs write the same bytes) */
+			if (J.multi < 0) { s.pos = (uint32_t)p; s.n_cigar = m; memcpy(s.cigar, cg, 2 * m); }
+			else { s.multi[J.multi].pos = (uint32_t)p; s.multi[J.multi].n_cigar = m; memcpy(s.multi[J.multi].cigar, cg, 2 * m); }
 		}
-		if (COP(cg[0]) == 2) { p += CLEN(cg[0]); for (int k = 0; k + 1 < m; ++k) cg[k] = cg[k + 1]; --m; }
-		if (COP(cg[m - 1]) == 2) --m;
-		if (COP(cg[m - 1]) == 1) cg[m - 1] = CMAKE(3, CLEN(cg[m - 1]));
-		if (COP(cg[0]) == 1) cg[0] = CMAKE(3, CLEN(cg[0]));
-		nabwa_se_t &s = *rec_at(base, stride, J.rec);
-		if (J.multi < 0) { s.pos = (uint32_t)p; s.n_cigar = m; memcpy(s.cigar, cg, 2 * m); }
-		else { s.multi[J.multi].pos = (uint32_t)p; s.multi[J.multi].n_cigar = m; memcpy(s.multi[J.multi].cigar, cg, 2 * m); }
-	}
+	});
+	for (int b : bad) if (b) return nabwa_fail(NABWA_ECAP, "refined CIGAR longer than NABWA_MAX_CIGAR");
 	return NABWA_OK;
 }
 

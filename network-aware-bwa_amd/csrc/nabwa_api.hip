@@ -1043,13 +1043,14 @@ extern "C" int nabwa_sa_lookup(nabwa_index_t *ix, int n, const uint8_t *which, c
 	if (n == 0) return NABWA_OK;
 	HIPCHK(hipSetDevice(ix->device));
 	uint8_t *dw = 0; uint32_t *dk = 0, *dout = 0;
-	HIPCHK(hipMalloc(&dw, n)); HIPCHK(hipMalloc(&dk, (size_t)n * 4)); HIPCHK(hipMalloc(&dout, (size_t)n * 4));
+	/* (buffers from the pool kept with the index: this is called once per batch by the finishing chains) */
+	HIPCHK(pool_malloc(ix, (void**)&dw, (size_t)n)); HIPCHK(pool_malloc(ix, (void**)&dk, (size_t)n * 4)); HIPCHK(pool_malloc(ix, (void**)&dout, (size_t)n * 4));
 	HIPCHK(hipMemcpy(dw, which, n, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(dk, k, (size_t)n * 4, hipMemcpyHostToDevice));
 	nabwa_launch_sa_lookup(ix->bwt, n, dw, dk, dout, 0);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpy(sa_out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-	HIPCHK(hipFree(dw)); HIPCHK(hipFree(dk)); HIPCHK(hipFree(dout));
+	HIPCHK(pool_free(ix, dw)); HIPCHK(pool_free(ix, dk)); HIPCHK(pool_free(ix, dout));
 	return NABWA_OK;
 }
 

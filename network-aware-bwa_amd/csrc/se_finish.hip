@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include "../../include/nabwa.h"
 #include "nabwa_internal.hpp"
@@ -38,6 +39,37 @@ extern "C" void nabwa_launch_dp_global(const DpParams *P, hipStream_t s);
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 	char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
 	return nabwa_fail(NABWA_ENODEV, "%s", b_); } } while (0)
+
+/* Working memory of the alignment entry points: one grow-only block per device, kept between calls (hipMalloc / hipFree of the
+ * traceback matrices -- 1.5 GB for 64 k pairs of 150 bases -- cost more than the kernels), handed out under a lock for the length
+ * of one launch.  nabwa_dp_scratch_release gives it back. */
+namespace {
+struct DevArena { std::mutex mu; void *base = 0; size_t cap = 0; };
+DevArena g_arena[16];
+struct ArenaUse {
+	DevArena &A; std::unique_lock<std::mutex> lk; size_t used = 0;
+	explicit ArenaUse(int dev) : A(g_arena[dev & 15]), lk(A.mu) {}
+	hipError_t reserve(size_t bytes)
+	{
+		used = 0;
+		if (bytes <= A.cap) return hipSuccess;
+		if (A.base) { (void)hipFree(A.base); A.base = 0; A.cap = 0; }
+		const size_t c = bytes + bytes / 4;
+		const hipError_t e = hipMalloc(&A.base, c);
+		if (e == hipSuccess) A.cap = c;
+		return e;
+	}
+	template <class T> T *take(size_t bytes) { T *p = (T*)((char*)A.base + used); used += (bytes + 255) & ~(size_t)255; return p; }
+};
+inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+}
+
+extern "C" void nabwa_dp_scratch_release(int device)
+{
+	DevArena &A = g_arena[device & 15];
+	std::lock_guard<std::mutex> lk(A.mu);
+	if (A.base) { (void)hipFree(A.base); A.base = 0; A.cap = 0; }
+}
 
 /* ------------------------------------------------------------------ batched aln_global_core */
 
@@ -62,14 +94,14 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		for (int i = 0; i <= m; ++i) { ro[i] = ref_off[c0 + i] - ref_off[c0]; qo[i] = qry_off[c0 + i] - qry_off[c0]; }
 		const size_t waves = (size_t)((m + 255) / 256) * 4;
 		DpParams P; memset(&P, 0, sizeof(P));
-		int64_t *d_ro = 0, *d_qo = 0; uint8_t *d_ref = 0, *d_qry = 0;
-		SCHK(hipMalloc(&d_ro, (m + 1) * 8)); SCHK(hipMalloc(&d_qo, (m + 1) * 8));
-		SCHK(hipMalloc(&d_ref, ro[m] + 16)); SCHK(hipMalloc(&d_qry, qo[m] + 16));
-		SCHK(hipMalloc(&P.rows, waves * 6 * (size_t)W * 64 * 4));
-		SCHK(hipMalloc(&P.tb, waves * (size_t)H * W * 64));
-		SCHK(hipMalloc(&P.path, waves * (size_t)(W + H) * 64));
-		SCHK(hipMalloc(&P.score, (size_t)m * 4)); SCHK(hipMalloc(&P.n_cigar, (size_t)m * 4));
-		SCHK(hipMalloc(&P.cigar, (size_t)m * max_cigar * 4));
+		ArenaUse A(device);
+		const size_t sz[10] = { (size_t)(m + 1) * 8, (size_t)(m + 1) * 8, (size_t)ro[m] + 16, (size_t)qo[m] + 16, waves * 6 * (size_t)W * 64 * 4,
+								waves * (size_t)H * W * 64, waves * (size_t)(W + H) * 64, (size_t)m * 4, (size_t)m * 4, (size_t)m * max_cigar * 4 };
+		size_t need = 0; for (size_t z : sz) need += up256(z);
+		SCHK(A.reserve(need));
+		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
+		P.rows = A.take<int32_t>(sz[4]); P.tb = A.take<uint8_t>(sz[5]); P.path = A.take<uint8_t>(sz[6]);
+		P.score = A.take<int32_t>(sz[7]); P.n_cigar = A.take<int32_t>(sz[8]); P.cigar = A.take<uint32_t>(sz[9]);
 		SCHK(hipMemcpy(d_ro, ro.data(), (m + 1) * 8, hipMemcpyHostToDevice));
 		SCHK(hipMemcpy(d_qo, qo.data(), (m + 1) * 8, hipMemcpyHostToDevice));
 		if (ro[m]) SCHK(hipMemcpy(d_ref, ref + ref_off[c0], ro[m], hipMemcpyHostToDevice));
@@ -83,8 +115,6 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		SCHK(hipMemcpy(score + c0, P.score, (size_t)m * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(n_cigar + c0, P.n_cigar, (size_t)m * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(cigar32 + (size_t)c0 * max_cigar, P.cigar, (size_t)m * max_cigar * 4, hipMemcpyDeviceToHost));
-		void *fr[] = { d_ro, d_qo, d_ref, d_qry, P.rows, P.tb, P.path, P.score, P.n_cigar, P.cigar };
-		for (void *p : fr) SCHK(hipFree(p));
 	}
 	return NABWA_OK;
 }
@@ -120,11 +150,14 @@ extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, con
 	{
 		ExtParams P; memset(&P, 0, sizeof(P));
 		const size_t waves = (size_t)((n + 255) / 256) * 4;
-		int64_t *d_ro = 0, *d_qo = 0; uint8_t *d_ref = 0, *d_qry = 0; int32_t *d_g0 = 0;
-		SCHK(hipMalloc(&d_ro, (size_t)(n + 1) * 8)); SCHK(hipMalloc(&d_qo, (size_t)(n + 1) * 8));
-		SCHK(hipMalloc(&d_ref, ref_off[n] + 16)); SCHK(hipMalloc(&d_qry, qry_off[n] + 16)); SCHK(hipMalloc(&d_g0, (size_t)n * 4));
-		SCHK(hipMalloc(&P.eh, waves * (size_t)W * 64 * 4));
-		SCHK(hipMalloc(&P.score, (size_t)n * 4)); SCHK(hipMalloc(&P.end_i, (size_t)n * 4)); SCHK(hipMalloc(&P.end_j, (size_t)n * 4));
+		ArenaUse A(device);
+		const size_t sz[9] = { (size_t)(n + 1) * 8, (size_t)(n + 1) * 8, (size_t)ref_off[n] + 16, (size_t)qry_off[n] + 16, (size_t)n * 4,
+							   waves * (size_t)W * 64 * 4, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4 };
+		size_t need = 0; for (size_t z : sz) need += up256(z);
+		SCHK(A.reserve(need));
+		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
+		int32_t *d_g0 = A.take<int32_t>(sz[4]);
+		P.eh = A.take<uint32_t>(sz[5]); P.score = A.take<int32_t>(sz[6]); P.end_i = A.take<int32_t>(sz[7]); P.end_j = A.take<int32_t>(sz[8]);
 		SCHK(hipMemcpy(d_ro, ref_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		SCHK(hipMemcpy(d_qo, qry_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		if (ref_off[n]) SCHK(hipMemcpy(d_ref, ref, ref_off[n], hipMemcpyHostToDevice));
@@ -137,8 +170,6 @@ extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, con
 		SCHK(hipMemcpy(fs.data(), P.score, (size_t)n * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(ei.data(), P.end_i, (size_t)n * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(ej.data(), P.end_j, (size_t)n * 4, hipMemcpyDeviceToHost));
-		void *fr[] = { d_ro, d_qo, d_ref, d_qry, d_g0, P.eh, P.score, P.end_i, P.end_j };
-		for (void *p : fr) SCHK(hipFree(p));
 	}
 	/* path: global alignment of the two prefixes with gap_end = -1 and a doubling band (stdaln.c:985-1000) */
 	std::vector<int> act;
@@ -199,10 +230,13 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 	{
 		LocParams P; memset(&P, 0, sizeof(P));
 		const size_t waves = (size_t)((n + 255) / 256) * 4;
-		int64_t *d_ro = 0, *d_qo = 0; uint8_t *d_ref = 0, *d_qry = 0;
-		SCHK(hipMalloc(&d_ro, (size_t)(n + 1) * 8)); SCHK(hipMalloc(&d_qo, (size_t)(n + 1) * 8));
-		SCHK(hipMalloc(&d_ref, ref_off[n] + 16)); SCHK(hipMalloc(&d_qry, qry_off[n] + 16));
-		SCHK(hipMalloc(&P.eh, waves * (size_t)W * 64 * 4)); SCHK(hipMalloc(&P.suba, (size_t)n * H * 4)); SCHK(hipMalloc(&P.out, (size_t)n * 24));
+		ArenaUse A(device);
+		const size_t sz[7] = { (size_t)(n + 1) * 8, (size_t)(n + 1) * 8, (size_t)ref_off[n] + 16, (size_t)qry_off[n] + 16,
+							   waves * (size_t)W * 64 * 4, (size_t)n * H * 4, (size_t)n * 24 };
+		size_t need = 0; for (size_t z : sz) need += up256(z);
+		SCHK(A.reserve(need));
+		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
+		P.eh = A.take<int32_t>(sz[4]); P.suba = A.take<int32_t>(sz[5]); P.out = A.take<int32_t>(sz[6]);
 		SCHK(hipMemcpy(d_ro, ref_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		SCHK(hipMemcpy(d_qo, qry_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
 		if (ref_off[n]) SCHK(hipMemcpy(d_ref, ref, ref_off[n], hipMemcpyHostToDevice));
@@ -213,8 +247,6 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 		SCHK(hipGetLastError());
 		SCHK(hipMemcpy(o.data(), P.out, (size_t)n * 24, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(sub.data(), P.suba, (size_t)n * H * 4, hipMemcpyDeviceToHost));
-		void *fr[] = { d_ro, d_qo, d_ref, d_qry, P.eh, P.suba, P.out };
-		for (void *p : fr) SCHK(hipFree(p));
 	}
 	std::vector<int> act;
 	for (int i = 0; i < n; ++i) {

@@ -6,6 +6,7 @@ run() { name=$1; shift; timeout -k 10 600 python3 bench.py "$@" > $O/$name.json 
 run headline --steps 5 --warmup 1 || exit 1
 run repeats --repeats --steps 3 --warmup 1 || exit 1
 run adna --adna --reads 1000000 --steps 3 --warmup 1 || exit 1
+run adna_6m --adna --reads 6250000 --steps 2 --warmup 1 --no-e2e || exit 1      # config 5's share of one GPU: 50 M reads over 8
 run pe --pe --pairs 1000000 --steps 3 --warmup 1 || exit 1
 # the index in the reference's own 2 GB-per-direction form: no k-mer table, no packed text
 NABWA_KMER_T=0 NABWA_TEXT_MODE=0 run headline_plain_index --steps 3 --warmup 1 --no-e2e || exit 1
