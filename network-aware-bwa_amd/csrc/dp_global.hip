@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void dp_global_kernel(const DpParams P)
 		const int cur = j & 1, prv = cur ^ 1;
 		const int left = j > b2 ? j - b2 : 0, right = j + b1 - 1 < l1 ? j + b1 - 1 : l1;
 		const int *mat = P.matrix + s2[j - 1] * 5;
+		const int mt0 = mat[0], mt1 = mat[1], mt2 = mat[2], mt3 = mat[3], mt4 = mat[4];      // this row's scores against A, C, G, T, N
 		const int dpen = j == l2 ? end_pen : gap_ext;
 		int cm_l = NINF, cd_l = NINF;          // M and D of the cell to the left in this row
 		ROW(0, cur, left) = NINF; ROW(1, cur, left) = NINF; ROW(2, cur, left) = NINF; TBC(j, left) = 0;
@@ -82,25 +83,45 @@ __global__ __launch_bounds__(256) void dp_global_kernel(const DpParams P)
 			ROW(1, cur, 0) = v; TBC(j, 0) = (uint8_t)(tt << 2);
 		}
 		int pm_d = ROW(0, prv, left), pi_d = ROW(1, prv, left), pd_d = ROW(2, prv, left);   // diagonal cell (i-1) of the previous row
-		for (int i = left + 1; i <= right; ++i) {
-			const int sc = mat[s1[i - 1]];
-			int m, mt, iv = NINF, it = 0, dv, dt;
-			if (pm_d >= pi_d) { if (pm_d >= pd_d) { m = pm_d + sc; mt = FM; } else { m = pd_d + sc; mt = FD; } }
-			else { if (pi_d > pd_d) { m = pi_d + sc; mt = FI; } else { m = pd_d + sc; mt = FD; } }
-			// the cell above (row j-1, column i): needed for I, and it is the next column's diagonal
-			const bool above = !(i == right && !(j + b1 - 1 > l1));
-			int pm_u = NINF, pi_u = NINF, pd_u = NINF;
-			if (above || i < right) { pm_u = ROW(0, prv, i); pi_u = ROW(1, prv, i); pd_u = ROW(2, prv, i); }
-			if (above) {
-				const int ipen = i == l1 ? end_pen : gap_ext;
-				if (pm_u - gap_open > pi_u) { it = FM; iv = pm_u - gap_open - ipen; } else { it = FI; iv = pi_u - ipen; }
+		// a lane's cells are a chain of dependent loads when taken one at a time (the previous row's three scores, the base, its
+		// score): DPB columns are fetched together -- the previous row is not written in this row, so nothing read here is stale
+#define DPB 4
+		for (int i0 = left + 1; i0 <= right; i0 += DPB) {
+			int um[DPB], ui[DPB], ud[DPB], ub[DPB];
+#pragma unroll
+			for (int u = 0; u < DPB; ++u) {
+				const int i = i0 + u;
+				um[u] = ui[u] = ud[u] = NINF; ub[u] = 4;
+				if (i <= right) {
+					ub[u] = s1[i - 1];
+					// the cell above (row j-1, column i): needed for I, and it is the next column's diagonal
+					const bool above = !(i == right && !(j + b1 - 1 > l1));
+					if (above || i < right) { um[u] = ROW(0, prv, i); ui[u] = ROW(1, prv, i); ud[u] = ROW(2, prv, i); }
+				}
 			}
-			if (cm_l - gap_open > cd_l) { dt = FM; dv = cm_l - gap_open - dpen; } else { dt = FD; dv = cd_l - dpen; }
-			ROW(0, cur, i) = m; ROW(1, cur, i) = iv; ROW(2, cur, i) = dv;
-			TBC(j, i) = (uint8_t)(mt | it << 2 | dt << 4);
-			cm_l = m; cd_l = dv;
-			pm_d = pm_u; pi_d = pi_u; pd_d = pd_u;
+#pragma unroll
+			for (int u = 0; u < DPB; ++u) {
+				const int i = i0 + u;
+				if (i > right) break;
+				const int b = ub[u];
+				const int sc = b == 0 ? mt0 : (b == 1 ? mt1 : (b == 2 ? mt2 : (b == 3 ? mt3 : mt4)));
+				int m, mt, iv = NINF, it = 0, dv, dt;
+				if (pm_d >= pi_d) { if (pm_d >= pd_d) { m = pm_d + sc; mt = FM; } else { m = pd_d + sc; mt = FD; } }
+				else { if (pi_d > pd_d) { m = pi_d + sc; mt = FI; } else { m = pd_d + sc; mt = FD; } }
+				const bool above = !(i == right && !(j + b1 - 1 > l1));
+				const int pm_u = um[u], pi_u = ui[u], pd_u = ud[u];
+				if (above) {
+					const int ipen = i == l1 ? end_pen : gap_ext;
+					if (pm_u - gap_open > pi_u) { it = FM; iv = pm_u - gap_open - ipen; } else { it = FI; iv = pi_u - ipen; }
+				}
+				if (cm_l - gap_open > cd_l) { dt = FM; dv = cm_l - gap_open - dpen; } else { dt = FD; dv = cd_l - dpen; }
+				ROW(0, cur, i) = m; ROW(1, cur, i) = iv; ROW(2, cur, i) = dv;
+				TBC(j, i) = (uint8_t)(mt | it << 2 | dt << 4);
+				cm_l = m; cd_l = dv;
+				pm_d = pm_u; pi_d = pi_u; pd_d = pd_u;
+			}
 		}
+#undef DPB
 	}
 	// backtrace
 	int i = l1, j = l2, score, type, ctype;
@@ -282,23 +303,36 @@ __global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
 				E(i) = a << 16 | b;
 			}
 		}
+		const int mt0 = mat[0], mt1 = mat[1], mt2 = mat[2], mt3 = mat[3], mt4 = mat[4];      // this row's scores against A, C, G, T, N
 		int sv = E(0);                                   // *s with s = &eh[i-1]
-		for (int i = 1; i != tmp_len; ++i) {
-			const int sn = E(i);                         // *(s+1)
-			int curr_h = (sv >> 16) + mat[s1[i]];
-			if (curr_h < 0) curr_h = 0;
-			if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
-			if (sn >= qr_shift) {
-				const int curr_last_h = sn >> 16;
-				const int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
-				if (curr_h < e) curr_h = e;
-				E(i - 1) = last_h << 16 | e;
-			} else E(i - 1) = last_h << 16;
-			last_h = curr_h;
-			if (subo < curr_h) subo = curr_h;
-			if (score_f < curr_h) { score_f = curr_h; end_i = i; end_j = j; if (score_f > 32000) is_overflow = 1; }
-			sv = sn;
+		// LB cells at a time: their row words and bases are fetched together (a cell reads eh[i] before any cell of this row has
+		// written it -- the writes go to eh[i-1] -- so the values are the ones the one-by-one loop would have seen)
+#define LB 8
+		for (int i0 = 1; i0 < tmp_len; i0 += LB) {
+			int us[LB], ub[LB];
+#pragma unroll
+			for (int u = 0; u < LB; ++u) { us[u] = 0; ub[u] = 4; if (i0 + u < tmp_len) { us[u] = E(i0 + u); ub[u] = s1[i0 + u]; } }
+#pragma unroll
+			for (int u = 0; u < LB; ++u) {
+				const int i = i0 + u;
+				if (i >= tmp_len) break;
+				const int sn = us[u], b = ub[u];                 // *(s+1)
+				int curr_h = (sv >> 16) + (b == 0 ? mt0 : (b == 1 ? mt1 : (b == 2 ? mt2 : (b == 3 ? mt3 : mt4))));
+				if (curr_h < 0) curr_h = 0;
+				if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
+				if (sn >= qr_shift) {
+					const int curr_last_h = sn >> 16;
+					const int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
+					if (curr_h < e) curr_h = e;
+					E(i - 1) = last_h << 16 | e;
+				} else E(i - 1) = last_h << 16;
+				last_h = curr_h;
+				if (subo < curr_h) subo = curr_h;
+				if (score_f < curr_h) { score_f = curr_h; end_i = i; end_j = j; if (score_f > 32000) is_overflow = 1; }
+				sv = sn;
+			}
 		}
+#undef LB
 		E(l1) = last_h << 16;
 		suba[j] = subo + of_base;
 	}
@@ -324,24 +358,39 @@ __global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
 				E(i + 1) = a << 16 | b;
 			}
 		}
+		const int mt0 = mat[0], mt1 = mat[1], mt2 = mat[2], mt3 = mat[3], mt4 = mat[4];
 		int i = start;
-		for (; i != end && i >= 0; --i) {                // s = &eh[i+1]
-			const int sv = E(i + 1), sp = E(i);          // *s and *(s-1)
-			int curr_h = (sv >> 16) + mat[s1[i]];
-			if (curr_h < 0) curr_h = 0;
-			if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
-			const int curr_last_h = sp >> 16;
-			int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
-			if (e < 0) e = 0;
-			if (curr_h < e) curr_h = e;
-			E(i + 1) = last_h << 16 | e;
-			last_h = curr_h;
-			if (score_r < curr_h) {
-				score_r = curr_h; start_i = i; start_j = j;
-				if (score_r + of_base - qr == score_f) { j = 1; break; }
-				if (score_r > 32000) is_overflow = 1;
+		// the same in blocks, downwards: cell i reads eh[i+1] and eh[i] and writes eh[i+1]; eh[i] is the next cell's eh[i+1], carried
+		bool found = false;
+		int sv = (i != end && i >= 0) ? E(i + 1) : 0;   // *s with s = &eh[i+1]
+#define LB 8
+		while (i != end && i >= 0 && !found) {
+			int us[LB], ub[LB];
+#pragma unroll
+			for (int u = 0; u < LB; ++u) { us[u] = 0; ub[u] = 4; const int ii = i - u; if (ii >= 0 && (u == 0 || ii > end || end > i)) { us[u] = E(ii); ub[u] = s1[ii]; } }
+#pragma unroll
+			for (int u = 0; u < LB; ++u) {
+				if (i == end || i < 0) break;
+				const int sp = us[u], b = ub[u];         // *(s-1)
+				int curr_h = (sv >> 16) + (b == 0 ? mt0 : (b == 1 ? mt1 : (b == 2 ? mt2 : (b == 3 ? mt3 : mt4))));
+				if (curr_h < 0) curr_h = 0;
+				if (last_h > 0) { f = (f > last_h - q) ? f - r : last_h - qr; if (curr_h < f) curr_h = f; }
+				const int curr_last_h = sp >> 16;
+				int e = ((sv & 0xffff) > curr_last_h - q) ? (sv & 0xffff) - r : curr_last_h - qr;
+				if (e < 0) e = 0;
+				if (curr_h < e) curr_h = e;
+				E(i + 1) = last_h << 16 | e;
+				last_h = curr_h;
+				if (score_r < curr_h) {
+					score_r = curr_h; start_i = i; start_j = j;
+					if (score_r + of_base - qr == score_f) { j = 1; found = true; break; }
+					if (score_r > 32000) is_overflow = 1;
+				}
+				sv = sp;
+				--i;
 			}
 		}
+#undef LB
 		E(i + 1) = last_h << 16;                         // on the break, s was not advanced: same cell
 		if ((E(start) >> 16) <= qr) --start;
 		if (start <= 0) start = 0;

@@ -137,7 +137,19 @@ static int build_one(nabwa_index *ix, int t_, const uint32_t *words, uint64_t n_
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(hipMemGetInfo(&free_b, &total_b));
 		auto table_entries = [](int t) { size_t x = 0; for (int u = 1; u <= t; ++u) x += (size_t)1 << (2 * u); return x; };
-		while (T > 12 && table_entries(T) * 8 > free_b / 5 * 2) --T;
+		/* both directions must get the same depth (the search runs without tables otherwise): the first one built decides, leaving
+		 * room for the second; the second takes that depth, and says so loudly if it cannot */
+		if (ix->kmer_T_pick < 0) {
+			while (T > 12 && 2 * table_entries(T) * 8 > free_b / 5 * 3) --T;
+			ix->kmer_T_pick = T;
+		} else {
+			T = ix->kmer_T_pick;
+			if (T >= 1 && table_entries(T) * 8 > free_b / 10 * 9) {
+				fprintf(stderr, "[nabwa] WARNING: no device memory for the second interval table of depth %d (%zu MB free): the search runs WITHOUT interval tables "
+								"(several times slower); free device memory or set NABWA_KMER_T lower\n", T, free_b >> 20);
+				T = 0;
+			}
+		}
 		if (T >= 1) {
 			const size_t lo_n = table_entries(T);
 			HIPCHK(hipMalloc(&ix->kmer[t_], lo_n * 8));

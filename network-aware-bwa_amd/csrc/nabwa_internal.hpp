@@ -23,6 +23,7 @@ struct nabwa_index {
 	uint32_t *sa_full[2], *isa[2], *text[2];   // text-mode companions (nabwa_dev.hpp), null when switched off
 	uint2 *kmer[2], *kmer_top[2];  // interval table: levels 1..LW back to back; level T on its own when T > LW (else inside the former)
 	uint64_t bytes;
+	int kmer_T_pick = -1;           // depth of the interval tables, decided when the first direction is built
 	nabwa_reference *ref;
 	struct nabwa_dev_pool *pool;   // released working buffers of earlier batches, kept for the next one (nabwa_api.hip)
 };
