@@ -60,3 +60,30 @@ def test_pairing_golden():
             want = [int(x) for x in v["pr_out"][t][11 * e:11 * e + 11]]
             got = [getattr(ends[e], f) for f, _ in nabwa.PeEnd._fields_]
             assert got == want, (t, e)
+
+
+def test_isize_add_pairs_bins_like_isize_bin_and_wraps():
+    """improve_isize_est over a batch of positioned pairs (insert_size.c:141-165): the same bins as nabwa_isize_bin record by
+    record, and the reference's uint16_t bins wrap"""
+    rng = np.random.default_rng(3)
+    n = 70000
+    recs = (nabwa.PeRec * (2 * n))()
+    want = np.zeros(100000, np.uint16)
+    L = nabwa.lib()
+    for i in range(n):
+        a, b = recs[2 * i].se, recs[2 * i + 1].se
+        a.mapQ, b.mapQ = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        a.len, b.len = 100, int(rng.integers(30, 101))
+        a.pos = int(rng.integers(0, 1 << 20))
+        b.pos = int(rng.integers(0, 1 << 20))
+        if i % 3 == 0:                                                              # every third pair lands in ONE bin
+            a.mapQ = b.mapQ = 37
+            b.len, b.pos = 100, a.pos + 250
+        k = L.nabwa_isize_bin(2, a.mapQ, b.mapQ, a.pos, a.len, b.pos, b.len)
+        if k >= 0:
+            want[k] += 4                                                            # numpy wraps uint16 the way the reference's array does
+    got = np.zeros(100000, np.uint16)
+    for _ in range(4):                                                              # four batches into the same histogram: 93 k in bin 350
+        nabwa.isize_add_pairs(recs, n, got)
+    assert (got == want).all()
+    assert int(got[350]) == (4 * ((n + 2) // 3)) % 65536 and 4 * ((n + 2) // 3) > 65535
