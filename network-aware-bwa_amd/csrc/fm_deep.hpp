@@ -39,4 +39,3 @@ struct DeepParams {
 	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
 	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures, [6] rank steps and [7] text finishes of exact tails (lane counts)
 };
-

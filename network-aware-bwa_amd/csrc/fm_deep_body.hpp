@@ -89,7 +89,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #endif
 							)
 {
-	const DeepParams P = P_;          /* (a by-value copy: the kernel argument stays in scalar registers / the kernarg segment) */
+	const DeepParams P = P_;          /* (a by-value copy: the kernel argument stays in scalar registers / the kernarg segment; splitting its tuples
+	                                   * with nabwa_dev.hpp's own() as fm_search_kernel does was measured here too: no gain) */
 	const SearchParams &S = P.S;
 	// this wave's LDS: per score level the entry count and the top page; the pages a commit takes; and (lds_rd > 0) the read's
 	// own data -- bound bytes, seed bound bytes, bases of both strands -- copied in when the read starts

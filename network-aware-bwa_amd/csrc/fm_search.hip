@@ -333,8 +333,14 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 #define LS_EXIT  4
 
 template <bool WIDE, bool COUNT>
-__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P)
+__global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P_)
 {
+	SearchParams P = P_;
+	// the gap options as scalar values of their own (nabwa_dev.hpp: own): they arrive as one 256-bit tuple, which this kernel -- it has
+	// more uniform values than scalar registers -- spilled whole and read back, all eight dwords, at 26 places.  (Doing the same for
+	// EVERY argument removes more v_readlane instructions still, 492 -> 212, and makes the kernel 3 % slower: measured, not kept.)
+	own(P.n); own(P.s_mm); own(P.s_gapo); own(P.s_gape); own(P.mode); own(P.indel_end_skip); own(P.max_del_occ); own(P.max_entries);
+	own(P.max_gape); own(P.max_seed_diff); own(P.seed_len); own(P.max_top2);
 	const uint32_t NIL = WIDE ? 0xffffffffu : 0xffffu;
 	const uint32_t lane = threadIdx.x & 63u;
 	const size_t slot = (size_t)blockIdx.x * NABWA_SEARCH_BLOCK + threadIdx.x;

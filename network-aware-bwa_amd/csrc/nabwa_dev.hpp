@@ -45,6 +45,20 @@ struct DevBwt {
 	const uint32_t *text;      // the indexed text itself, 2 bits per base, base j in word j>>4 at bits 2*(j&15)
 };
 
+#ifndef NABWA_EMU
+// Kernel arguments reach a kernel as wide scalar loads (s_load_dwordx8 / x16), and a value that is part of such a tuple stays
+// tied to it: when the kernel has more uniform values than scalar registers -- the search kernels do -- the register allocator
+// spills the whole tuple and reads ALL its dwords back through v_readlane wherever one of them is used.  Copies made through an
+// opaque move are values of their own: spilled and reloaded one by one, only where used.
+__device__ __forceinline__ uint32_t own_u32(uint32_t x) { uint32_t v; asm volatile("s_mov_b32 %0, %1" : "=s"(v) : "s"(x)); return v; }
+__device__ __forceinline__ uint64_t own_u64(uint64_t x) { uint64_t v; asm volatile("s_mov_b64 %0, %1" : "=s"(v) : "s"(x)); return v; }
+template <class T> __device__ __forceinline__ void own(T &x)
+{
+	if (sizeof(T) == 4) { uint32_t u; __builtin_memcpy(&u, &x, 4); u = own_u32(u); __builtin_memcpy(&x, &u, 4); }
+	else if (sizeof(T) == 8) { uint64_t u; __builtin_memcpy(&u, &x, 8); u = own_u64(u); __builtin_memcpy(&x, &u, 8); }
+}
+#endif
+
 struct Occ4 { uint32_t c[4]; };
 
 // counts of the four bases in rows [192*b, 192*b + r] of a bucket already in registers
