@@ -118,8 +118,9 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 		n_hit_rows += rows.size();
 		std::vector<uint32_t> sa(rows.size());
 		if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
+		fin_parallel(fin_threads(pairs.size()), pairs.size(), [&](int, size_t t_lo, size_t t_hi) {      /* pairs are independent of each other */
 		std::vector<uint64_t> hits;
-		for (size_t t = 0; t < pairs.size(); ++t) {
+		for (size_t t = t_lo; t < t_hi; ++t) {
 			const int pr = pairs[t];
 			hits.clear();
 			size_t u = pair_lo[t];
@@ -145,6 +146,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 				s.n_gape = e[j].n_gape; s.score = e[j].score; r.extra_flag = e[j].extra_flag;
 			}
 		}
+		});
 		p0 = p1;
 	}
 	t1 = now();
@@ -152,7 +154,13 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 	/* ---- B. multi-hit lists and their positions (bam2bam.c:773-790) */
 	{
 		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look_rec, look_multi;
-		for (int pr = 0; pr < n_pairs; ++pr)
+		const int ntb = fin_threads((size_t)n_pairs);
+		struct MultiPart { std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look_rec, look_multi; };
+		std::vector<MultiPart> parts((size_t)ntb);
+		fin_parallel(ntb, (size_t)n_pairs, [&](int slice, size_t p_lo, size_t p_hi) {
+		MultiPart &M = parts[(size_t)slice];
+		std::vector<uint8_t> &which = M.which; std::vector<uint32_t> &rows = M.rows; std::vector<int> &look_rec = M.look_rec, &look_multi = M.look_multi;
+		for (int pr = (int)p_lo; pr < (int)p_hi; ++pr)
 			for (int j = 0; j < 2; ++j) {
 				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &s = r.se;
 				s.n_multi = 0;
@@ -165,6 +173,11 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 					which.push_back(s.multi[z].strand ? 0 : 1); rows.push_back(s.multi[z].pos); look_rec.push_back(2 * pr + j); look_multi.push_back(z);
 				}
 			}
+		});
+		for (MultiPart &M : parts) {
+			which.insert(which.end(), M.which.begin(), M.which.end()); rows.insert(rows.end(), M.rows.begin(), M.rows.end());
+			look_rec.insert(look_rec.end(), M.look_rec.begin(), M.look_rec.end()); look_multi.insert(look_multi.end(), M.look_multi.begin(), M.look_multi.end());
+		}
 		std::vector<uint32_t> sa(rows.size());
 		if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
 		for (size_t t = 0; t < rows.size(); ++t) {
@@ -182,13 +195,21 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 		std::vector<int64_t> ro(1, 0), qo(1, 0); std::vector<uint8_t> rb, qb;
 		std::vector<int64_t> begs((size_t)n, 0);                         /* beg[k] of every attempted end, by record index */
 		std::vector<int> job_of((size_t)n, -1);
-		for (int pr = 0; pr < n_pairs; ++pr) {
-			nabwa_pe_t &r0 = PE(out, pr, 0), &r1 = PE(out, pr, 1);
-			if (!((r0.se.mapQ >= SW_MIN_MAPQ || r1.se.mapQ >= SW_MIN_MAPQ) && (r0.extra_flag & F_PP) == 0)) continue;
-			const int single = (r0.se.type == 0 || r1.se.type == 0) ? 1 : 0;
-			++n_tot[single];
-			if (single) continue;
-			cand.push_back(pr);
+		{	/* which pairs are tried: unpaired, one end with a high mapping quality, both ends mapped (slices of pairs in threads) */
+			const int ntc = fin_threads((size_t)n_pairs);
+			std::vector<std::vector<int>> cparts((size_t)ntc);
+			std::vector<uint64_t> tot0((size_t)ntc, 0), tot1((size_t)ntc, 0);
+			fin_parallel(ntc, (size_t)n_pairs, [&](int slice, size_t p_lo, size_t p_hi) {
+				for (int pr = (int)p_lo; pr < (int)p_hi; ++pr) {
+					const nabwa_pe_t &r0 = PE(out, pr, 0), &r1 = PE(out, pr, 1);
+					if (!((r0.se.mapQ >= SW_MIN_MAPQ || r1.se.mapQ >= SW_MIN_MAPQ) && (r0.extra_flag & F_PP) == 0)) continue;
+					const int single = (r0.se.type == 0 || r1.se.type == 0) ? 1 : 0;
+					if (single) ++tot1[(size_t)slice]; else { ++tot0[(size_t)slice]; cparts[(size_t)slice].push_back(pr); }
+				}
+			});
+			for (int t = 0; t < ntc; ++t) { n_tot[0] += tot0[(size_t)t]; n_tot[1] += tot1[(size_t)t]; cand.insert(cand.end(), cparts[(size_t)t].begin(), cparts[(size_t)t].end()); }
+		}
+		for (int pr : cand) {
 			for (int k = 0; k < 2; ++k) {
 				const nabwa_se_t &ref = PE(out, pr, 1 - k).se, &mate = PE(out, pr, k).se;
 				int64_t a, b;
