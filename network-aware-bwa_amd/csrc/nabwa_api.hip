@@ -204,7 +204,7 @@ static int env_int(const char *name, int dflt)
 
 /* Working buffers come from a per-index pool: a streaming caller makes one batch after the other, of about the same
  * size, and hipMalloc of the search arena (tens of GB) costs 0.5 - 1 s each time -- more than the search itself.
- * A released buffer is kept (up to NABWA_POOL_GB, default 48) and handed to the next request it fits within 25 %;
+ * A released buffer is kept (up to NABWA_POOL_GB, default 80: a 10 M-read batch holds about 20 GB, kernel D's page pool 32 GB) and handed to the next request it fits within 25 %;
  * everything cached goes back to the driver when an allocation fails and when the index is destroyed. */
 struct nabwa_dev_pool {
 	std::mutex mu;
@@ -323,7 +323,7 @@ extern "C" int nabwa_index_from_arrays(int device, int is_device, const uint32_t
 	HIPCHK(hipSetDevice(device));
 	nabwa_index *ix = new nabwa_index();
 	ix->pool = new nabwa_dev_pool();
-	ix->pool->limit = (size_t)env_int("NABWA_POOL_GB", 48) << 30;
+	ix->pool->limit = (size_t)env_int("NABWA_POOL_GB", 80) << 30;
 	memset(ix->bwt, 0, sizeof(ix->bwt)); ix->bk[0] = ix->bk[1] = 0; ix->sa[0] = ix->sa[1] = 0; ix->kmer[0] = ix->kmer[1] = 0; ix->kmer_top[0] = ix->kmer_top[1] = 0; for (int t = 0; t < 2; ++t) ix->sa_full[t] = ix->isa[t] = ix->text[t] = 0; ix->bytes = 0; ix->ref = 0;
 	ix->device = device;
 	int r = build_one(ix, 0, bwt0, nw0, is_device != 0, sa0, ns0);

@@ -29,15 +29,8 @@
 
 static inline nabwa_pe_t &PE(nabwa_pe_t *out, int pair, int end) { return out[2 * (size_t)pair + end]; }
 
-static void clear_record(nabwa_pe_t &r, int len, int full_len, int end)
-{
-	nabwa_se_t &s = r.se;
-	memset(&s, 0, offsetof(nabwa_se_t, cigar));
-	s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = -1; s.nn = 0; s.rpos = 0; s.xt = 0;
-	s.len = len; s.clip_len = len; s.full_len = full_len;
-	r.extra_flag = F_PD | (end ? F_R2 : F_R1);
-	r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0;
-}
+int nabwa_se_posn_strided(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
+						  const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride);      /* se_finish.hip */
 
 /* posn_pair (bam2bam.c:683-703) for n_pairs pairs; records and reads are interleaved: index 2*pair + end. */
 extern "C" int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, const int64_t *off, const int32_t *full_len,
@@ -45,25 +38,18 @@ extern "C" int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int 
 {
 	if (!ix || !opt || !rng48 || n_pairs < 0 || (n_pairs && (!off || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	const int n = 2 * n_pairs;
-	const uint32_t rlen = ix->bwt[1].seq_len;
-	std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look;
-	size_t a0 = 0;
-	for (int i = 0; i < n; ++i) {
-		const int len = (int)(off[i + 1] - off[i]);
-		clear_record(out[i], len, full_len ? full_len[i] : len, i & 1);
-		nabwa_se_t &s = out[i].se;
-		choose_main(s, n_aln[i], aln + a0, rng48);
-		a0 += n_aln[i];
-		if (s.type) { which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look.push_back(i); }
-	}
-	std::vector<uint32_t> sa(rows.size());
-	if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
-	for (size_t t = 0; t < rows.size(); ++t) {                                   /* bwase.c:139-154 */
-		nabwa_se_t &s = out[look[t]].se;
-		s.pos = which[t] == 0 ? sa[t] : rlen - (sa[t] + (uint32_t)s.len);
-		const int md = opt->fnr > 0.0f ? nabwa_cal_maxdiff(s.len, 0.02, opt->fnr) : opt->max_diff;
-		s.mapQ = s.seQ = approx_mapq(s, md);
-	}
+	/* the single-end part of posn_pair is posn_singleton without other hits listed (bam2bam.c:688-700): hit choice on the caller's
+	 * drand48 stream, the bwt_sa batch, mapQ -- done by the single-end chain's code on these records in place (its head is theirs) */
+	int rc = nabwa_se_posn_strided(ix, opt, n, off, full_len, n_aln, aln, 0, rng48, out, sizeof(nabwa_pe_t));
+	if (rc != NABWA_OK) return rc;
+	fin_parallel(fin_threads((size_t)n), (size_t)n, [&](int, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			nabwa_pe_t &r = out[i];
+			r.se.seqid = -1;
+			r.extra_flag = F_PD | ((i & 1) ? F_R2 : F_R1);
+			r.m_seqid = -1; r.m_rpos = 0; r.isize = 0; r.am = 0; r.mapQ_paired = 0;
+		}
+	});
 	return NABWA_OK;
 }
 

@@ -429,25 +429,67 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = now();
-	/* ---- host, record order: hit choice with the caller's RNG stream (bwase.c:19-95) */
+	/* ---- host: hit choice with the caller's RNG stream (bwase.c:19-95).  The stream is consumed in record order and how many
+	 * numbers a read takes depends on the numbers themselves (a second draw follows every accepted row), so ONE light serial pass
+	 * runs the generator alone over the batch -- two multiplications per draw, no record touched -- and notes its state at the slice
+	 * boundaries; the slices then do the whole choice in threads, each from its own state, and draw exactly what that pass drew. */
+	const int nt0 = host_threads(n);
+	std::vector<uint64_t> slice_state((size_t)nt0 + 1, 0); std::vector<size_t> slice_a0((size_t)nt0 + 1, 0);
+	{
+		uint64_t st = *rng48; size_t a0 = 0; int next = 0;
+		for (int i = 0; i <= n; ++i) {
+			while (next <= nt0 && (size_t)i == (size_t)n * next / nt0) { slice_state[next] = st; slice_a0[next] = a0; ++next; }
+			if (i == n) break;
+			const int na = n_aln[i]; const nabwa_aln1_t *A = aln + a0;
+			a0 += na;
+			if (na == 0) continue;
+			int cnt = 0; const int best = A[0].score;
+			for (int j = 0; j < na; ++j) {                       /* choose_main's draws, nothing else */
+				if (A[j].score > best) break;
+				const uint32_t w = A[j].l - A[j].k + 1;
+				if (rng48_next(&st) * (double)(w + cnt) > (double)cnt) (void)rng48_next(&st);
+				cnt += w;
+			}
+		}
+		*rng48 = st;
+	}
+	struct Part { std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<int> look_rec, look_multi; };
+	std::vector<Part> parts((size_t)nt0);
+	{
+		std::vector<std::thread> th;
+		auto work = [&](int t) {
+			Part &Q = parts[(size_t)t];
+			const size_t lo = (size_t)n * t / nt0, hi = (size_t)n * (t + 1) / nt0;
+			Q.which.reserve((hi - lo) + (hi - lo) / 4); Q.rows.reserve((hi - lo) + (hi - lo) / 4); Q.look_rec.reserve((hi - lo) + (hi - lo) / 4); Q.look_multi.reserve((hi - lo) + (hi - lo) / 4);
+			uint64_t st = slice_state[(size_t)t]; size_t a0 = slice_a0[(size_t)t];
+			for (size_t i = lo; i < hi; ++i) {
+				nabwa_se_t &s = out_at(i);
+				memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
+				s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
+				const int len = (int)(off[i + 1] - off[i]);
+				s.len = len; s.clip_len = len; s.full_len = full_len ? full_len[i] : len;
+				const nabwa_aln1_t *A = aln + a0; const int na = n_aln[i];
+				a0 += na;
+				if (na == 0) continue;
+				choose_main(s, na, A, &st);
+				list_multi(s, na, A, n_occ_v ? (int)n_occ_v[i] : n_occ);
+				Q.which.push_back(s.strand ? 0 : 1); Q.rows.push_back(s.sa); Q.look_rec.push_back((int)i); Q.look_multi.push_back(-1);
+				for (int j = 0; j < s.n_multi; ++j) {
+					Q.which.push_back(s.multi[j].strand ? 0 : 1); Q.rows.push_back(s.multi[j].pos); Q.look_rec.push_back((int)i); Q.look_multi.push_back(j);
+				}
+			}
+		};
+		if (nt0 == 1) work(0);
+		else { for (int t = 0; t < nt0; ++t) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+	}
 	std::vector<uint8_t> which; std::vector<uint32_t> rows;           /* SA lookups: [main of each mapped read][multi...] */
 	std::vector<int> look_rec, look_multi;
-	which.reserve((size_t)n + n / 4); rows.reserve((size_t)n + n / 4); look_rec.reserve((size_t)n + n / 4); look_multi.reserve((size_t)n + n / 4);
-	size_t a0 = 0;
-	for (int i = 0; i < n; ++i) {
-		nabwa_se_t &s = out_at(i);
-		memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
-		s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
-		const int len = (int)(off[i + 1] - off[i]);
-		s.len = len; s.clip_len = len; s.full_len = full_len ? full_len[i] : len;
-		const nabwa_aln1_t *A = aln + a0; const int na = n_aln[i];
-		a0 += na;
-		if (na == 0) continue;
-		choose_main(s, na, A, rng48);
-		list_multi(s, na, A, n_occ_v ? (int)n_occ_v[i] : n_occ);
-		which.push_back(s.strand ? 0 : 1); rows.push_back(s.sa); look_rec.push_back(i); look_multi.push_back(-1);
-		for (int j = 0; j < s.n_multi; ++j) {
-			which.push_back(s.multi[j].strand ? 0 : 1); rows.push_back(s.multi[j].pos); look_rec.push_back(i); look_multi.push_back(j);
+	{
+		size_t tot = 0; for (Part &Q : parts) tot += Q.rows.size();
+		which.reserve(tot); rows.reserve(tot); look_rec.reserve(tot); look_multi.reserve(tot);
+		for (Part &Q : parts) {
+			which.insert(which.end(), Q.which.begin(), Q.which.end()); rows.insert(rows.end(), Q.rows.begin(), Q.rows.end());
+			look_rec.insert(look_rec.end(), Q.look_rec.begin(), Q.look_rec.end()); look_multi.insert(look_multi.end(), Q.look_multi.begin(), Q.look_multi.end());
 		}
 	}
 	const double t1 = now();
