@@ -33,9 +33,8 @@
 // trip; the gap children of an expansion are one grouped stack entry, materialised only if popped; the
 // next pop is fetched ahead into LDS while a tail is walked; reads with an exact occurrence (kernel W's
 // class) are searched first, by waves that refill all 64 lanes together.
-// First pass: bump allocation (arena = pushes that reach memory).  Reads that outgrow the arena
-// or the per-read hit list are flagged and re-run from scratch by the WIDE instantiation
-// (32-bit links, slot reuse, arena of max_entries+16 live entries) -- never on the CPU.
+// Bump allocation (arena = pushes that reach memory).  Reads that outgrow the arena, the per-read hit list or the trip budget
+// are flagged and searched from the start by kernel D (fm_deep.hip: one search per wavefront, paged arenas) -- never on the CPU.
 #include "nabwa_dev.hpp"
 #include "fm_search.hpp"
 
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 #define LS_EXACT 3   // inside an exact tail (bwt.c:237-252), next position e_i - 1
 #define LS_EXIT  4
 
-template <bool WIDE, bool COUNT>
+template <bool COUNT>
 __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search_kernel(const SearchParams P_)
 {
 	SearchParams P = P_;
@@ -341,24 +340,20 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// EVERY argument removes more v_readlane instructions still, 492 -> 212, and makes the kernel 3 % slower: measured, not kept.)
 	own(P.n); own(P.s_mm); own(P.s_gapo); own(P.s_gape); own(P.mode); own(P.indel_end_skip); own(P.max_del_occ); own(P.max_entries);
 	own(P.max_gape); own(P.max_seed_diff); own(P.seed_len); own(P.max_top2);
-	const uint32_t NIL = WIDE ? 0xffffffffu : 0xffffu;
+	const uint32_t NIL = 0xffffu;
 	const uint32_t lane = threadIdx.x & 63u;
 	const size_t slot = (size_t)blockIdx.x * NABWA_SEARCH_BLOCK + threadIdx.x;
 	uint8_t *const sc = P.scratch + slot * P.lane_stride;
 	uint4 *const ent = (uint4*)sc;
-	uint32_t *const lnk = (uint32_t*)(sc + P.off_link);     // WIDE only
-	uint32_t *const freel = (uint32_t*)(sc + P.off_free);   // WIDE only
-	uint32_t *const ghead = (uint32_t*)(sc + P.off_head);   // WIDE only
 	const bool gape_mode = P.mode & 0x01, nonstop = P.mode & 0x10, loggap = P.mode & 0x04;
 
 	int st = LS_IDLE;
 	unsigned int w_next = 0, w_end = 0; bool w_sync = false;   // this wave's block of read numbers; lockstep mode
 	// per-read
-	uint32_t item = 0, rid_w = 0; int len = 0; uint32_t mdmg = 0;   // mdmg: this read's max_diff | max_gapo << 8
+	uint32_t item = 0; int len = 0; uint32_t mdmg = 0;   // mdmg: this read's max_diff | max_gapo << 8
 	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
-	// the few reads of the second pass carry no LDS: they walk every tail step by step
-	const int KT = WIDE ? 0 : (int)P.bwt[0].kmer_T;         // 0 also in the touch-counting run
-#define RID (WIDE ? rid_w : item)                           /* the first pass takes reads in batch order (P.ids == 0) */
+	const int KT = (int)P.bwt[0].kmer_T;                    // 0 in the touch-counting run
+#define RID item                                            /* results and width records are indexed by read */
 #define REC (P.wdata + (size_t)RID * P.wstride)            /* this read's width record (kernel W) */
 #define MD_READ ((int)(mdmg & 0xffu))
 #define MG_READ ((int)(mdmg >> 8))
@@ -366,7 +361,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint32_t k = 0, l = 0;
 	// search globals
 	int max_diff = 0, best_score = 0, best_cnt = 0, n_aln = 0, max_ent = 0, n_entries = 0;
-	uint32_t bump = 0, nfree = 0; uint64_t mask_lo = 0, mask_hi = 0; bool seeded = false; int status = 0;   // masks: non-empty scores; the first pass has at most 64 levels (host) and uses mask_lo only
+	uint32_t bump = 0; uint64_t mask_lo = 0; bool seeded = false; int status = 0;   // masks: non-empty scores; the first pass has at most 64 levels (host) and uses mask_lo only
 	// current entry
 	int e_i = 0, e_a = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_ldp = 0, e_score = 0, m = 0;
 	// pending entry: the last child pushed by the previous expansion, still in registers
@@ -379,25 +374,23 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	int sq_tag = -1;                     // 16 read bases
 	int bw_base = -1, bw_a = -1;         // 16 bound bytes of strand bw_a from bw_base
 	int sw_base = -1, sw_a = -1;         // same for the seed bounds
-	uint4 wq_sq = make_uint4(0, 0, 0, 0), wq_bw = wq_sq, wq_sw = wq_sq;   // WIDE only (no LDS): the same windows in registers
 	unsigned long long touches = 0; uint32_t rd_touch = 0, rd_trips = 0;  // COUNT only
 	uint32_t rk_kf = 0, rk_row2 = 0, rk_row1 = 0, rk_tx = 0, rk_pop = 0, rk_tail = 0, rk_jump = 0, rk_gap = 0;   // COUNT only: this read's trips by kind
 	unsigned long long st_trips = 0, st_expand = 0, st_exact = 0, st_ent = 0, st_spec = 0, st_query = 0, st_two = 0, st_exit = 0, st_jump = 0, st_txe = 0, st_txt = 0;
 	bool ovf = false;
 
 	auto head_get = [&](int score) -> uint32_t {
-		return WIDE ? ghead[score] : (uint32_t)s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x];
+		return (uint32_t)s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x];
 	};
 	auto head_set = [&](int score, uint32_t v) {
-		if (WIDE) ghead[score] = v; else s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x] = (uint16_t)v;
+		s_head[score * NABWA_SEARCH_BLOCK + threadIdx.x] = (uint16_t)v;
 	};
-	auto mask_has = [&](int score) -> bool { if (!WIDE) return mask_lo >> score & 1ull; return score < 64 ? (mask_lo >> score & 1ull) : (mask_hi >> (score - 64) & 1ull); };
-	auto mask_set = [&](int score) { if (!WIDE || score < 64) mask_lo |= 1ull << score; else mask_hi |= 1ull << (score - 64); };
-	auto mask_clr = [&](int score) { if (!WIDE || score < 64) mask_lo &= ~(1ull << score); else mask_hi &= ~(1ull << (score - 64)); };
-	auto mask_any = [&]() -> bool { return WIDE ? (mask_lo | mask_hi) != 0ull : mask_lo != 0ull; };
+	auto mask_has = [&](int score) -> bool { return mask_lo >> score & 1ull; };
+	auto mask_set = [&](int score) { mask_lo |= 1ull << score; };
+	auto mask_clr = [&](int score) { mask_lo &= ~(1ull << score); };
+	auto mask_any = [&]() -> bool { return mask_lo != 0ull; };
 	auto mask_first = [&]() -> int {          // lowest non-empty score, 0x7fffffff when none
-		if (mask_lo) return __ffsll((unsigned long long)mask_lo) - 1;
-		return (WIDE && mask_hi) ? 64 + __ffsll((unsigned long long)mask_hi) - 1 : 0x7fffffff;
+		return mask_lo ? __ffsll((unsigned long long)mask_lo) - 1 : 0x7fffffff;
 	};
 	// After the first hit best_score is final (bwtgap.c:170), and the loop ends at the first pop whose score
 	// exceeds best_score + s_mm (bwtgap.c:144): such a child can never be expanded.  It is still COUNTED
@@ -407,17 +400,15 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// the arena word of an entry: {k, l, i | last_diff_pos << 16, counters / state / strand (+ the list link, first pass)}
 	auto mk_entry = [&](uint32_t nk, uint32_t nl, int ni, int nldp, int nmm, int ngo, int nge, int nstate, int na) -> uint4 {
 		const uint32_t z = (uint32_t)ni | (uint32_t)nldp << 16;
-		if (WIDE) return make_uint4(nk, nl, z, (uint32_t)nmm | (uint32_t)ngo << 8 | (uint32_t)nge << 16 | (uint32_t)nstate << 24 | (uint32_t)na << 26);
 		return make_uint4(nk, nl, z, (uint32_t)nmm << 16 | (uint32_t)ngo << 20 | (uint32_t)nge << 24 | (uint32_t)nstate << 29 | (uint32_t)na << 31);
 	};
 	auto push_mem = [&](int score, uint4 e) {
 		if (ovf || never_popped(score)) return;
 		if ((uint32_t)score >= P.NS) { ovf = true; return; }       // cannot happen (nabwa_api.hip sizes NS); the second pass would take over
-		uint32_t s;
-		if (WIDE && nfree) s = freel[--nfree];
-		else { if (bump >= P.cap) { ovf = true; return; } s = bump++; }
+		if (bump >= P.cap) { ovf = true; return; }
+		const uint32_t s = bump++;
 		const uint32_t prev = mask_has(score) ? head_get(score) : NIL;
-		if (WIDE) lnk[s] = prev; else e.w |= prev;
+		e.w |= prev;
 		ent[s] = e;
 		head_set(score, s);
 		mask_set(score);
@@ -436,43 +427,35 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	// s_fb: per strand (byte a) the lower bound of differences of the read's first len-KT symbols, bound[len-KT-1] -- what
 	// decides whether every level down to depth KT is a forced match (see the tail jump); 0xff: unknown / no longer valid
 	uint32_t *const s_fb = s_sq + 4 * NABWA_SEARCH_BLOCK;
-	auto win_byte = [&](const uint32_t *W, const uint4 &q, uint32_t idx) -> uint32_t {
-		if (WIDE) { const uint32_t w = idx < 8u ? (idx < 4u ? q.x : q.y) : (idx < 12u ? q.z : q.w); return w >> ((idx & 3u) << 3) & 0xffu; }
+	auto win_byte = [&](const uint32_t *W, uint32_t idx) -> uint32_t {
 		return (uint32_t)((const uint8_t*)W)[(threadIdx.x << 4) + idx];
 	};
-	// 16 bytes from global memory into this lane's window slot (first pass) or into the register copy (second pass)
-	auto win_load = [&](const void *src, uint32_t *W, uint4 &q) {
-		if (WIDE) { const uint2 *p2 = (const uint2*)src; const uint2 u = p2[0], v = p2[1]; q = make_uint4(u.x, u.y, v.x, v.y); return; }
+	// 16 bytes from global memory into this lane's window slot
+	auto win_load = [&](const void *src, uint32_t *W) {
 		__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
 										 (void __attribute__((address_space(3)))*)(W + ((threadIdx.x & ~63u) << 2)), 16, 0, 0);
 	};
-#define BW_BYTE(i_) win_byte(s_bw, wq_bw, (uint32_t)(i_))
-#define SW_BYTE(i_) win_byte(s_sw, wq_sw, (uint32_t)(i_))
-#define SQ_BYTE(i_) win_byte(s_sq, wq_sq, (uint32_t)(i_))
+#define BW_BYTE(i_) win_byte(s_bw, (uint32_t)(i_))
+#define SW_BYTE(i_) win_byte(s_sw, (uint32_t)(i_))
+#define SQ_BYTE(i_) win_byte(s_sq, (uint32_t)(i_))
 	// Key form.  With all levels of the interval table present, a gap-free entry of depth d <= KT (d = len - i reference symbols
 	// matched, substitutions included) needs no interval at all: its path key addresses level d, its four children are the
 	// 32 bytes at level d+1, its exact tail or forced walk lands at level KT under (key ++ the read's next symbols).  Such
 	// entries are carried as {k = key, l = KEYM}, are expanded without a rank query, and take on rows (one table load)
 	// when they are reported, reach depth KT, or yield a gap child that is popped.
-	const bool kf_ok = !WIDE && KT > 0 && (int)P.bwt[0].kmer_LW == KT && (int)P.bwt[1].kmer_LW == KT && (P.text_mode & 4);
-	const bool text_ok = !WIDE && (P.text_mode & 2) && P.bwt[0].sa_full && P.bwt[1].sa_full && P.bwt[0].seq_len < 0xfffffff0u;
+	const bool kf_ok = KT > 0 && (int)P.bwt[0].kmer_LW == KT && (int)P.bwt[1].kmer_LW == KT && (P.text_mode & 4);
+	const bool text_ok = (P.text_mode & 2) && P.bwt[0].sa_full && P.bwt[1].sa_full && P.bwt[0].seq_len < 0xfffffff0u;
 	uint32_t pf_slot = NIL;
 	bool finish = false;
 	// unpack a popped arena entry into the current-entry registers and unlink it (bwtgap.c:66-79)
 	auto unpack = [&](const uint4 &r) {
 		k = r.x; l = r.y; e_i = (int)(r.z & 0xffffu); e_ldp = (int)(r.z >> 16);
-		if (WIDE) {
-			e_mm = (int)(r.w & 0xffu); e_go = (int)(r.w >> 8 & 0xffu); e_ge = (int)(r.w >> 16 & 0xffu);
-			e_state = (int)(r.w >> 24 & 3u); e_a = (int)(r.w >> 26 & 1u);
-		} else {
-			e_mm = (int)(r.w >> 16 & 15u); e_go = (int)(r.w >> 20 & 15u); e_ge = (int)(r.w >> 24 & 31u);
-			e_state = (int)(r.w >> 29 & 3u); e_a = (int)(r.w >> 31);
-		}
+		e_mm = (int)(r.w >> 16 & 15u); e_go = (int)(r.w >> 20 & 15u); e_ge = (int)(r.w >> 24 & 31u);
+		e_state = (int)(r.w >> 29 & 3u); e_a = (int)(r.w >> 31);
 	};
-	auto take_entry = [&](const uint4 &r_ent, uint32_t r_lnk, uint32_t ent_slot) {
+	auto take_entry = [&](const uint4 &r_ent) {
 		unpack(r_ent);
-		const uint32_t nx = WIDE ? r_lnk : (r_ent.w & 0xffffu);
-		if (WIDE) freel[nfree++] = ent_slot;
+		const uint32_t nx = r_ent.w & 0xffffu;
 		head_set(e_score, nx);
 		if (nx == NIL) mask_clr(e_score);
 		--n_entries;
@@ -504,10 +487,10 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				const unsigned int idx = base + rank;
 				if (idx < (unsigned int)P.n) {
 					const uint32_t rid = P.ids ? (uint32_t)P.ids[idx] : idx;
-					item = WIDE ? (P.res_slot ? (uint32_t)P.res_slot[rid] : idx) : rid;   // results: by slot (wide passes) / by read (first pass)
+					item = rid;
 					const int64_t o = P.poff[rid];
 					len = P.rd_len[rid];
-					sq_off = (uint32_t)o; rid_w = rid;
+					sq_off = (uint32_t)o;
 					mdmg = (uint32_t)P.rd_maxdiff[rid] | (uint32_t)P.rd_maxgapo[rid] << 8;
 					if (KT) {
 						s_key[threadIdx.x] = *(const uint2*)(P.rd_key + 6 * (size_t)rid);   // interval-table keys of the two strands
@@ -526,7 +509,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 						best_score = (MD_READ + 1) * P.s_mm + (MG_READ + 1) * P.s_gapo + (P.max_gape + 1) * P.s_gape;
 						best_cnt = 0;
 						// roots: strand 0 is pushed first, strand 1 second -> strand 1 (pending) is expanded first
-						bump = 0; nfree = 0; mask_lo = 0ull; mask_hi = 0ull;
+						bump = 0; mask_lo = 0ull;
 						push_mem(0, mk_entry(0u, kf_ok ? KEYM : P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 0));
 						pe = mk_entry(0u, kf_ok ? KEYM : P.bwt[0].seq_len, len, 0, 0, 0, 0, STATE_M, 1); p_score = 0;
 						n_entries = 2;
@@ -565,14 +548,10 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 					if (ovf) { status = NABWA_ST_OVERFLOW; finish = true; }
 					else {
 						ent_slot = head_get(best_mem); e_score = best_mem;
-						if (!WIDE && ent_slot == pf_slot) {                 // already here: pop it and go on in this trip
+						if (ent_slot == pf_slot) {                          // already here: pop it and go on in this trip
 							const uint4 r = s_pf[threadIdx.x];
-							take_entry(r, 0u, ent_slot);
+							take_entry(r);
 							pf_slot = NIL;
-							if (!finish) have = true;
-						} else if (WIDE && P.wide_inline) {                   // a wide pass is a few lanes walking dependent trips: waiting for the
-							const uint4 r = ent[ent_slot];                     // entry here costs the others little and saves this lane a whole trip
-							take_entry(r, lnk[ent_slot], ent_slot);
 							if (!finish) have = true;
 						} else want_ent = true;
 					}
@@ -674,18 +653,17 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 		const bool need_seed = use_seed && !(sw_a == e_a && ii - 1 >= sw_base && ii < sw_base + 16);
 
 		// ================================================================ phase 2: issue every load
-		uint4 r_ent = make_uint4(0, 0, 0, 0); uint32_t r_lnk = 0;
-		if (WIDE && want_ent) { r_ent = ent[ent_slot]; r_lnk = lnk[ent_slot]; }
+		uint4 r_ent = make_uint4(0, 0, 0, 0);
 		if (need_win) {
 			int base = (win_hi | 7) - 15; if (base < 0) base = 0;
-			win_load(REC + P.woff_bid + e_a * P.WLB + base, s_bw, wq_bw); bw_base = base; bw_a = e_a;
+			win_load(REC + P.woff_bid + e_a * P.WLB + base, s_bw); bw_base = base; bw_a = e_a;
 		}
 		if (need_seq) {
-			win_load((e_a ? P.rseq : P.seq) + sq_off + (spos & ~15), s_sq, wq_sq); sq_tag = stag;
+			win_load((e_a ? P.rseq : P.seq) + sq_off + (spos & ~15), s_sq); sq_tag = stag;
 		}
 		if (need_seed) {
 			int base = (ii | 7) - 15; if (base < 0) base = 0;
-			win_load(REC + P.woff_sbid + e_a * P.SLB + base, s_sw, wq_sw); sw_base = base; sw_a = e_a;
+			win_load(REC + P.woff_sbid + e_a * P.SLB + base, s_sw); sw_base = base; sw_a = e_a;
 		}
 		uint32_t r_x = 0u;       // text word, or the row of a reported suffix, or the position of the last row
 		if (need_tw) r_x = (qb ? P.bwt[1].text : P.bwt[0].text)[(k - 1u) >> 4];
@@ -729,15 +707,13 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 
 		// look-ahead pop (see s_pf): only from inside a tail, with nothing pending in registers
 		bool pf_now = false; uint32_t pf_cand = NIL;
-		if (!WIDE) {
-			if (want_ent) { pf_cand = ent_slot; pf_now = true; }            // a pop that was not fetched ahead: fetch now, pop next trip
-			else if ((kind == 2 || kind == 4 || kind == 7) && !p_valid && mask_any()) {
-				const int bm = mask_first();
-				pf_cand = head_get(bm);
-				pf_now = pf_cand != pf_slot;
-			}
-			if (pf_now) r_ent = ent[pf_cand];
+		if (want_ent) { pf_cand = ent_slot; pf_now = true; }                // a pop that was not fetched ahead: fetch now, pop next trip
+		else if ((kind == 2 || kind == 4 || kind == 7) && !p_valid && mask_any()) {
+			const int bm = mask_first();
+			pf_cand = head_get(bm);
+			pf_now = pf_cand != pf_slot;
 		}
+		if (pf_now) r_ent = ent[pf_cand];
 		if (!COUNT && P.trip_budget && st != LS_IDLE && st != LS_EXIT) ++rd_trips;
 		if (COUNT && st != LS_IDLE && st != LS_EXIT) {
 			++rd_trips;
@@ -753,12 +729,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 			}
 		}
 		asm volatile("" ::: "memory");   // keep every consumer below every load above (no block merging across)
-		if (!WIDE) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window loads above wrote LDS behind the compiler's back
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window loads above wrote LDS behind the compiler's back
 		// ================================================================ phase 3: consume
-		if (WIDE && want_ent) {
-			take_entry(r_ent, r_lnk, ent_slot);
-			if (!finish) st = LS_HAVE;                                          // pre-checks + query in the next trip
-		}
 		if (pf_now) { s_pf[threadIdx.x] = r_ent; pf_slot = pf_cand; }
 		if (spec && m < (int)(BW_BYTE(win_hi - bw_base) & 127u)) kind = 0;   // pruned after all (bwtgap.c:156)
 		if (need_tw) { tw.x = r_x; s_tw[threadIdx.x] = tw; }
@@ -1038,22 +1010,18 @@ extern "C" int nabwa_width_occupancy(void)
 	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_width_kernel<false>, NABWA_SEARCH_BLOCK, 0) == hipSuccess ? nb : 0;
 }
 
-extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s)
+extern "C" void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, hipStream_t s)
 {
-	const size_t lds = wide ? 0 : (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84;
-	if (P->touch_counter) {
-		if (wide) hipLaunchKernelGGL((fm_search_kernel<true, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
-		else hipLaunchKernelGGL((fm_search_kernel<false, true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
-	} else if (wide) hipLaunchKernelGGL((fm_search_kernel<true, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
-	else hipLaunchKernelGGL((fm_search_kernel<false, false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
+	const size_t lds = (size_t)P->NS * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84;
+	if (P->touch_counter) hipLaunchKernelGGL((fm_search_kernel<true>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
+	else hipLaunchKernelGGL((fm_search_kernel<false>), dim3(n_blocks), dim3(NABWA_SEARCH_BLOCK), lds, s, *P);
 }
 
-extern "C" int nabwa_search_occupancy(int wide, int ns)
+extern "C" int nabwa_search_occupancy(int ns)
 {
 	int nb = 0;
-	hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<true, false>, NABWA_SEARCH_BLOCK, 0)
-						: hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false, false>, NABWA_SEARCH_BLOCK,
-																	   (size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_search_kernel<false>, NABWA_SEARCH_BLOCK,
+																(size_t)ns * NABWA_SEARCH_BLOCK * 2 + NABWA_SEARCH_BLOCK * 84);
 	return e == hipSuccess ? nb : 0;
 }
 

@@ -17,9 +17,8 @@ struct SearchParams {
 	const int64_t *poff;
 	const int32_t *rd_len;
 	const uint8_t *rd_maxdiff, *rd_maxgapo;   // per read: max_diff and clamped max_gapo (host-side FP, bwtaln.c:104-105,125)
-	const int32_t *ids;                       // work item -> read id (wide pass), or null
-	int wide_inline;                          // wide passes: pop and classify in one trip (NABWA_WIDE_INLINE, default 1)
-	const int32_t *res_slot;                  // wide passes: read id -> row of the wide result arrays (stable over the tiers), or null = list position
+	const int32_t *ids;                       // work item -> read id (kernel S: the class-sorted work order; kernel D: its list), or null
+	const int32_t *res_slot;                  // kernel D: read id -> row of its result arrays, or null = list position
 	int n;
 	// gap_opt_t fields that are uniform over the batch
 	int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries, max_gape, max_seed_diff, seed_len, max_top2;
@@ -31,10 +30,9 @@ struct SearchParams {
 	int text_mode;                            // 0: never leave the FM-index (the touch-counting run); 1: text mode where the index has it
 	const uint32_t *rd_key;                   // per read six interval-table keys [6*rid + ..] (see pad_reads_kernel), ~0u = none
 	uint8_t *rd_nN;                           // per read: number of N in the read, saturated at 255
-	// per-lane scratch of kernel S: the arena (and, wide pass only, links / free list / heads)
+	// per-lane scratch of kernel S: the arena
 	uint8_t *scratch;
 	size_t lane_stride;
-	uint32_t off_link, off_free, off_head;
 	uint32_t cap, NS;
 	// outputs, indexed by work item
 	int32_t *n_aln, *max_ent;

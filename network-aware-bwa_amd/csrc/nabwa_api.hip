@@ -24,7 +24,7 @@ void nabwa_launch_sa_fill(const DevBwt *B, uint32_t *sa_full, uint32_t *isa, uin
 void nabwa_launch_text_pack(const uint8_t *bytes, uint32_t n, uint32_t n_words, uint32_t *out, hipStream_t s);
 void nabwa_launch_sa_lookup(const DevBwt *B, int n, const uint8_t *which, const uint32_t *k, uint32_t *out, hipStream_t s);
 void nabwa_launch_occ4(const DevBwt *B, int n, const uint32_t *k, uint32_t *out, hipStream_t s);
-void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, int wide, hipStream_t s);
+void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, hipStream_t s);
 void nabwa_launch_fm_width(const SearchParams *P, int n_blocks, hipStream_t s);
 int nabwa_width_occupancy(void);
 void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
@@ -42,7 +42,7 @@ void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2
 void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, const uint4 *aln, int aln_cap,
 						 const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
 						 uint4 *out, hipStream_t s);
-int nabwa_search_occupancy(int wide, int ns);
+int nabwa_search_occupancy(int ns);
 void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s);
 void nabwa_launch_padded_len(int n, const int64_t *off, int64_t *plen, hipStream_t s);
 void nabwa_launch_pad_reads(int n, const uint8_t *seq, const uint8_t *rseq, const int64_t *off, const int64_t *poff,
@@ -444,7 +444,7 @@ struct nabwa_batch {
 
 static uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int seed_len, uint32_t NS)
+static void layout(SearchParams &P, uint32_t cap, int max_len, int seed_len, uint32_t NS)
 {
 	// per-read width record
 	P.WL = align_up((uint32_t)max_len + 1, 16);
@@ -455,11 +455,7 @@ static void layout(SearchParams &P, uint32_t cap, bool wide, int max_len, int se
 	P.wstride = align_up(P.woff_sbid + 2 * P.SLB, 64);
 	// per-lane search scratch
 	P.cap = cap; P.NS = NS;
-	uint32_t o = cap * 16;
-	P.off_link = o; if (wide) o = align_up(o + cap * 4, 16);
-	P.off_free = o; if (wide) o = align_up(o + cap * 4, 16);
-	P.off_head = o; if (wide) o = align_up(o + NS * 4, 16);
-	P.lane_stride = align_up(o, 64);
+	P.lane_stride = align_up((size_t)cap * 16, 64);
 }
 
 extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
@@ -629,7 +625,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	int cap1 = env_int("NABWA_CAP1", 4096);
 	if (cap1 < 16) cap1 = 16;
 	if (cap1 > 65534) cap1 = 65534;
-	layout(P, (uint32_t)cap1, false, max_len, opt->seed_len, deep_only ? 1u : NS1);
+	layout(P, (uint32_t)cap1, max_len, opt->seed_len, deep_only ? 1u : NS1);
 	b->NS_wide = NS;
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
@@ -642,7 +638,7 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 
 	hipDeviceProp_t prop;
 	BCHK(hipGetDeviceProperties(&prop, ix->device));
-	int occ = nabwa_search_occupancy(0, deep_only ? 1 : (int)NS1);
+	int occ = nabwa_search_occupancy(deep_only ? 1 : (int)NS1);
 	if (occ < 1) occ = 1;
 	const int occ_env = env_int("NABWA_BLOCKS_PER_CU", 0);
 	if (occ_env > 0) occ = occ_env;
@@ -691,7 +687,7 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	}
 	HIPCHK(hipEventRecord(b->ev0, b->stream));
 	SearchParams PS = b->P; PS.ids = b->class_sort ? b->d_perm : 0; PS.n_sync = b->class_sort ? b->d_ncls + 10 : 0;
-	if (!b->deep_only) nabwa_launch_fm_search(&PS, b->n_blocks, 0, b->stream);
+	if (!b->deep_only) nabwa_launch_fm_search(&PS, b->n_blocks, b->stream);
 	else {      /* option blocks the first-pass kernel's compact entries cannot hold: every read goes to kernel D */
 		HIPCHK(hipMemsetAsync(b->d_status, NABWA_ST_OVERFLOW, b->n, b->stream));
 		HIPCHK(hipMemsetAsync(b->d_naln, 0, (size_t)b->n * 4, b->stream));
@@ -744,7 +740,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	if (env_int("NABWA_TIER_A", 0) && b->P.cap < 65534 && b->deep_only == 0) {
 		const double tt0 = now();
 		SearchParams Q = b->P;
-		layout(Q, 65534u, false, b->max_len, b->opt.seed_len, b->P.NS);
+		layout(Q, 65534u, b->max_len, b->opt.seed_len, b->P.NS);
 		long blocks = ((long)cur + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;
 		size_t budget = (size_t)env_int("NABWA_WIDE_GB", 32) << 30;
 		const long fit = (long)(budget / ((size_t)NABWA_SEARCH_BLOCK * Q.lane_stride));
@@ -758,7 +754,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)cur; Q.n_sync = 0; Q.w_sync = 0;
 		rebuild_widths(Q, cur);
 		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-		nabwa_launch_fm_search(&Q, (int)blocks, 0, b->stream);
+		nabwa_launch_fm_search(&Q, (int)blocks, b->stream);
 		HIPCHK(hipGetLastError());
 		unsigned int left = 0;
 		int r = recollect(NABWA_ST_OVERFLOW, &left);
