@@ -483,11 +483,12 @@ def read_genome():
     return out
 
 
-def make_pe_reads(rng, contigs):
+def make_pe_reads(rng, contigs, L=100, mu=300, sd=25, heavy=False):
     """Read pairs of the toy genome: proper FR pairs (insert ~N(300,25)), pairs whose second end is too diverged for
     `aln` (singletons), far-apart and cross-contig pairs (discordant), ends inside the exact duplicate (pairing
     has to choose), and pairs whose second end carries the chr1 version of the diverged chr2 copy (so `aln` places it
-    on chr1 and the mate rescue finds it next to read 1 on chr2)."""
+    on chr1 and the mate rescue finds it next to read 1 on chr2).  L / mu / sd: read length and insert sizes; heavy: the
+    error load of BASELINE config 3 (about 2 % substitutions on every read)."""
     g = dict(contigs)
     pairs = []
 
@@ -515,8 +516,8 @@ def make_pe_reads(rng, contigs):
         made = 0
         while made < n:
             contig = "chr1" if rng.random() < 0.6 else "chr2"
-            isize = int(np.clip(rng.normal(300, 25), 210, 420))
-            L1 = L2 = 100
+            isize = int(np.clip(rng.normal(mu, sd), 2 * L + 10, mu + 5 * sd))
+            L1 = L2 = L
             if kind == "short":
                 L1, L2 = int(rng.choice([76, 50, 100])), int(rng.choice([76, 50]))
             start = int(rng.integers(0, len(g[contig]) - isize))
@@ -524,31 +525,32 @@ def make_pe_reads(rng, contigs):
                 contig, start = "chr1", int(rng.choice([5000, 30000])) + int(rng.integers(-250, 4900))
             if kind == "rescue":
                 contig, start = "chr2", int(rng.integers(7700, 7990))
-                isize = int(rng.integers(330, 420))
+                isize = int(rng.integers(mu + 30, mu + 120))
             if not clean(contig, start, isize):
                 continue
             r1, r2 = frag_pair(contig, start, isize, L1, L2)
             if kind == "proper":
-                r1, r2 = subs(r1, int(rng.integers(0, 3))), subs(r2, int(rng.integers(0, 3)))
+                hi = 6 if heavy else 3
+                r1, r2 = subs(r1, int(rng.integers(0, hi))), subs(r2, int(rng.integers(0, hi)))
             elif kind == "sub":
                 r1, r2 = subs(r1, int(rng.integers(2, 5)), 34), subs(r2, int(rng.integers(2, 5)), 34)
             elif kind == "diverged":                  # too many differences for aln: the end stays unmapped
                 r2 = subs(r2, int(rng.integers(9, 14)))
             elif kind == "far":
-                start2 = int(rng.integers(0, len(g[contig]) - 100))
-                if not clean(contig, start2, 100) or abs(start2 - start) < 1500:
+                start2 = int(rng.integers(0, len(g[contig]) - L))
+                if not clean(contig, start2, L) or abs(start2 - start) < 1500:
                     continue
-                r2 = revcomp(g[contig][start2:start2 + 100]) if rng.random() < 0.7 else g[contig][start2:start2 + 100]
+                r2 = revcomp(g[contig][start2:start2 + L]) if rng.random() < 0.7 else g[contig][start2:start2 + L]
             elif kind == "cross":
                 other = "chr2" if contig == "chr1" else ("chr3" if rng.random() < 0.3 else "chr1")
-                start2 = int(rng.integers(0, len(g[other]) - 100))
-                if not clean(other, start2, 100):
+                start2 = int(rng.integers(0, len(g[other]) - L))
+                if not clean(other, start2, L):
                     continue
-                r2 = revcomp(g[other][start2:start2 + 100])
+                r2 = revcomp(g[other][start2:start2 + L])
             elif kind == "rescue":
                 # second end: chr1 version (chr1[5000+x]) of the chr2 copy window, with differences outside the seed
                 e2 = start + isize                    # fragment end on chr2, inside the copy 8000..10000
-                lo = e2 - 100
+                lo = e2 - L
                 if lo < 8000 or e2 > 10000:
                     continue
                 w1 = g["chr1"][5000 + lo - 8000: 5000 + e2 - 8000]
@@ -557,7 +559,7 @@ def make_pe_reads(rng, contigs):
                 if ndiv < 1:
                     continue
                 r2f = list(w1)
-                cand = [i for i in range(0, 66) if w1[i] == w2[i]]        # read 2 is the reverse complement: its seed is the window's tail
+                cand = [i for i in range(0, L - 34) if w1[i] == w2[i]]        # read 2 is the reverse complement: its seed is the window's tail
                 for p in rng.choice(cand, int(rng.integers(4, 6)), replace=False):
                     r2f[p] = "ACGT"[("ACGT".index(r2f[p]) + 1 + int(rng.integers(0, 3))) % 4]
                 r2 = revcomp("".join(r2f))
@@ -569,8 +571,8 @@ def make_pe_reads(rng, contigs):
                     r2 = (r2[:p] + "TGCA"[:d] + r2[p:])[:len(r2)]
                 r1 = subs(r1, int(rng.integers(0, 2)), 34)
             elif kind == "junk":
-                r1 = "".join("ACGT"[i] for i in rng.integers(0, 4, 100))
-                r2 = "".join("ACGT"[i] for i in rng.integers(0, 4, 100))
+                r1 = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+                r2 = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
             if kind in ("proper", "sub") and rng.random() < 0.04:
                 r1 = r1[:50] + "N" + r1[51:]
             add(kind, r1, r2)
@@ -583,25 +585,28 @@ PE_F = ("type", "strand", "n_mm", "n_gapo", "n_gape", "score", "sa", "c1", "c2",
         "nm", "n_multi", "len")
 
 
-def make_pe_chain(lib=None):
+def make_pe_chain(lib=None, tag="", L=100, mu=300, sd=25, heavy=False, seed=4242):
     """The paired-end chain (bam2bam.c:683-811 / bwape.c:295-425,519-633 / bwase.c:356-423) on toy read pairs:
     reads_pe_[12].fq, pe_[12].sai, pe_default.sam (the reference's `sampe`), vectors_pe_chain.npz (state of every end
-    after pass 1 and after pass 2 under three insert-size estimates: sampe's own, bam2bam's histogram one, none)."""
+    after pass 1 and after pass 2 under three insert-size estimates: sampe's own, bam2bam's histogram one, none).
+    tag "150": the same for 2 x 150 bp pairs with config 3's error load (files reads_pe150_[12].fq, pe150_[12].sai,
+    pe150_default.sam, vectors_pe150_chain.npz)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import nabwa_testlib as T
     if lib is None:
         lib = C.CDLL(REFLIB)
-    rng = np.random.default_rng(4242)
-    pairs = make_pe_reads(rng, read_genome())
-    fq = [os.path.join(HERE, "reads_pe_%d.fq" % e) for e in (1, 2)]
-    sai = [os.path.join(HERE, "pe_%d.sai" % e) for e in (1, 2)]
+    rng = np.random.default_rng(seed)
+    pairs = make_pe_reads(rng, read_genome(), L=L, mu=mu, sd=sd, heavy=heavy)
+    fq = [os.path.join(HERE, "reads_pe%s_%d.fq" % (tag, e)) for e in (1, 2)]
+    sai = [os.path.join(HERE, "pe%s_%d.sai" % (tag, e)) for e in (1, 2)]
     for e in range(2):
         with open(fq[e], "w") as f:
             for n, r1, r2 in pairs:
                 s = (r1, r2)[e]
                 f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
         run([REFBIN, "aln", PREFIX, fq[e]], sai[e])
-    run([REFBIN, "sampe", PREFIX, sai[0], sai[1], fq[0], fq[1]], os.path.join(HERE, "pe_default.sam"))
+    sam_path = os.path.join(HERE, "pe%s_default.sam" % tag)
+    run([REFBIN, "sampe", PREFIX, sai[0], sai[1], fq[0], fq[1]], sam_path)
 
     P = C.c_void_p
     lib.ref_index_load.restype = P
@@ -677,13 +682,13 @@ def make_pe_chain(lib=None):
         out["md_" + mode] = np.array(fin[3])
         print("pe chain [%s] ii=%s  types=%s  FPP=%d  MATESW=%d" % (mode, ii, np.bincount(fin[0][:, 0], minlength=4),
               int((fin[0][:, 12] & 2).astype(bool).sum()), int((fin[0][:, 0] == 3).sum())))
-    check_against_sampe(T, out, read_genome(), pairs)
-    np.savez_compressed(os.path.join(HERE, "vectors_pe_chain.npz"), **out)
+    check_against_sampe(T, out, read_genome(), pairs, sam_path)
+    np.savez_compressed(os.path.join(HERE, "vectors_pe%s_chain.npz" % tag), **out)
 
 
-def check_against_sampe(T, out, contigs, pairs):
+def check_against_sampe(T, out, contigs, pairs, sam_path):
     """The harness chain under sampe's own insert-size estimate must reproduce what the reference's `sampe` printed."""
-    sam = T.parse_sam(os.path.join(HERE, "pe_default.sam"))
+    sam = T.parse_sam(sam_path)
     f, cg, md = out["f_sampe"], out["cig_sampe"], out["md_sampe"]
     offs = np.cumsum([0] + [len(s) for _, s in contigs])
     assert len(sam) == len(f), (len(sam), len(f))
@@ -708,5 +713,7 @@ def check_against_sampe(T, out, contigs, pairs):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pe_chain":
         make_pe_chain()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pe_chain150":
+        make_pe_chain(tag="150", L=150, mu=400, sd=40, heavy=True, seed=150150)
     else:
         main()

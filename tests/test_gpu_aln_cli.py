@@ -30,6 +30,8 @@ GOLDEN_RUNS = {
     "se_nonstop": (["-N"], "reads_se_head.fq"),
     "pe_1": ([], "reads_pe_1.fq"),
     "pe_2": ([], "reads_pe_2.fq"),
+    "pe150_1": ([], "reads_pe150_1.fq"),          # 2 x 150 bp pairs with BASELINE config 3's error load (make_golden.py pe_chain150)
+    "pe150_2": ([], "reads_pe150_2.fq"),
 }
 
 

@@ -20,18 +20,21 @@ F = {k: i for i, k in enumerate(("type", "strand", "n_mm", "n_gapo", "n_gape", "
                                  "extra_flag", "n_cigar", "nm", "n_multi", "len"))}
 
 
-@pytest.fixture(scope="module")
-def pe():
+@pytest.fixture(scope="module", params=["", "150"], ids=["100bp", "150bp_config3"])
+def pe(request):
+    """two fixture sets: the 100 bp toy pairs, and 2 x 150 bp pairs with BASELINE config 3's error load (inserts ~ N(400, 40),
+    up to 5 substitutions per read, gapped reads, diverged / far / cross-contig / duplicated / rescue pairs; make_golden.py pe_chain150)"""
+    tag = request.param
     ix = nabwa.Index.load(T.TOY)
     ix.attach_reference(T.TOY)
-    fq = [T.read_fastq(os.path.join(T.GOLDEN, "reads_pe_%d.fq" % e)) for e in (1, 2)]
-    sai = [T.read_sai(os.path.join(T.GOLDEN, "pe_%d.sai" % e)) for e in (1, 2)]
+    fq = [T.read_fastq(os.path.join(T.GOLDEN, "reads_pe%s_%d.fq" % (tag, e))) for e in (1, 2)]
+    sai = [T.read_sai(os.path.join(T.GOLDEN, "pe%s_%d.sai" % (tag, e))) for e in (1, 2)]
     n = len(fq[0])
     inter = [fq[e][i] for i in range(n) for e in range(2)]               # interleaved ends: 2*pair + end
     hits = [sai[e][1][i] for i in range(n) for e in range(2)]
     seq, rseq, off, full = T.encode_reads(inter)
-    v = np.load(os.path.join(T.GOLDEN, "vectors_pe_chain.npz"))
-    yield dict(ix=ix, opt=sai[1][0], seq=seq, rseq=rseq, off=off, full=full, hits=hits, v=v, n=n, names=[r[0] for r in fq[0]])
+    v = np.load(os.path.join(T.GOLDEN, "vectors_pe%s_chain.npz" % tag))
+    yield dict(tag=tag, ix=ix, opt=sai[1][0], seq=seq, rseq=rseq, off=off, full=full, hits=hits, v=v, n=n, names=[r[0] for r in fq[0]])
     ix.close()
 
 
@@ -127,7 +130,7 @@ def test_pe_finish_matches_reference_chain(pe, mode):
 def test_pe_records_match_reference_sampe_output(pe):
     """flags, mate fields, template length and tags against the SAM the reference's `sampe` printed"""
     recs, _, _ = finish(pe, "sampe")
-    sam = T.parse_sam(os.path.join(T.GOLDEN, "pe_default.sam"))
+    sam = T.parse_sam(os.path.join(T.GOLDEN, "pe%s_default.sam" % pe["tag"]))
     _, names, offs = toy_ann()
     assert len(sam) == 2 * pe["n"]
     for r, w in enumerate(sam):
