@@ -54,13 +54,13 @@ def read_bam(path):
     return text, refs, B.decode(np.frombuffer(body, np.uint8), np.array(off, np.int64), [r[0] for r in refs])
 
 
-def run(tmp_path, records, args, env=None, bgzf=True):
+def run(tmp_path, records, args, env=None, bgzf=True, prefix=None):
     if not os.path.exists(EXE):
         nabwa.build()
     inp, outp = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
     write_bam(inp, records, bgzf)
     e = dict(os.environ, **(env or {}))
-    r = subprocess.run([EXE, "-g", T.TOY, "-f", outp + "_"] + args + [inp], capture_output=True, text=True, env=e, timeout=600)
+    r = subprocess.run([EXE, "-g", prefix or T.TOY, "-f", outp + "_"] + args + [inp], capture_output=True, text=True, env=e, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(outp) and not os.path.exists(outp + "_")
     raw = open(outp, "rb").read()
@@ -124,3 +124,54 @@ def test_unsupported_modes_are_refused(tmp_path):
         nabwa.build()
     r = subprocess.run([EXE, "-g", T.TOY, "-p", "5000", "x.bam"], capture_output=True, text=True)
     assert r.returncode != 0 and "not provided" in r.stderr
+
+
+def test_config1_ecoli_size_genome_10k_reads_against_the_reference_commands(tmp_path):
+    """BASELINE config 1: an E. coli K-12-sized genome (4.6 Mbp, synthetic: there is no network), 10 k 100 bp single-end reads in a
+    BAM file.  The reference's own commands (oracle/_ref/bwa_ref, compiled from /root/reference: `index`, `aln`, `samse` -- its CPU
+    path) build the index and the expected records; nabwa_bam2bam loads that index and must write the same records."""
+    refbin = os.path.join(T.ROOT, "oracle", "_ref", "bwa_ref")
+    if not os.path.exists(refbin):
+        pytest.skip("the compiled reference (oracle/_ref) did not travel")
+    rng = np.random.default_rng(20261004)
+    genome = rng.integers(0, 4, 4_641_652, dtype=np.uint8)                       # the length of E. coli K-12 MG1655
+    for _ in range(40):                                                          # a few repeats (rRNA operons, IS elements)
+        a, b, L = int(rng.integers(0, 4_600_000)), int(rng.integers(0, 4_600_000)), int(rng.integers(800, 5000))
+        genome[b:b + L] = genome[a:a + L]
+    text = "".join("ACGT"[c] for c in genome)
+    fa = str(tmp_path / "eco.fa")
+    with open(fa, "w") as f:
+        f.write(">eco_syn\n")
+        for o in range(0, len(text), 70):
+            f.write(text[o:o + 70] + "\n")
+    reads = []
+    for i in range(10000):
+        p = int(rng.integers(0, len(text) - 100))
+        s = list(text[p:p + 100])
+        for j in range(100):
+            if rng.random() < 0.01:
+                s[j] = "ACGT"[("ACGT".index(s[j]) + 1 + int(rng.integers(0, 3))) % 4]
+        s = "".join(s)
+        if i % 50 == 0:                                                          # some gapped reads
+            s = s[:40] + s[42:] + "AC"
+        if rng.random() < 0.5:
+            s = revcomp(s)
+        reads.append(("r%05d" % i, s, "".join(chr(33 + int(q)) for q in rng.integers(20, 41, 100))))
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for n, sq, q in reads:
+            f.write("@%s\n%s\n+\n%s\n" % (n, sq, q))
+    def ref(args, out=None):
+        r = subprocess.run([refbin] + args, stdout=open(out, "wb") if out else subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    ref(["index", fa])
+    sai, samf = str(tmp_path / "reads.sai"), str(tmp_path / "reads.sam")
+    ref(["aln", fa, fq], sai)
+    ref(["samse", fa, sai, fq], samf)
+    sam = T.parse_sam(samf)
+    recs = [B.make_record(n, sq, q, 4) for n, sq, q in reads]
+    _, refs, out = run(tmp_path, recs, [], prefix=fa)
+    assert refs == [("eco_syn", len(text))]
+    assert len(out) == len(sam) == 10000
+    check_se(out, sam)
+    assert sum(1 for o in out if not (o["flag"] & 4)) > 9900
