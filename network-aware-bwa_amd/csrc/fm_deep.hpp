@@ -37,5 +37,6 @@ struct DeepParams {
 	uint32_t lds_rd, rd_pl;          // bytes of LDS for the read's own data (2 WLB + 2 SLB + 2 rd_pl; 0: it stays in global memory), stride of a strand's bases there
 	                                 // LDS per wave: DEEP_LDS_WORDS(NS, lds_rd) words
 	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
+	uint32_t *rounds_out;            // or null (statistics build): per work item the rounds its search took
 	unsigned long long *stats;       // or null: [0] rounds, [1] lane-chains run, [2] chains committed, [3] chain steps, [4] careful rounds, [5] pool failures, [6] rank steps and [7] text finishes of exact tails (lane counts)
 };

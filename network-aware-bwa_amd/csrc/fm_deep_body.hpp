@@ -588,6 +588,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			}
 		}
 		ONE_LANE { S.n_aln[item] = n_aln; S.max_ent[item] = max_ent; S.status[item] = (uint8_t)status; }
+		if (PROF && P.rounds_out) { ONE_LANE { P.rounds_out[idx] = (uint32_t)(st_rounds - rounds0); } }
 		if (prof) { const unsigned long long dt = DEEP_CLOCK() - clk0; st_sumclk += dt; if (dt > st_maxclk) st_maxclk = dt; if (st_rounds - rounds0 > st_maxrounds) st_maxrounds = st_rounds - rounds0; }
 		if (counting && status == NABWA_ST_OK) { ONE_LANE { DEEP_ATOMIC_ADD_U64(S.touch_counter, rd_touch); } }
 	}

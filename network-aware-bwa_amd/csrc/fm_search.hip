@@ -968,7 +968,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 #undef CL
 
 		if (finish) {
-			P.n_aln[item] = n_aln; P.max_ent[item] = max_ent; P.status[item] = (uint8_t)status;
+			P.n_aln[item] = n_aln; P.max_ent[item] = (!COUNT && status == NABWA_ST_OVERFLOW) ? (int)rd_trips : max_ent; P.status[item] = (uint8_t)status;      // (a search handed on: the trips it took here -- kernel D's statistics dump reads them; its own max_ent replaces this)
 			if (COUNT && status == NABWA_ST_OK) touches += rd_touch;   // abandoned reads are counted by the wide pass
 			if (COUNT && P.touch_counter && rd_trips > 8000u) {
 				atomicAdd(P.touch_counter + 16, 1ull); atomicAdd(P.touch_counter + 17, (unsigned long long)rd_trips); atomicAdd(P.touch_counter + 18, (unsigned long long)rk_kf);
@@ -1123,7 +1123,10 @@ __global__ __launch_bounds__(256) void collect_kernel(int n, const uint8_t *__re
 }
 
 // The same, in the order kernel D should start them: its launch ends with its longest search, so the searches that look
-// longest go first.  Key = max_diff - (the lower bound of the read's differences from kernel W: the smaller restart count of
+// longest go first.  (Measured with NABWA_DEEP_DUMP + profiles/probes/deep_order_probe.py on the ancient-DNA workload: by the searches'
+// round counts this key schedules no better than a random order, 1.19 x the bound, and a key of {no hit yet, max_diff, read length}
+// reaches 1.07 -- but the launch got 4 % SLOWER with it: the longest search then runs its whole life beside a full machine, 21 us per
+// round instead of 17 when it finishes alone.  Wave priority for the head of the list changed nothing.  Not kept.)  Key = max_diff - (the lower bound of the read's differences from kernel W: the smaller restart count of
 // its two strands): the more differences the bounds leave open, the larger the tree; reads that filled the first pass's hit list
 // (repeat families: hundreds of hit rows, every one-difference variant walked to the end) go before everything else.  One pass per
 // key value, largest first.

@@ -848,6 +848,21 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		if (D.max_lanes > 64) D.max_lanes = 64;
 
 		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
+		/* NABWA_DEEP_DUMP=<file> (investigations of the work order): per search of the first launch its read, length, max_diff, the width
+		 * passes' restart classes, what kernel S saw of it (trips, hits) and the rounds kernel D needed -- int32 x 8 per search */
+		const char *dump_path = getenv("NABWA_DEEP_DUMP");
+		std::vector<int32_t> dump_ids, dump_trips, dump_naln; uint32_t *d_rounds = 0;
+		if (dump_path) {
+			D.stats = b->d_deep_ctr;
+			dump_ids.resize(cur); dump_trips.resize(b->n); dump_naln.resize(b->n);
+			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(hipMemcpy(dump_ids.data(), b->d_ovf_ids, (size_t)cur * 4, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(dump_trips.data(), b->d_maxent, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(dump_naln.data(), b->d_naln, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+			HIPCHK(pool_malloc(b->ix, (void**)&d_rounds, (size_t)cur * 4));
+			HIPCHK(hipMemsetAsync(d_rounds, 0, (size_t)cur * 4, b->stream));
+			D.rounds_out = d_rounds;
+		}
 		// pass 1: as many waves as fit the CUs, pages on demand; pass 2 (only if the pool ran dry under some reads): as many
 		// waves as the pool can serve in the worst case
 		unsigned int todo = cur, n_pool = 0;
@@ -879,6 +894,24 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
 				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f; active lanes per chain step %.1f\n",
 						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
+			}
+			if (pass == 0 && dump_path) {
+				std::vector<uint32_t> rounds(dump_ids.size());
+				std::vector<uint8_t> cls((size_t)b->n * 2), md((size_t)b->n); std::vector<int32_t> lens((size_t)b->n);
+				HIPCHK(hipMemcpy(rounds.data(), d_rounds, rounds.size() * 4, hipMemcpyDeviceToHost));
+				if (b->d_cls) HIPCHK(hipMemcpy(cls.data(), b->d_cls, cls.size(), hipMemcpyDeviceToHost));
+				HIPCHK(hipMemcpy(md.data(), b->d_md, md.size(), hipMemcpyDeviceToHost));
+				HIPCHK(hipMemcpy(lens.data(), b->d_len, lens.size() * 4, hipMemcpyDeviceToHost));
+				FILE *f = fopen(dump_path, "wb");
+				if (f) {
+					for (size_t t = 0; t < dump_ids.size(); ++t) {
+						const int32_t r = dump_ids[t];
+						const int32_t row[8] = { r, lens[r], (int32_t)md[r], (int32_t)cls[2 * (size_t)r], (int32_t)cls[2 * (size_t)r + 1], dump_trips[r], dump_naln[r], (int32_t)rounds[t] };
+						fwrite(row, 4, 8, f);
+					}
+					fclose(f);
+				}
+				HIPCHK(pool_free(b->ix, d_rounds)); D.rounds_out = 0;
 			}
 			todo = n_pool;
 		}
