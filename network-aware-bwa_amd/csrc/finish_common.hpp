@@ -70,38 +70,57 @@ static inline int pac2real(const nabwa_reference *R, int64_t pos, int len, int *
 /* one gap-refinement job: which record, main hit (-1) or multi index, query orientation, window */
 struct RefineJob { int rec, multi, strand, ext, len; int64_t pos; int64_t win_lo; int win_n; };
 
-/* MD string and NM of an alignment (bwa_cal_md1, bwase.c:253-315) */
+/* MD string and NM of an alignment (bwa_cal_md1, bwase.c:253-315).  Written straight into the caller's field (no heap string, no
+ * printf per run of matches); where no ambiguity hole of the .amb file touches the alignment's stretch of the reference -- one search
+ * per record instead of one per base -- the bases come from the packed text directly. */
 static inline bool make_md(const nabwa_reference *R, int n_cigar, const uint16_t *cigar, int len, uint32_t pos0, const uint8_t *q,
 					char *md, int cap, int *nm_out)
 {
-	int64_t pos = pos0; int u = 0, nm = 0, y = 0; std::string s; char num[16];
-	auto flush_num = [&]() { snprintf(num, sizeof num, "%d", u); s += num; };
+	int64_t pos = pos0; int u = 0, nm = 0, y = 0;
+	int o = 0; bool fits = true;                         /* characters written; false once the field is full */
+	auto put = [&](char c) { if (o + 1 < cap) md[o++] = c; else fits = false; };
+	auto flush_num = [&]() {
+		char t[12]; int n = 0; unsigned v = (unsigned)u;
+		do { t[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+		while (n) put(t[--n]);
+	};
 	auto base_chr = [](int c) -> char { return c > 3 ? (char)c : "ACGT"[c]; };
+	/* the stretch of the reference this alignment can touch: pos0 .. pos0 + (M + D lengths) */
+	int64_t span = len;
+	if (n_cigar) { span = 0; for (int k = 0; k < n_cigar; ++k) { const int op = COP(cigar[k]); if (op == 0 || op == 2) span += CLEN(cigar[k]); } }
+	bool plain = true;                                   /* no hole overlaps [pos0, pos0 + span) */
+	{
+		size_t lo = 0, hi = R->holes.size();
+		while (lo < hi) { const size_t mid = (lo + hi) / 2; if (R->holes[mid].offset + R->holes[mid].len <= (int64_t)pos0) lo = mid + 1; else hi = mid; }
+		if (lo < R->holes.size() && R->holes[lo].offset < (int64_t)pos0 + span) plain = false;
+	}
+#define MD_REF(p_) (plain ? pac_at(R, (p_)) : ref_char(R, (p_)))
 	if (n_cigar) {
 		for (int k = 0; k < n_cigar; ++k) {
 			const int l = CLEN(cigar[k]), op = COP(cigar[k]);
 			if (op == 0) {
 				for (int z = 0; z < l && pos < R->l_pac; ++z, ++y, ++pos) {
-					const int c = ref_char(R, pos);
-					if (c > 3 || q[y] > 3 || c != q[y]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
+					const int c = MD_REF(pos);
+					if (c > 3 || q[y] > 3 || c != q[y]) { flush_num(); put(base_chr(c)); ++nm; u = 0; } else ++u;
 				}
 			} else if (op == 1 || op == 3) { y += l; if (op == 1) nm += l; }
 			else {
-				flush_num(); s += '^';
-				for (int z = 0; z < l && pos < R->l_pac; ++z, ++pos) s += base_chr(ref_char(R, pos));
+				flush_num(); put('^');
+				for (int z = 0; z < l && pos < R->l_pac; ++z, ++pos) put(base_chr(MD_REF(pos)));
 				u = 0; nm += l;
 			}
 		}
 	} else {
 		for (int z = 0; z < len; ++z, ++pos) {
-			const int c = ref_char(R, pos);
-			if (c > 3 || q[z] > 3 || c != q[z]) { flush_num(); s += base_chr(c); ++nm; u = 0; } else ++u;
+			const int c = MD_REF(pos);
+			if (c > 3 || q[z] > 3 || c != q[z]) { flush_num(); put(base_chr(c)); ++nm; u = 0; } else ++u;
 		}
 	}
+#undef MD_REF
 	flush_num();
-	snprintf(md, cap, "%s", s.c_str());
+	md[o < cap ? o : cap - 1] = 0;
 	*nm_out = nm;
-	return (int)s.size() < cap;          /* false: the string did not fit (the caller reports NABWA_ECAP, never a cut-off tag) */
+	return fits;                                         /* false: the string did not fit (the caller reports NABWA_ECAP, never a cut-off tag) */
 }
 
 
