@@ -337,7 +337,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	SearchParams P = P_;
 	// the gap options as scalar values of their own (nabwa_dev.hpp: own): they arrive as one 256-bit tuple, which this kernel -- it has
 	// more uniform values than scalar registers -- spilled whole and read back, all eight dwords, at 26 places.  (Doing the same for
-	// EVERY argument removes more v_readlane instructions still, 492 -> 212, and makes the kernel 3 % slower: measured, not kept.)
+	// EVERY argument removes more v_readlane instructions still, 492 -> 212, and makes the kernel 3 % slower; for the index
+	// descriptors' scalars, their pointers, the batch's pointers or the per-read arrays' pointers alone: 1 - 7 % slower.  Measured, not kept.)
 	own(P.n); own(P.s_mm); own(P.s_gapo); own(P.s_gape); own(P.mode); own(P.indel_end_skip); own(P.max_del_occ); own(P.max_entries);
 	own(P.max_gape); own(P.max_seed_diff); own(P.seed_len); own(P.max_top2);
 	const uint32_t NIL = 0xffffu;
