@@ -629,7 +629,11 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	b->NS_wide = NS;
 	P.aln_cap = env_int("NABWA_ALNCAP1", 16);
 	P.sync_refill = env_int("NABWA_SYNC_REFILL", 0);
-	P.trip_budget = (uint32_t)env_int("NABWA_TRIP_BUDGET", 2000);   /* 0: never; measured 10 M x 100 bp: 0 -> 123.6 ms per pass, 2000 -> 108.9 (1111 reads handed on, kernel D 2 ms), 1000 -> 116.2, 500 -> 189.6 */
+	/* trips after which kernel S hands a search on to kernel D (0: never).  Seeded searches (the default options): measured 10 M x 100 bp,
+	 * 0 -> 123.6 ms per pass, 2000 -> 108.9 (1111 reads handed on, kernel D 2 ms), 1000 -> 116.2, 500 -> 189.6; 2 x 150 bp pairs: 2000 is the
+	 * optimum too.  Without a seed (reads no longer than seed_len: the ancient-DNA options) the searches that do not end early are deep, and
+	 * every trip kernel S spends on them is spent again by kernel D: 6.25 M reads, 300 / 1000 / 2000 / 5000 -> 2.29 / 2.20 / 2.20 / 2.04 M reads/s */
+	P.trip_budget = (uint32_t)env_int("NABWA_TRIP_BUDGET", max_len > opt->seed_len ? 2000 : 300);
 	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
 	{
 		P.w_sync = (n > 0 && min_len == max_len) ? env_int("NABWA_W_SYNC", 1) : 0;
