@@ -23,8 +23,9 @@ extern "C" {
 #define NABWA_EIO      -3   /* index file missing / malformed */
 #define NABWA_ENOMEM   -4
 #define NABWA_ECAP     -5   /* caller-provided output capacity too small (n_aln[] / *n_rows say how much is needed) */
-#define NABWA_EHITS    -6   /* some reads have more hit rows than the device-side result rows (env NABWA_ALNCAP2, default 1024):
-                             their n_aln is 0, every other read is resolved and can be fetched */
+#define NABWA_EHITS    -6   /* some reads have more hit rows than the device-side result rows can be grown to (NABWA_ALNCAP2 = 1024 rows, searched
+                             again with 16 x, 256 x, 4096 x that within NABWA_HIT_GROW_GB = 8 GB): their n_aln is 0, every other read is resolved
+                             and can be fetched */
 
 /* gap_opt_t -- identical layout to the reference's (bwtaln.h:143-153, 64 bytes); it is the
  * block `bwa worker` receives over the wire (bam2bam.c:1260-1263). */

@@ -1171,6 +1171,28 @@ __global__ __launch_bounds__(256) void scatter_wide_kernel(int n2, const int32_t
 	else { n_aln[rid] = 0; max_ent[rid] = max_ent2[j]; status[rid] = status2[j]; }     /* NABWA_ST_POOL / NABWA_ST_HITCAP: the host decides */
 }
 
+// results of the searches that were run again with longer hit lists (nabwa_batch_sync): the q-th search of the list -> its read; its
+// rows are block + q * cap3, entered in the table of grown row blocks at slot0 + q, which the read's wide_idx names from now on
+__global__ __launch_bounds__(256) void scatter_grown_kernel(int n2, const int32_t *__restrict__ ids, const int32_t *__restrict__ n_aln3,
+															const int32_t *__restrict__ max_ent3, const uint8_t *__restrict__ status3,
+															int32_t *__restrict__ n_aln, int32_t *__restrict__ max_ent, uint8_t *__restrict__ status,
+															int32_t *__restrict__ wide_idx, const uint4 *block, size_t cap3, const uint4 **__restrict__ grown, int slot0)
+{
+	const int q = blockIdx.x * 256 + threadIdx.x;
+	if (q >= n2) return;
+	const int rid = ids[q];
+	max_ent[rid] = max_ent3[q];
+	if (status3[q] == NABWA_ST_OK) { n_aln[rid] = n_aln3[q]; status[rid] = NABWA_ST_GROWN; wide_idx[rid] = slot0 + q; grown[slot0 + q] = block + (size_t)q * cap3; }
+	else { n_aln[rid] = 0; status[rid] = status3[q]; }
+}
+extern "C" void nabwa_launch_scatter_grown(int n2, const int32_t *ids, const int32_t *n_aln3, const int32_t *max_ent3, const uint8_t *status3,
+										   int32_t *n_aln, int32_t *max_ent, uint8_t *status, int32_t *wide_idx, const uint4 *block, size_t cap3,
+										   const uint4 **grown, int slot0, hipStream_t s)
+{
+	if (n2 <= 0) return;
+	hipLaunchKernelGGL(scatter_grown_kernel, dim3((n2 + 255) / 256), dim3(256), 0, s, n2, ids, n_aln3, max_ent3, status3, n_aln, max_ent, status, wide_idx, block, cap3, grown, slot0);
+}
+
 // the reads that go to the wide passes get a row each in the wide result arrays; it stays theirs over the tiers
 __global__ __launch_bounds__(256) void assign_slots_kernel(int n2, const int32_t *__restrict__ ids, int32_t *__restrict__ wide_idx)
 {
@@ -1194,32 +1216,34 @@ extern "C" void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int3
 }
 
 __device__ __forceinline__ const uint4 *rows_of(int i, const uint4 *aln, int aln_cap, const uint8_t *status,
-												const int32_t *wide_idx, const uint4 *aln2, int aln_cap2)
+												const int32_t *wide_idx, const uint4 *aln2, int aln_cap2, const uint4 *const *grown)
 {
-	return status[i] == NABWA_ST_WIDE ? aln2 + (size_t)wide_idx[i] * aln_cap2 : aln + (size_t)i * aln_cap;
+	const int st = status[i];
+	if (st == NABWA_ST_GROWN) return grown[wide_idx[i]];           /* a hit list that outgrew the wide rows: its own block (nabwa_batch_sync) */
+	return st == NABWA_ST_WIDE ? aln2 + (size_t)wide_idx[i] * aln_cap2 : aln + (size_t)i * aln_cap;
 }
 
 // compaction: rows of read i go to out[row_off[i] ...]
 __global__ __launch_bounds__(256) void gather_kernel(int n, const int32_t *__restrict__ n_aln, const uint32_t *__restrict__ row_off,
 												 const uint4 *__restrict__ aln, int aln_cap, const uint8_t *__restrict__ status,
 												 const int32_t *__restrict__ wide_idx, const uint4 *__restrict__ aln2, int aln_cap2,
-												 uint4 *__restrict__ out)
+												 const uint4 *const *__restrict__ grown, uint4 *__restrict__ out)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	const int na = n_aln[i];
-	const uint4 *src = rows_of(i, aln, aln_cap, status, wide_idx, aln2, aln_cap2);
+	const uint4 *src = rows_of(i, aln, aln_cap, status, wide_idx, aln2, aln_cap2, grown);
 	uint4 *dst = out + row_off[i];
 	for (int j = 0; j < na; ++j) dst[j] = src[j];
 }
 
 extern "C" void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, const uint4 *aln, int aln_cap,
 									const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
-									uint4 *out, hipStream_t s)
+									const uint4 *const *grown, uint4 *out, hipStream_t s)
 {
 	if (n <= 0) return;
 	hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, n_aln, row_off, aln, aln_cap, status,
-					   wide_idx, aln2, aln_cap2, out);
+					   wide_idx, aln2, aln_cap2, grown, out);
 }
 
 // order-independent checksum over all hits: sum of a mix of (read, row index, row words)
@@ -1231,14 +1255,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 
 __global__ __launch_bounds__(256) void checksum_kernel(int n, const int32_t *__restrict__ n_aln, const uint4 *__restrict__ aln,
 												   int aln_cap, const uint8_t *__restrict__ status, const int32_t *__restrict__ wide_idx,
-												   const uint4 *__restrict__ aln2, int aln_cap2,
+												   const uint4 *__restrict__ aln2, int aln_cap2, const uint4 *const *__restrict__ grown,
 												   unsigned long long *__restrict__ sum, unsigned long long *__restrict__ rows)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	uint64_t s = 0, r = 0;
 	if (i < n) {
 		const int na = n_aln[i];
-		const uint4 *src = rows_of(i, aln, aln_cap, status, wide_idx, aln2, aln_cap2);
+		const uint4 *src = rows_of(i, aln, aln_cap, status, wide_idx, aln2, aln_cap2, grown);
 		r = (uint64_t)na;
 		s = mix64(((uint64_t)i << 20) ^ (uint64_t)na ^ 0x9e3779b97f4a7c15ULL);
 		for (int j = 0; j < na; ++j) {
@@ -1252,11 +1276,11 @@ __global__ __launch_bounds__(256) void checksum_kernel(int n, const int32_t *__r
 
 extern "C" void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
 									  const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
-									  unsigned long long *sum, unsigned long long *rows, hipStream_t s)
+									  const uint4 *const *grown, unsigned long long *sum, unsigned long long *rows, hipStream_t s)
 {
 	if (n <= 0) return;
 	hipLaunchKernelGGL(checksum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, n_aln, aln, aln_cap, status, wide_idx,
-					   aln2, aln_cap2, sum, rows);
+					   aln2, aln_cap2, grown, sum, rows);
 }
 
 // Work order of the search kernel by kernel W's class of a read = the smaller of its two strands' restart counts, i.e. a

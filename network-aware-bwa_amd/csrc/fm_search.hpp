@@ -8,7 +8,8 @@
 #define NABWA_ST_OVERFLOW  1   // arena or hit list outgrown in the first pass (kernel S): the read goes to kernel D
 #define NABWA_ST_WIDE      2   // resolved by kernel D: the result lives in the wide result arrays at wide_idx[read]
 #define NABWA_ST_POOL      3   // kernel D: the page pool ran dry under this read -- it is run again in the guaranteed pass
-#define NABWA_ST_HITCAP    4   // kernel D: more hit rows than the wide result rows (NABWA_ALNCAP2)
+#define NABWA_ST_HITCAP    4   // kernel D: more hit rows than the wide result rows (NABWA_ALNCAP2): searched again with longer lists
+#define NABWA_ST_GROWN     5   // resolved by such a second search: the rows are the block grown[wide_idx[read]] names
 
 struct SearchParams {
 	DevBwt bwt[2];

@@ -28,7 +28,7 @@ void nabwa_launch_fm_search(const SearchParams *P, int n_blocks, hipStream_t s);
 void nabwa_launch_fm_width(const SearchParams *P, int n_blocks, hipStream_t s);
 int nabwa_width_occupancy(void);
 void nabwa_launch_checksum(int n, const int32_t *n_aln, const uint4 *aln, int aln_cap, const uint8_t *status,
-						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
+						   const int32_t *wide_idx, const uint4 *aln2, int aln_cap2, const uint4 *const *grown,
 						   unsigned long long *sum, unsigned long long *rows, hipStream_t s);
 void nabwa_launch_collect(int n, const uint8_t *status, int32_t *ids, unsigned int *count, int which, hipStream_t s);
 void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s);
@@ -36,12 +36,15 @@ void nabwa_launch_collect_keyed(int n, const uint8_t *status, int32_t *ids, unsi
 								const uint8_t *cls, const uint8_t *md, int max_key, const int32_t *n_aln, int aln_cap, hipStream_t s);
 int nabwa_deep_occupancy(int ns, int lds_rd);
 void nabwa_launch_assign_slots(int n2, const int32_t *ids, int32_t *wide_idx, hipStream_t s);
+void nabwa_launch_scatter_grown(int n2, const int32_t *ids, const int32_t *n_aln3, const int32_t *max_ent3, const uint8_t *status3,
+								 int32_t *n_aln, int32_t *max_ent, uint8_t *status, int32_t *wide_idx, const uint4 *block, size_t cap3,
+								 const uint4 **grown, int slot0, hipStream_t s);
 void nabwa_launch_scatter_wide(int n2, const int32_t *ids, const int32_t *n_aln2, const int32_t *max_ent2,
 							   const uint8_t *status2, int32_t *n_aln, int32_t *max_ent, uint8_t *status,
 							   int32_t *wide_idx, hipStream_t s);
 void nabwa_launch_gather(int n, const int32_t *n_aln, const uint32_t *row_off, const uint4 *aln, int aln_cap,
 						 const uint8_t *status, const int32_t *wide_idx, const uint4 *aln2, int aln_cap2,
-						 uint4 *out, hipStream_t s);
+						 const uint4 *const *grown, uint4 *out, hipStream_t s);
 int nabwa_search_occupancy(int ns);
 void nabwa_launch_partition(int n, const uint8_t *cls, int32_t *ids, unsigned int *cnt, hipStream_t s);
 void nabwa_launch_padded_len(int n, const int64_t *off, int64_t *plen, hipStream_t s);
@@ -431,6 +434,8 @@ struct nabwa_batch {
 	SearchParams P; int class_sort; uint32_t NS_wide; int n_blocks, n_blocks_w; uint8_t *d_scratch, *d_wdata, *d_nN; float last_ms_w;
 	int32_t *d_naln, *d_maxent, *d_wide_idx; uint8_t *d_status; uint4 *d_aln;
 	unsigned int *d_counter, *d_novf; int32_t *d_ovf_ids;
+	uint8_t *grown[8]; int n_grown;           // row blocks of the reads whose hit lists outgrew the wide rows (nabwa_batch_sync)
+	const uint4 **d_grown_tab; int grown_cap, grown_used;      // device table: slot -> rows of one such read (wide_idx of a NABWA_ST_GROWN read)
 	// wide pass (allocated on demand)
 	int n2, aln_cap2; uint8_t *d_scratch2; size_t scratch2_bytes; int32_t *d_naln2, *d_maxent2; uint8_t *d_status2; uint4 *d_aln2;
 	int unresolved;
@@ -467,6 +472,8 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 					 b->d_status2, b->d_aln2, b->d_sum, b->d_pages, b->d_page_prev, b->d_deep_own, b->d_deep_stage, b->d_deep_ctr };
 	if (b->stream) (void)hipStreamSynchronize(b->stream);      /* the buffers go back to the pool, not to the driver: nothing may still use them */
 	for (void *p : ptrs) if (p) (void)pool_free(b->ix, p);
+	for (int t = 0; t < b->n_grown; ++t) (void)pool_free(b->ix, b->grown[t]);
+	if (b->d_grown_tab) (void)pool_free(b->ix, (void*)b->d_grown_tab);
 	if (b->ev0) (void)hipEventDestroy(b->ev0);
 	if (b->ev1) (void)hipEventDestroy(b->ev1);
 	if (b->evw) (void)hipEventDestroy(b->evw);
@@ -680,6 +687,11 @@ extern "C" int nabwa_batch_run(nabwa_batch_t *b)
 	HIPCHK(hipSetDevice(b->ix->device));
 	b->unresolved = 0;
 	if (b->n == 0) return NABWA_OK;
+	if (b->n_grown) {          /* row blocks of the previous run's longest hit lists: that run's results are gone with this one */
+		HIPCHK(hipStreamSynchronize(b->stream));
+		for (int t = 0; t < b->n_grown; ++t) HIPCHK(pool_free(b->ix, b->grown[t]));
+		b->n_grown = 0; b->grown_used = 0;
+	}
 	HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 	HIPCHK(hipMemsetAsync(b->d_novf, 0, 4, b->stream));
 	HIPCHK(hipEventRecord(b->evw, b->stream));
@@ -925,8 +937,50 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		unsigned int n_hit = 0;
 		int r = recollect(NABWA_ST_HITCAP, &n_hit);
 		if (r != NABWA_OK) return r;
+		/* A hit list that outgrew the wide rows: the reference's list grows without bound (bwtgap.c:186-190), so those searches run
+		 * again with 16 x the rows, then 256 x ... in a block of their own (NABWA_HIT_GROW steps, NABWA_HIT_GROW_GB at most); a table
+		 * on the device names the rows of every read resolved that way (status NABWA_ST_GROWN, wide_idx = its slot there). */
+		size_t cap3 = (size_t)b->aln_cap2;
+		for (int grow = 0; n_hit && grow < env_int("NABWA_HIT_GROW", 3) && b->n_grown < 8; ++grow) {
+			cap3 *= 16;
+			const size_t bytes = (size_t)n_hit * cap3 * 16;
+			if (bytes > ((size_t)env_int("NABWA_HIT_GROW_GB", 8) << 30) || cap3 > 0x7fffffffu) break;
+			uint8_t *raw = 0; int32_t *n3 = 0, *m3 = 0; uint8_t *s3 = 0;
+			HIPCHK(pool_malloc(b->ix, (void**)&raw, bytes));
+			b->grown[b->n_grown++] = raw;
+			HIPCHK(pool_malloc(b->ix, (void**)&n3, (size_t)n_hit * 4)); HIPCHK(pool_malloc(b->ix, (void**)&m3, (size_t)n_hit * 4)); HIPCHK(pool_malloc(b->ix, (void**)&s3, n_hit));
+			uint8_t *const base = raw;
+			if (!b->d_grown_tab || (b->grown_used == 0 && b->grown_cap < 8 * (int)n_hit + 8)) {      /* every step resolves or repeats reads of the first step's list */
+				if (b->d_grown_tab) { HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(pool_free(b->ix, (void*)b->d_grown_tab)); b->d_grown_tab = 0; }
+				b->grown_cap = 8 * (int)n_hit + 8;
+				HIPCHK(pool_malloc(b->ix, (void**)&b->d_grown_tab, (size_t)b->grown_cap * 8));
+				b->grown_used = 0;
+			}
+			if (b->grown_used + (int)n_hit > b->grown_cap) break;
+			DeepParams G = D;
+			G.S.res_slot = 0; G.S.n_aln = n3; G.S.max_ent = m3; G.S.status = s3; G.S.aln = (uint4*)base; G.S.aln_cap = (int)cap3;
+			G.rounds_out = 0;
+			long waves = (long)(n_pages / cap_pages);          /* as many searches at a time as the pool can hold in the worst case */
+			if (waves < 1) waves = 1;
+			if (waves > n_waves) waves = n_waves;
+			if (waves > (long)n_hit) waves = (long)n_hit;
+			G.S.n = (int)n_hit; G.own_cap = (uint32_t)cap_pages;
+			rebuild_widths(G.S, n_hit);
+			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
+			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 256, b->stream));
+			G.S.work_counter = b->d_counter;
+			nabwa_launch_fm_deep(&G, (int)waves, b->stream);
+			nabwa_launch_scatter_grown((int)n_hit, b->d_ovf_ids, n3, m3, s3, b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, (const uint4*)base, cap3, b->d_grown_tab, b->grown_used, b->stream);
+			b->grown_used += (int)n_hit;
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(b->stream));
+			HIPCHK(pool_free(b->ix, n3)); HIPCHK(pool_free(b->ix, m3)); HIPCHK(pool_free(b->ix, s3));
+			if (timing) fprintf(stderr, "[nabwa] kernel D, hit lists beyond %d rows: %u reads searched again with %zu rows each\n", b->aln_cap2, n_hit, cap3);
+			r = recollect(NABWA_ST_HITCAP, &n_hit);
+			if (r != NABWA_OK) return r;
+		}
 		b->unresolved = (int)n_hit;
-		if (n_hit) return fail(NABWA_EHITS, "reads with more hit rows than NABWA_ALNCAP2: raise it (their n_aln is reported as 0, every other read is resolved)");
+		if (n_hit) return fail(NABWA_EHITS, "reads with more hit rows than the grown lists hold (NABWA_ALNCAP2 x 16^NABWA_HIT_GROW within NABWA_HIT_GROW_GB): their n_aln is reported as 0, every other read is resolved");
 	}
 	return NABWA_OK;
 }
@@ -1006,7 +1060,7 @@ extern "C" int nabwa_batch_checksum(nabwa_batch_t *b, uint64_t *sum, int64_t *n_
 	HIPCHK(hipSetDevice(b->ix->device));
 	unsigned long long h[2] = { 0, 0 };
 	HIPCHK(hipMemsetAsync(b->d_sum, 0, 16, b->stream));
-	nabwa_launch_checksum(b->n, b->d_naln, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2,
+	nabwa_launch_checksum(b->n, b->d_naln, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2, b->d_grown_tab,
 						  b->d_sum, b->d_sum + 1, b->stream);
 	HIPCHK(hipMemcpyAsync(h, b->d_sum, 16, hipMemcpyDeviceToHost, b->stream));
 	HIPCHK(hipStreamSynchronize(b->stream));
@@ -1040,7 +1094,7 @@ extern "C" int nabwa_batch_fetch(nabwa_batch_t *b, int32_t *n_aln, nabwa_aln1_t 
 	if (total > aln_cap || (total && !aln_out)) rc = fail(NABWA_ECAP, "aln_cap too small");
 	else if (total) {
 		HIPCHK(pool_malloc(b->ix, (void**)&d_rows, (size_t)total * 16));
-		nabwa_launch_gather(b->n, b->d_naln, d_off, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2,
+		nabwa_launch_gather(b->n, b->d_naln, d_off, b->d_aln, b->P.aln_cap, b->d_status, b->d_wide_idx, b->d_aln2, b->aln_cap2, b->d_grown_tab,
 							d_rows, b->stream);
 		HIPCHK(hipMemcpyAsync(aln_out, d_rows, (size_t)total * 16, hipMemcpyDeviceToHost, b->stream));
 		HIPCHK(hipStreamSynchronize(b->stream));

@@ -90,7 +90,31 @@ def test_max_entries_cutoff_on_the_gpu(gix, orc, monkeypatch, max_entries):
     assert not bad and np.array_equal(maxe, wmaxe)
 
 
-def test_more_hit_rows_than_alncap2_is_an_error_with_the_other_reads_intact(gix, orc, monkeypatch):
+def test_hit_lists_beyond_the_wide_rows_are_searched_again_with_longer_lists(gix, orc, monkeypatch):
+    """NABWA_ALNCAP2 = 1 row per read in the wide result arrays: the reference's hit list grows without bound (bwtgap.c:186-190), so
+    the reads with more hits are searched again with 16 x the rows (then 256 x ...), and every read gets its rows"""
+    monkeypatch.setenv("NABWA_CAP1", "16")
+    monkeypatch.setenv("NABWA_ALNCAP2", "1")
+    for name in ("se_adna", "se_nonstop"):
+        opt, gold = T.read_sai(os.path.join(T.GOLDEN, name + ".sai"))
+        reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "se_nonstop" else "reads_se.fq"))
+        seq, rseq, off, _ = T.encode_reads(reads)
+        assert max(len(g) for g in gold) > 1
+        for _ in range(2):                                           # the same batch run twice: the grown blocks of the first run are released
+            b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
+            b.run(); b.sync()
+            b.run(); b.sync()
+            got, _ = b.fetch()
+            b.close()
+            for i in range(len(reads)):
+                assert got[i].tobytes() == gold[i].tobytes(), (name, reads[i][0])
+        got, _ = gix.cal_sa_reg_gap(to_gap_opt(opt), seq, rseq, off)
+        for i in range(len(reads)):
+            assert got[i].tobytes() == gold[i].tobytes(), (name, reads[i][0])
+
+
+def test_more_hit_rows_than_the_grown_lists_is_an_error_with_the_other_reads_intact(gix, orc, monkeypatch):
+    monkeypatch.setenv("NABWA_HIT_GROW", "0")                        # no second search: the error path
     """NABWA_ALNCAP2 = 1 row per read in the wide result arrays: reads with more hits cannot be answered.  That is its own
     error code (never an empty answer that looks like "unmapped"), the resolved reads are still handed out, and the
     bwa_seq_t-level entry reports the error too."""
