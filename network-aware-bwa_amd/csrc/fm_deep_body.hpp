@@ -11,11 +11,13 @@
 //   * A ROUND pops the top W <= 64 entries of the lowest non-empty score s at once, one per lane (lane 0 = the top).
 //     Each lane runs its entry's CHAIN: pre-checks, hit test / exact tail, expansion; the matching child (same score,
 //     pushed last, hence the very next pop of the reference) continues the chain in registers; every other child has a
-//     score > s and is STAGED in the lane's own buffer.  Between two hits the reference's loop body is a pure function
-//     of the popped entry, so the W chains are independent -- this is where the parallelism comes from.
+//     score > s and is STAGED: the step files one 64-byte RECORD in the lane's own buffer (the intervals of the four
+//     possible next symbols, the parent, which groups of children it pushes) and counts the children per class.  Between
+//     two hits the reference's loop body is a pure function of the popped entry, so the W chains are independent -- this
+//     is where the parallelism comes from.
 //   * COMMIT restores the reference's order exactly: the reference would have run chain 0 to its end, then chain 1, ...
 //     so the staged children go to their score levels lane by lane (a prefix sum over the lanes gives every lane its
-//     slots; within a lane in chain order).  A chain that ends in a hit (the search state changes: max_diff, the width
+//     slots; within a lane in chain order): the 64 lanes share out the round's records and turn each into its entries.  A chain that ends in a hit (the search state changes: max_diff, the width
 //     bounds through gap_shadow, best_score) or that fills its staging buffer invalidates the lanes above it: they are
 //     dropped (their entries are still on the stack) and popped again in the next round.
 //   * The live-entry count before every pop (bwtgap.c:139-140: statistic and cut-off) is exact: a lane tracks the count
