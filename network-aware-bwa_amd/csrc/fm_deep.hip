@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const Dee
 extern "C" void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s)
 {
 	const size_t lds = (size_t)DEEP_LDS_WORDS(P->NS, P->lds_rd) * 4u;
-	if (P->stats) hipLaunchKernelGGL(fm_deep_kernel<true>, dim3(n_waves), dim3(64), lds, s, *P);
+	if (P->stats || P->S.touch_counter) hipLaunchKernelGGL(fm_deep_kernel<true>, dim3(n_waves), dim3(64), lds, s, *P);
 	else hipLaunchKernelGGL(fm_deep_kernel<false>, dim3(n_waves), dim3(64), lds, s, *P);
 }
 

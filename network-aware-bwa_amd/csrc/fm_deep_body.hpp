@@ -130,7 +130,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(uint32_t, d); LANE(uint32_t, off);
 	LANE(int, nst);
 	LANE(uint32_t, tch);      // bucket touches of the reference algorithm in this lane's chain (instrumented runs only)
-	const bool counting = S.touch_counter != 0;
+	const bool counting = PROF && S.touch_counter != 0;      // (the touch-counting run uses the statistics instantiation: one per-lane counter less to carry)
 
 	// the read's own data: from LDS, or (reads too long for it) from where kernel W / the batch put them
 #define DEEP_BB(a_, p_) (lds_mode ? (uint32_t)s_bb[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)] : (uint32_t)(rec + S.woff_bid)[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)])
