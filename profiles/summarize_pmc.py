@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, "g*", "**", "*counter_collection.csv"), re
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         nm = name.replace(" ", "")
-        if "fm_search_kernel<false,false>" in nm:        # production first pass (not the touch-counting instantiation)
+        if "fm_search_kernel<false>" in nm or "fm_search_kernel<false,false>" in nm:      # production first pass (not the touch-counting instantiation; two parameters until round 2's clean-up)
             k = "S"
         elif "fm_width_kernel<false>" in nm:
             k = "W"
