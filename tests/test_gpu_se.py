@@ -37,6 +37,8 @@ def test_global_align_golden():
             want = vec["dp_cig"][vec["dp_cig_off"][t]:vec["dp_cig_off"][t + 1]]
             assert score[j] == vec["dp_score"][t], (pid, t)
             assert list(cigs[j]) == list(want), (pid, t)
+        if pid == 0:                                   # the working memory kept between calls can be given back at any time
+            nabwa.lib().nabwa_dp_scratch_release(0)
 
 
 def test_global_align_random_vs_oracle():
