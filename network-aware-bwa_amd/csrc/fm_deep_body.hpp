@@ -31,7 +31,8 @@
 #include "fm_deep.hpp"
 #include "wave_spmd.hpp"
 
-struct DeepLane { uint32_t k, l; int i, a, mm, go, ge, state, ldp; };
+// the entry a lane's chain works on, packed as it is stored (two words of fields: five registers less per lane than one per field)
+struct DeepLane { uint32_t k, l; uint32_t i : 16, ldp : 16; uint32_t mm : 8, go : 8, ge : 8, state : 2, a : 1, unused_ : 5; };
 
 #ifdef NABWA_EMU
 #define DEEP_FN static
@@ -51,9 +52,9 @@ DEEP_FN uint4 deep_pack(uint32_t k, uint32_t l, int i, int ldp, int mm, int go, 
 
 DEEP_FN void deep_unpack(const uint4 &r, DeepLane &e)
 {
-	e.k = r.x; e.l = r.y; e.i = (int)(r.z & 0xffffu); e.ldp = (int)(r.z >> 16);
-	e.mm = (int)(r.w & 0xffu); e.go = (int)(r.w >> 8 & 0xffu); e.ge = (int)(r.w >> 16 & 0xffu);
-	e.state = (int)(r.w >> 24 & 3u); e.a = (int)(r.w >> 26 & 1u);
+	e.k = r.x; e.l = r.y; e.i = r.z & 0xffffu; e.ldp = r.z >> 16;
+	e.mm = r.w & 0xffu; e.go = r.w >> 8 & 0xffu; e.ge = r.w >> 16 & 0xffu;
+	e.state = r.w >> 24 & 3u; e.a = r.w >> 26 & 1u; e.unused_ = 0u;
 }
 
 // nabwa_occ4_pair (nabwa_dev.hpp) with the loads of BOTH buckets issued before either is used: one memory latency per query
