@@ -927,6 +927,12 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 					}
 					fclose(f);
 				}
+				{	/* <file>.all: per read of the batch its two restart classes and whether kernel S handed it on */
+					std::vector<uint8_t> st((size_t)b->n);
+					HIPCHK(hipMemcpy(st.data(), b->d_status, st.size(), hipMemcpyDeviceToHost));
+					FILE *g = fopen((std::string(dump_path) + ".all").c_str(), "wb");
+					if (g) { for (int i = 0; i < b->n; ++i) { const uint8_t row[4] = { cls[2 * (size_t)i], cls[2 * (size_t)i + 1], (uint8_t)(st[i] != NABWA_ST_OK), md[i] }; fwrite(row, 1, 4, g); } fclose(g); }
+				}
 				HIPCHK(pool_free(b->ix, d_rounds)); D.rounds_out = 0;
 			}
 			todo = n_pool;
