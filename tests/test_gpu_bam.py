@@ -177,3 +177,36 @@ def test_isize_table_blob_and_merge():
     assert L.nabwa_isize_table_get(b, b"grp1", C.byref(got)) == 0 and bytes(got) == bytes(ii)
     chk(L, L.nabwa_isize_table_merge(a, b))
     L.nabwa_isize_table_destroy(a); L.nabwa_isize_table_destroy(b)
+
+
+def test_awkward_records_go_through_both_passes():
+    """an empty batch; a record without bases; a read of nothing but N; a read shorter than any seed: none of them may stop a batch,
+    and the ordinary reads around them keep the answers the reference's samse gives them.  A record flagged as paired whose mate is not
+    the next record is the reference's error too (read_bam_pair returns -2 unless broken input is allowed, bwaseqio.c:378-396)."""
+    L = bind()
+    opt, _ = T.read_sai(os.path.join(T.GOLDEN, "se_default.sai"))
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:40]
+    sam = T.parse_sam(os.path.join(T.GOLDEN, "se_default.sam"))[:40]
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    normal = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    odd = [B.make_record("empty", "", "", 4), B.make_record("all_n", "N" * 60, "I" * 60, 4), B.make_record("tiny", "ACGTACG", "IIIIIII", 4)]
+    out, _, _ = run_batches(L, ix, opt, [[], normal[:20] + odd[:2], odd[2:] + normal[20:], []])
+    names = [o["name"] for o in out]
+    assert names == [r[0] for r in reads[:20]] + ["empty", "all_n", "tiny"] + [r[0] for r in reads[20:]]
+    by = {o["name"]: o for o in out}
+    for nm in ("empty", "all_n"):
+        assert by[nm]["flag"] & 4 and by[nm]["rname"] == "*" and by[nm]["cigar"] == "*", (nm, by[nm])
+    assert by["tiny"]["seq"] in ("ACGTACG", "CGTACGT") and by["tiny"]["mapq"] == 0          # seven bases occur in many places: placed somewhere, mapping quality 0
+    assert by["empty"]["seq"] in ("", "*") and by["all_n"]["seq"] == "N" * 60
+    for g, s in zip([o for o in out if o["name"] not in ("empty", "all_n", "tiny")], sam):
+        # the drand48 stream differs from samse's run once extra records sit between the reads: only reads with one best place are compared
+        if s["tags"].get("X0", 1) == 1 and not (s["flag"] & 4):
+            assert (g["rname"], g["pos"], g["cigar"], g["tags"].get("NM")) == (s["rname"], s["pos"], s["cigar"], s["tags"].get("NM")), s["name"]
+    # the lone mate
+    g = nabwa.GapOpt(); C.memmove(C.byref(g), C.byref(opt), 64)
+    po = nabwa.pe_opt_default()
+    buf, off = B.pack([B.make_record("widow", reads[0][1], reads[0][2], 1 | 4 | 8 | 64), normal[1]])
+    h = P()
+    assert L.nabwa_bam_batch_create(ix._h, C.byref(g), C.byref(po), 2, T.ptr(buf), T.ptr(off), C.byref(h)) == nabwa.EINVAL
+    assert b"lone mate" in L.nabwa_last_error()
+    ix.close()
