@@ -320,6 +320,22 @@ int64_t nabwa_isize_table_encode(const nabwa_isize_table_t *t, uint8_t *out, int
 int nabwa_isize_table_decode(nabwa_isize_table_t *t, const uint8_t *in, int64_t n);
 int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
 						   const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out);
+/* the same with bam2bam's record-handling switches (bam2bam.c:96-101,1988-1993):
+ *   BROKEN_INPUT    --broken-input   : read_bam_pair's allow_broken (bwaseqio.c:345-410): wrong read 1 / read 2 flags of two reads of
+ *                                      one name are set right, a paired read followed by another name (or by nothing) is discarded
+ *   DROP_ALIGNED    --drop-aligned   : logical records with a read that is already mapped are left out (bwaseqio.c:466-474)
+ *   SKIP_DUPLICATES --skip-duplicates: logical records with a read flagged as duplicate (0x400) are neither aligned nor counted
+ *                                      for the insert size; they come out as they came in, less the erased tags (unique(), bam2bam.c:595-606)
+ *   DEBUG           --debug-bam      : YQ:i = the most entries the search of the read held (bam2bam.c:433)
+ *   ONLY_ALIGNED    --only-aligned   : output leaves out logical records with a read that stayed unmapped (pair_print_bam, bam2bam.c:911-925) */
+#define NABWA_BAM_BROKEN_INPUT    1u
+#define NABWA_BAM_DROP_ALIGNED    2u
+#define NABWA_BAM_SKIP_DUPLICATES 4u
+#define NABWA_BAM_DEBUG           8u
+#define NABWA_BAM_ONLY_ALIGNED    16u
+#define NABWA_BAM_ALL_FLAGS       31u
+int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, uint32_t flags, int n_rec,
+							  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out);
 int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab);
 int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2]);
 int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes);

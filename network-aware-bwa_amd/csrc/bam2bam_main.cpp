@@ -6,8 +6,8 @@
 // (bam2bam.c:1143-1216) through the batch front-end of the library (nabwa_bam_batch_*, bam_batch.hip) -> BGZF BAM out with
 // the header bwa_print_bam_header writes (@HD VN:1.4, a new @PG chained to the old one, @SQ from the .ann file, the other old
 // lines kept; bam2bam.c:164-301).  Host code only; the GPU work is the library's.  Not provided: the 0MQ master / worker modes
-// (-p, `bwa worker`: libzmq is absent from the build image), resuming from .sai files (-0 -1 -2), --only-aligned,
-// --drop-aligned, --skip-duplicates, --broken-input, --debug-bam -- each is refused, none is silently ignored.
+// (-p, `bwa worker`: libzmq is absent from the build image) and resuming from .sai files (-0 -1 -2) -- each is refused, none is
+// silently ignored.  --only-aligned, --drop-aligned, --skip-duplicates, --broken-input and --debug-bam are the library's NABWA_BAM_* flags.
 // -t is accepted and ignored (one GPU; NABWA_DEVICE picks it), --temp-dir likewise (the records wait in memory between the passes).
 #include <getopt.h>
 #include <stdint.h>
@@ -119,6 +119,7 @@ static std::string header_text(nabwa_index_t *ix, const std::string &old, int ar
 
 int main(int argc, char **argv)
 {
+	uint32_t rec_flags = 0;                                    /* NABWA_BAM_*: --only-aligned, --drop-aligned, --debug-bam, --broken-input, --skip-duplicates */
 	static struct option longopts[] = {
 		{ "num-diff", 1, 0, 'n' }, { "max-gap-open", 1, 0, 'o' }, { "max-gap-extensions", 1, 0, 'e' }, { "indel-near-end", 1, 0, 'i' },
 		{ "deletion-occurences", 1, 0, 'd' }, { "seed-length", 1, 0, 'l' }, { "seed-mismatches", 1, 0, 'k' }, { "queue-size", 1, 0, 'm' },
@@ -160,8 +161,13 @@ int main(int argc, char **argv)
 			case 'h': po.n_multi = atoi(optarg); break;
 			case 'H': po.N_multi = atoi(optarg); break;
 			case 132: break;
-			case 'p': case '0': case '1': case '2': case 128: case 129: case 130: case 131: case 133:
-				fprintf(stderr, "[nabwa_bam2bam] this option of bwa bam2bam is not provided (0MQ modes, .sai resume, --only-aligned, --drop-aligned, --debug-bam, --broken-input, --skip-duplicates)\n");
+			case 128: rec_flags |= NABWA_BAM_ONLY_ALIGNED; break;
+			case 129: rec_flags |= NABWA_BAM_DEBUG; break;
+			case 130: rec_flags |= NABWA_BAM_BROKEN_INPUT; break;
+			case 131: rec_flags |= NABWA_BAM_SKIP_DUPLICATES; break;
+			case 133: rec_flags |= NABWA_BAM_DROP_ALIGNED; break;
+			case 'p': case '0': case '1': case '2':
+				fprintf(stderr, "[nabwa_bam2bam] this option of bwa bam2bam is not provided (0MQ modes, .sai resume)\n");
 				return 1;
 			default: return 1;
 		}
@@ -217,12 +223,13 @@ int main(int argc, char **argv)
 		nabwa_bam_batch_destroy(b);
 	};
 	std::vector<uint8_t> buf; std::vector<int64_t> off(1, 0);
-	bool hold_mate = false;
+	bool hold_mate = false;                                   /* the last record is a paired read that waits for the record after it */
+	size_t held_at = 0;                                       /* where it starts in buf */
 	auto flush = [&]() {
 		const long n_rec = (long)off.size() - 1;
 		if (n_rec <= 0) return;
 		nabwa_bam_batch_t *b = 0;
-		if (nabwa_bam_batch_create(ix, &go, &po, (int)n_rec, buf.data(), off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
+		if (nabwa_bam_batch_create_ex(ix, &go, &po, rec_flags, (int)n_rec, buf.data(), off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
 		if (nabwa_bam_batch_pass1(b, &rng, tab) != NABWA_OK) die("pass 1", nabwa_last_error());
 		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
 		tot_seqs += nr;
@@ -243,7 +250,11 @@ int main(int argc, char **argv)
 		uint32_t z; memcpy(&z, &buf[at + 16], 4);
 		const bool paired = (z >> 16) & 1;
 		off.push_back((int64_t)buf.size());
-		hold_mate = paired ? !hold_mate : false;              /* a paired read waits for the record after it */
+		/* read_bam_pair_core's view of the stream (bwaseqio.c:345-410): a paired read takes the next record as its mate if the names
+		 * agree; if they do not it is a lone mate (an error, or dropped with --broken-input) and the next record starts afresh */
+		const bool mates = hold_mate && !strcmp((const char*)&buf[held_at + 36], (const char*)&buf[at + 36]);
+		hold_mate = mates ? false : paired;
+		held_at = at;
 		any_pairs |= paired;
 		if ((long)off.size() - 1 >= BATCH && !hold_mate) flush();
 	}

@@ -62,6 +62,7 @@ static void bam_parallel(size_t n, const std::function<void(int, size_t, size_t)
 #define F_R2 128
 #define F_SC 256
 #define F_QC 512
+#define F_DP 1024
 
 /* ------------------------------------------------------------------ per-@RG insert-size table (insert_size.c:141-213) */
 
@@ -294,9 +295,10 @@ static void set_cigar(BamRec &r, int n, const uint32_t *c)       /* bam_resize_c
  * end's pair fields.  p / mate are in the state nabwa_se_refine / nabwa_pe_finish leave them in, i.e. with the side effects the
  * reference's calls have on them (an unmapped end takes its mate's place, a contig-bridging hit loses its mapQ) already applied. */
 static void update_bam(BamRec &out, const nabwa_reference *R, const nabwa_se_t &p, const nabwa_se_t *mate, const nabwa_pe_t *pe,
-					   int mode, int max_top2)
+					   int mode, int max_top2, int yq)
 {
 	if (p.clip_len < p.full_len) push_int(out, 'X', 'C', p.clip_len);
+	if (yq) push_int(out, 'Y', 'Q', yq);                  /* --debug-bam: the most entries the search held (bam2bam.c:433) */
 	if (p.type != 0 || (mate && mate->type != 0)) {
 		if ((p.strand != 0) != ((out.flag & F_SR) != 0)) revcom_rec(out);
 		out.flag &= ~(uint32_t)(F_PP | F_SU | F_MU | F_SC | F_MR);
@@ -403,12 +405,14 @@ struct nabwa_bam_batch {
 	std::vector<int> kind;                         /* per logical record: 1 or 2 */
 	std::vector<int> first;                        /* per logical record: index of its first read */
 	std::vector<std::string> rg;                   /* per logical record */
+	std::vector<uint8_t> skip;                     /* per logical record: a flagged duplicate that passes through untouched (--skip-duplicates; unique(), bam2bam.c:595-606) */
+	uint32_t flags;                                /* NABWA_BAM_* */
 	std::vector<int64_t> off; RawBytes seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
 	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
 	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
 	size_t res_bytes;
-	nabwa_bam_batch() : res(0), phase(0), res_bytes(0) {}
+	nabwa_bam_batch() : flags(0), res(0), phase(0), res_bytes(0) {}
 	~nabwa_bam_batch() { res_give(res, res_bytes); }
 };
 
@@ -417,10 +421,17 @@ static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 
 extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
 									  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out)
 {
+	return nabwa_bam_batch_create_ex(ix, opt, popt, 0, n_rec, in, in_off, out);
+}
+
+extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, uint32_t flags, int n_rec,
+										 const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out)
+{
 	if (!ix || !opt || !popt || !out || n_rec < 0 || (n_rec && (!in || !in_off))) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (flags & ~(uint32_t)NABWA_BAM_ALL_FLAGS) return nabwa_fail(NABWA_EINVAL, "unknown NABWA_BAM_* flag");
 	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
 	nabwa_bam_batch *b = new nabwa_bam_batch();
-	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0;
+	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0; b->flags = flags;
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	const double tc0 = bam_now();
 	b->rec.resize(n_rec);
@@ -433,18 +444,48 @@ extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	}
 	const double tc1 = bam_now();
 	/* logical records (read_bam_pair_core, bwaseqio.c:346-410): a paired read takes the next record as its mate -- same name,
-	 * flags read 1 / read 2 in either order; anything else is the reference's "lone mate" error (no broken-input mode here) */
-	for (int i = 0; i < n_rec; ) {
-		if (b->rec[i].flag & F_PD) {
-			if (i + 1 >= n_rec) { delete b; return nabwa_fail(NABWA_EINVAL, "a paired read at the end of the batch without its mate (keep mates in one batch)"); }
-			BamRec &r0 = b->rec[i], &r1 = b->rec[i + 1];
-			const uint32_t f0 = r0.flag & (F_PD | F_R1 | F_R2), f1 = r1.flag & (F_PD | F_R1 | F_R2);
-			if (strcmp((const char*)r0.data.data(), (const char*)r1.data.data()) != 0) { delete b; return nabwa_fail(NABWA_EINVAL, "lone mate: two paired reads whose names do not match"); }
-			if (f0 == (F_PD | F_R2) && f1 == (F_PD | F_R1)) std::swap(r0, r1);
-			else if (!(f0 == (F_PD | F_R1) && f1 == (F_PD | F_R2))) { delete b; return nabwa_fail(NABWA_EINVAL, "a pair whose read 1 / read 2 flags are wrong"); }
-			r0.flag |= r1.flag & F_QC; r1.flag |= r0.flag & F_QC;          /* either none or both pass QC (bwaseqio.c:486-489) */
-			b->kind.push_back(2); b->first.push_back(i); i += 2;
-		} else { b->kind.push_back(1); b->first.push_back(i); i += 1; }
+	 * flags read 1 / read 2 in either order.  Anything else is an error, or with NABWA_BAM_BROKEN_INPUT (allow_broken) is mended as
+	 * the reference mends it: wrong flags are set right, a paired read whose successor has another name is discarded and that
+	 * successor starts the next logical record, a paired read with nothing after it is discarded.  NABWA_BAM_DROP_ALIGNED
+	 * (read_bam_pair's ignore_aligned, bwaseqio.c:466-474) leaves out logical records any read of which is already mapped. */
+	{
+		const bool broken = (flags & NABWA_BAM_BROKEN_INPUT) != 0, drop = (flags & NABWA_BAM_DROP_ALIGNED) != 0, nodup = (flags & NABWA_BAM_SKIP_DUPLICATES) != 0;
+		std::vector<int> src; src.reserve(n_rec);
+		for (int i = 0; i < n_rec; ) {
+			BamRec &r0 = b->rec[i];
+			int k = 1;
+			if (r0.flag & F_PD) {
+				if (i + 1 >= n_rec) {
+					if (broken) break;
+					delete b; return nabwa_fail(NABWA_EINVAL, "a paired read at the end of the batch without its mate (keep mates in one batch)");
+				}
+				BamRec &r1 = b->rec[i + 1];
+				const uint32_t f0 = r0.flag & (F_PD | F_R1 | F_R2), f1 = r1.flag & (F_PD | F_R1 | F_R2);
+				if (strcmp((const char*)r0.data.data(), (const char*)r1.data.data()) != 0) {
+					if (broken) { ++i; continue; }
+					delete b; return nabwa_fail(NABWA_EINVAL, "lone mate: two paired reads whose names do not match");
+				}
+				if (f0 == (F_PD | F_R2) && f1 == (F_PD | F_R1)) std::swap(r0, r1);
+				else if (!(f0 == (F_PD | F_R1) && f1 == (F_PD | F_R2))) {
+					if (!broken) { delete b; return nabwa_fail(NABWA_EINVAL, "a pair whose read 1 / read 2 flags are wrong"); }
+					r0.flag = (r0.flag & ~(uint32_t)F_R2) | F_PD | F_R1; r1.flag = (r1.flag & ~(uint32_t)F_R1) | F_PD | F_R2;
+				}
+				k = 2;
+			}
+			const uint32_t all = r0.flag & (k == 2 ? b->rec[i + 1].flag : ~0u), any = r0.flag | (k == 2 ? b->rec[i + 1].flag : 0u);
+			if (!(drop && !(all & F_SU))) {
+				if (k == 2) { BamRec &r1 = b->rec[i + 1]; r0.flag |= r1.flag & F_QC; r1.flag |= r0.flag & F_QC; }          /* either none or both pass QC (bwaseqio.c:486-489) */
+				b->kind.push_back(k); b->first.push_back((int)src.size()); b->skip.push_back(nodup && (any & F_DP));
+				for (int e = 0; e < k; ++e) src.push_back(i + e);
+			}
+			i += k;
+		}
+		if ((int)src.size() != n_rec) {
+			std::vector<BamRec> kept(src.size());
+			for (size_t t = 0; t < src.size(); ++t) kept[t] = std::move(b->rec[src[t]]);
+			b->rec.swap(kept);
+			n_rec = (int)src.size();
+		}
 	}
 	{
 		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
@@ -457,6 +498,8 @@ extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	b->off.assign(n_rec + 1, 0); b->full_len.assign(n_rec ? n_rec : 1, 0);
 	{
 		std::vector<int32_t> lens(n_rec ? n_rec : 1, 0);
+		std::vector<uint8_t> rskip(n_rec ? n_rec : 1, 0);       /* a duplicate that is passed through is searched as a read without bases */
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->skip[k]) for (int e = 0; e < b->kind[k]; ++e) rskip[b->first[k] + e] = 1;
 		bam_parallel((size_t)n_rec, [&](int, size_t lo, size_t hi) {
 			for (size_t i = lo; i < hi; ++i) {
 				const BamRec &x = b->rec[i];
@@ -474,7 +517,7 @@ extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *
 					}
 					len = max_l + 1;
 				}
-				lens[i] = len; b->full_len[i] = L;
+				lens[i] = rskip[i] ? 0 : len; b->full_len[i] = L;
 			}
 		});
 		for (int i = 0; i < n_rec; ++i) b->off[i + 1] = b->off[i] + lens[i];
@@ -535,6 +578,8 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 		if (rc != NABWA_OK) return rc;
 	}
 	for (int i = 0; i < n; ++i) b->row0[i + 1] = b->row0[i] + b->n_aln[i];
+	for (size_t k = 0; k < b->kind.size(); ++k) if (b->skip[k]) for (int e = 0; e < b->kind[k]; ++e)
+		if (b->n_aln[b->first[k] + e]) return nabwa_fail(NABWA_EINVAL, "internal: a read without bases came back with hits");
 	/* posn_singleton / posn_pair in record order: singletons list up to max_occ_se other hits, ends of pairs none */
 	std::vector<uint8_t> n_occ(n ? n : 1, 0);
 	for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) n_occ[b->first[k]] = (uint8_t)b->popt.max_occ_se;
@@ -551,6 +596,7 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	/* improve_isize_est (insert_size.c:141-165) */
 	for (size_t k = 0; k < b->kind.size(); ++k) {
 		const int i = b->first[k];
+		if (b->skip[k]) continue;
 		const nabwa_se_t &s0 = b->res[i].se;
 		const nabwa_se_t &s1 = b->kind[k] == 2 ? b->res[i + 1].se : s0;
 		isize_add(tab, b->rg[k], nabwa_isize_bin(b->kind[k], s0.mapQ, s1.mapQ, s0.pos, s0.len, s1.pos, s1.len));
@@ -571,7 +617,7 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	/* ---- singletons: bwa_refine_gapped + what bwa_update_bam1 derives */
 	{
 		std::vector<int> idx;
-		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1) idx.push_back(b->first[k]);
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 1 && !b->skip[k]) idx.push_back(b->first[k]);
 		if (idx.size() == b->rec.size() && !idx.empty()) {       /* a batch of singletons only: in place, no gathering */
 			int rc = nabwa_se_refine_strided(b->ix, (int)idx.size(), b->off.data(), b->seq.data(), b->rseq.data(), b->res, sizeof(nabwa_pe_t));
 			if (rc != NABWA_OK) return rc;
@@ -592,7 +638,7 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	/* ---- pairs, one read group at a time with that group's estimate (pass 2 draws no random numbers: its order is free) */
 	{
 		std::map<std::string, std::vector<int>> groups;
-		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2) groups[b->rg[k]].push_back(b->first[k]);
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2 && !b->skip[k]) groups[b->rg[k]].push_back(b->first[k]);
 		for (auto &g : groups) {
 			nabwa_isize_t ii;
 			nabwa_isize_table_get(tab, g.first.c_str(), &ii);
@@ -618,10 +664,12 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	bam_parallel(b->kind.size(), [&](int, size_t lo, size_t hi) {
 		for (size_t k = lo; k < hi; ++k) {
 			const int i = b->first[k];
-			if (b->kind[k] == 1) update_bam(b->rec[i], R, b->res[i].se, 0, 0, b->opt.mode, b->opt.max_top2);
+			if (b->skip[k]) continue;
+			const bool dbg = (b->flags & NABWA_BAM_DEBUG) != 0;
+			if (b->kind[k] == 1) update_bam(b->rec[i], R, b->res[i].se, 0, 0, b->opt.mode, b->opt.max_top2, dbg ? b->max_ent[i] : 0);
 			else {
-				update_bam(b->rec[i], R, b->res[i].se, &b->res[i + 1].se, &b->res[i], b->opt.mode, b->opt.max_top2);
-				update_bam(b->rec[i + 1], R, b->res[i + 1].se, &b->res[i].se, &b->res[i + 1], b->opt.mode, b->opt.max_top2);
+				update_bam(b->rec[i], R, b->res[i].se, &b->res[i + 1].se, &b->res[i], b->opt.mode, b->opt.max_top2, dbg ? b->max_ent[i] : 0);
+				update_bam(b->rec[i + 1], R, b->res[i + 1].se, &b->res[i].se, &b->res[i + 1], b->opt.mode, b->opt.max_top2, dbg ? b->max_ent[i + 1] : 0);
 			}
 		}
 	});
@@ -630,17 +678,28 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	return NABWA_OK;
 }
 
-/* the records as they now are (after create: cleaned; after pass 2: aligned), in logical-record order */
+/* the records as they now are (after create: cleaned; after pass 2: aligned), in logical-record order; with NABWA_BAM_ONLY_ALIGNED
+ * without the logical records a read of which is flagged unmapped (pair_print_bam, bam2bam.c:911-925); out_off then has one more
+ * entry than records were written, and the rest of its n_rec + 1 entries repeat the end */
 extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes)
 {
 	if (!b || !n_bytes) return nabwa_fail(NABWA_EINVAL, "null argument");
 	const size_t n = b->rec.size();
+	std::vector<int> pick; pick.reserve(n);
+	for (size_t k = 0; k < b->kind.size(); ++k) {
+		const int i = b->first[k];
+		bool keep = true;
+		if (b->flags & NABWA_BAM_ONLY_ALIGNED) for (int e = 0; e < b->kind[k]; ++e) if (b->rec[i + e].flag & F_SU) keep = false;
+		if (keep) for (int e = 0; e < b->kind[k]; ++e) pick.push_back(i + e);
+	}
+	const size_t m = pick.size();
 	std::vector<int64_t> at(n + 1, 0);
-	for (size_t i = 0; i < n; ++i) at[i + 1] = at[i] + 36 + (int64_t)b->rec[i].data.size();
+	for (size_t t = 0; t < m; ++t) at[t + 1] = at[t] + 36 + (int64_t)b->rec[pick[t]].data.size();
+	for (size_t t = m; t < n; ++t) at[t + 1] = at[m];
 	if (out_off) memcpy(out_off, at.data(), sizeof(int64_t) * (n + 1));
-	*n_bytes = at[n];
-	if (!out || cap < at[n]) return nabwa_fail(NABWA_ECAP, "output buffer too small");
-	bam_parallel(n, [&](int, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) write_rec(b->rec[i], out + at[i]); });
+	*n_bytes = at[m];
+	if (!out || cap < at[m]) return nabwa_fail(NABWA_ECAP, "output buffer too small");
+	bam_parallel(m, [&](int, size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) write_rec(b->rec[pick[t]], out + at[t]); });
 	return NABWA_OK;
 }
 

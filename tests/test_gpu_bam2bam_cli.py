@@ -119,6 +119,124 @@ def test_pairs_and_singletons_in_one_file(tmp_path):
             assert a["pnext"] == b["pos"] and b["pnext"] == a["pos"] and a["tlen"] == -b["tlen"]
 
 
+def test_only_aligned_drops_logical_records_with_an_unmapped_read(tmp_path):
+    """--only-aligned (pair_print_bam, bam2bam.c:910-922): a single read that stays unmapped is not written, and neither is a pair with
+    an unmapped mate -- both of its records go"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:120]
+    singles = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    pairs, n_pairs = pe_records()
+    _, _, full = run(tmp_path, singles + pairs, [])
+    _, _, only = run(tmp_path, singles + pairs, ["--only-aligned"])
+    want = []
+    i = 0
+    while i < len(full):
+        k = 2 if full[i]["flag"] & 1 else 1
+        if not any(r["flag"] & 4 for r in full[i:i + k]):
+            want += full[i:i + k]
+        i += k
+    assert 0 < len(want) < len(full)
+    assert [(r["name"], r["flag"], r["pos"], r["cigar"]) for r in only] == [(r["name"], r["flag"], r["pos"], r["cigar"]) for r in want]
+
+
+def reflag(rec, flag):
+    """the same record with another FLAG"""
+    return rec[:18] + struct.pack("<H", flag) + rec[20:]
+
+
+def core(recs):
+    return [(r["name"], r["flag"], r["rname"], r["pos"], r["mapq"], r["cigar"], r["rnext"], r["pnext"], r["tlen"], r["seq"], r["qual"], r["tags"], r["order"]) for r in recs]
+
+
+def test_debug_bam_adds_the_search_statistic(tmp_path):
+    """--debug-bam (bam2bam.c:433): YQ:i = bwt_match_gap's max_entries of the read, right after XC, left out when it is zero;
+    the value is the oracle's (the reference does not write it anywhere else)"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:200]
+    recs = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    _, _, plain = run(tmp_path, recs, [])
+    _, _, dbg = run(tmp_path, recs, ["--debug-bam"])
+    lib = T.load_oracle()
+    oix = T.OracleIndex(lib)
+    seq, rseq, off, _ = T.encode_reads(reads)
+    _, maxe = T.oracle_cal_sa_reg_gap(lib, oix.h, T.default_opt(), seq, rseq, off, per_read=1, n_threads=8)
+    assert (maxe > 0).any()
+    for g, w, m in zip(dbg, plain, maxe):
+        t = dict(g["tags"])
+        assert t.pop("YQ", 0) == int(m), g["name"]
+        assert t == w["tags"] and [k for k in g["order"] if k != "YQ:i"] == w["order"], g["name"]
+        if m:
+            assert g["order"][1 if "XC:i" in g["order"] else 0] == "YQ:i"
+
+
+def test_skip_duplicates_passes_flagged_records_through(tmp_path):
+    """--skip-duplicates (unique(), bam2bam.c:595-606): a logical record with a duplicate flag is not aligned, draws no random
+    number, adds nothing to the insert sizes and comes out as it came in, less the tags erase_unwanted_tags removes; the other
+    records come out as if the duplicates were not in the file"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:90]
+    singles = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    pairs, n_pairs = pe_records()
+    stale = B.tag_i("NM", 7) + B.tag_z("ZZ", "kept") + B.tag_a("XT", "U")
+    dup_single = B.make_record("dup_single", reads[3][1], reads[3][2], 4 | 1024, stale)
+    n0, s0, q0 = reads[5]
+    dup_pair = [B.make_record("dup_pair", s0, q0, 1 | 4 | 8 | 64), B.make_record("dup_pair", reads[6][1], reads[6][2], 1 | 4 | 8 | 128 | 1024 | 512, stale)]
+    rest = singles[:40] + pairs[:100] + singles[40:] + pairs[100:]
+    mixed = singles[:40] + [dup_single] + pairs[:100] + dup_pair + singles[40:] + pairs[100:] + [dup_single]
+    _, _, want = run(tmp_path, rest, [], env={"NABWA_BAM_BATCH": "64"})
+    _, _, got = run(tmp_path, mixed, ["--skip-duplicates"], env={"NABWA_BAM_BATCH": "64"})
+    dups = [r for r in got if r["name"].startswith("dup_")]
+    assert core([r for r in got if not r["name"].startswith("dup_")]) == core(want)
+    assert [r["name"] for r in got].index("dup_single") == 40 and got[-1]["name"] == "dup_single"
+    assert [(r["name"], r["flag"], r["pos"], r["cigar"], r["tags"]) for r in dups] == [
+        ("dup_single", 4 | 1024, 0, "*", {"ZZ": "kept"}),
+        ("dup_pair", 1 | 4 | 8 | 64 | 512, 0, "*", {}),                       # the QC flag goes over both mates (bwaseqio.c:486-489)
+        ("dup_pair", 1 | 4 | 8 | 128 | 1024 | 512, 0, "*", {"ZZ": "kept"}),
+        ("dup_single", 4 | 1024, 0, "*", {"ZZ": "kept"})]
+    assert dups[0]["seq"] == reads[3][1] and dups[0]["qual"] == reads[3][2]
+    # without the option a duplicate is aligned like any other read
+    _, _, aligned = run(tmp_path, mixed, [])
+    a = [r for r in aligned if r["name"] == "dup_single"][0]
+    assert (a["flag"], a["cigar"], a["tags"].get("ZZ")) == (want[3]["flag"] | 1024, want[3]["cigar"], "kept") and "NM" not in a["order"][:1]
+
+
+def test_drop_aligned_leaves_out_records_that_are_mapped_already(tmp_path):
+    """--drop-aligned (read_bam_pair, bwaseqio.c:466-474): a logical record any read of which lacks the unmapped flag is not
+    read at all; the rest comes out as if it had not been in the file"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:60]
+    singles = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    pairs, n_pairs = pe_records()
+    mapped_single = B.make_record("mapped_single", reads[0][1], reads[0][2], 0)
+    half = [B.make_record("half_mapped", reads[1][1], reads[1][2], 1 | 4 | 64), B.make_record("half_mapped", reads[2][1], reads[2][2], 1 | 8 | 128)]
+    rest = singles[:30] + pairs[:60] + singles[30:]
+    mixed = [mapped_single] + singles[:30] + half + pairs[:60] + [mapped_single] + singles[30:] + half
+    _, _, want = run(tmp_path, rest, [], env={"NABWA_BAM_BATCH": "32"})
+    _, _, got = run(tmp_path, mixed, ["--drop-aligned"], env={"NABWA_BAM_BATCH": "32"})
+    assert core(got) == core(want)
+    _, _, every = run(tmp_path, mixed, [])
+    assert len(every) == len(mixed)
+
+
+def test_broken_input_is_mended_the_way_the_reference_mends_it(tmp_path):
+    """--broken-input (read_bam_pair_core's allow_broken, bwaseqio.c:345-410): two reads of one name with wrong read 1 / read 2 flags
+    become read 1 and read 2 in file order; a paired read followed by another name is discarded, and so is one at the end of the
+    file; without the option each of these ends the run with an error"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:40]
+    singles = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    pairs, n_pairs = pe_records()
+    pairs = [p for i in range(0, 80, 2) for p in (pairs[i:i + 2] if i % 14 != 4 else pairs[i:i + 2][::-1])]     # read 1 first everywhere
+    both_first = [reflag(pairs[10], 1 | 4 | 8 | 64), reflag(pairs[11], 1 | 4 | 8 | 64)]
+    unflagged = [reflag(pairs[12], 1 | 4 | 8), reflag(pairs[13], 4)]                    # the second is not even flagged as paired
+    lone, lone_b = [B.make_record(nm, reads[0][1], reads[0][2], 1 | 4 | 8 | 64) for nm in ("lone_mate", "another_lone_mate")]
+    clean = singles[:20] + pairs[:40] + singles[20:] + pairs[40:]
+    broken = singles[:20] + pairs[:10] + both_first + unflagged + pairs[14:40] + [lone] + singles[20:] + [lone, lone_b] + pairs[40:] + [lone]
+    _, _, want = run(tmp_path, clean, [], env={"NABWA_BAM_BATCH": "16"})
+    _, _, got = run(tmp_path, broken, ["--broken-input"], env={"NABWA_BAM_BATCH": "16"})
+    assert core(got) == core(want)
+    inp = str(tmp_path / "strict.bam")
+    for bad in (both_first, [lone] + singles[:1], singles[:1] + [lone]):
+        write_bam(inp, bad, True)
+        r = subprocess.run([EXE, "-g", T.TOY, "-f", str(tmp_path / "strict_out.bam"), inp], capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and ("lone mate" in r.stderr or "flags are wrong" in r.stderr or "without its mate" in r.stderr), r.stderr[-500:]
+
+
 def test_unsupported_modes_are_refused(tmp_path):
     if not os.path.exists(EXE):
         nabwa.build()
