@@ -15,6 +15,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <sys/time.h>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -75,6 +80,144 @@ struct BgzfOut {
 	}
 };
 
+static double now_s() { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
+static int io_threads() { int nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16; return nt; }
+
+/* ---------------------------------------------------------------- BAM in: the plain bytes of a BGZF file (bgzf.c: independent
+ * gzip members of <= 64 KB that carry their own size in a "BC" extra field -- inflated many at a time, one thread per run of
+ * blocks) or of any other gzip stream (what the reference's bamlite reads through gzread: one inflate stream, member after member) */
+struct BamIn {
+	FILE *f; const char *name; bool bgzf, in_eof, z_open;
+	std::vector<uint8_t> cmp; size_t lo, hi;          /* compressed bytes not yet inflated: cmp[lo, hi) */
+	std::vector<uint8_t> plain; size_t pos;           /* inflated bytes, consumed up to pos */
+	z_stream zs;
+	double t_inflate;
+	struct Blk { size_t src, n_src, dst; uint32_t isize, crc; };
+
+	BamIn(FILE *f_, const char *name_) : f(f_), name(name_), bgzf(false), in_eof(false), z_open(false), lo(0), hi(0), pos(0), t_inflate(0)
+	{
+		cmp.resize((size_t)32 << 20);
+		more_input();
+		size_t total;
+		bgzf = block_at(lo, total) && total != 0;
+		if (!bgzf) {
+			memset(&zs, 0, sizeof(zs));
+			if (inflateInit2(&zs, 15 + 32) != Z_OK) die(name, "inflateInit failed");
+			z_open = true;
+		}
+	}
+	~BamIn() { if (z_open) inflateEnd(&zs); }
+	void more_input()
+	{
+		if (lo && lo == hi) lo = hi = 0;
+		if (lo) { memmove(cmp.data(), cmp.data() + lo, hi - lo); hi -= lo; lo = 0; }
+		while (!in_eof && hi < cmp.size()) {
+			const size_t r = fread(cmp.data() + hi, 1, cmp.size() - hi, f);
+			if (r == 0) { if (ferror(f)) die(name, "read error"); in_eof = true; }
+			hi += r;
+		}
+	}
+	/* is there a BGZF block header at cmp[o]?  total = the block's size (0: the header is not complete yet) */
+	bool block_at(size_t o, size_t &total) const
+	{
+		total = 0;
+		if (hi - o < 12) return hi - o == 0 ? false : (cmp[o] == 31);
+		const uint8_t *h = cmp.data() + o;
+		if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+		const size_t xlen = h[10] | (size_t)h[11] << 8;
+		if (hi - o < 12 + xlen) return true;
+		for (size_t q = 12; q + 4 <= 12 + xlen; ) {
+			const size_t sl = h[q + 2] | (size_t)h[q + 3] << 8;
+			if (h[q] == 'B' && h[q + 1] == 'C' && sl == 2 && q + 6 <= 12 + xlen) { total = (size_t)(h[q + 4] | (size_t)h[q + 5] << 8) + 1; return total >= 12 + xlen + 8; }
+			q += 4 + sl;
+		}
+		return false;
+	}
+	/* more plain bytes behind the unconsumed ones; false when the stream has ended */
+	bool fill()
+	{
+		if (pos) { plain.erase(plain.begin(), plain.begin() + pos); pos = 0; }
+		const double t0 = now_s();
+		bool got = bgzf ? fill_bgzf() : fill_stream();
+		t_inflate += now_s() - t0;
+		return got;
+	}
+	bool fill_bgzf()
+	{
+		for (;;) {
+			std::vector<Blk> blk;
+			size_t o = lo, out = plain.size();
+			while (o < hi) {
+				size_t total;
+				if (!block_at(o, total)) die(name, "not a BGZF block where one should start");
+				if (!total || hi - o < total) break;
+				const size_t xlen = cmp[o + 10] | (size_t)cmp[o + 11] << 8;
+				Blk b; b.src = o + 12 + xlen; b.n_src = total - 12 - xlen - 8; b.dst = out;
+				memcpy(&b.crc, &cmp[o + total - 8], 4); memcpy(&b.isize, &cmp[o + total - 4], 4);
+				if (b.isize > 0x10000) die(name, "a BGZF block of more than 64 KB");
+				out += b.isize; o += total;
+				blk.push_back(b);
+			}
+			if (blk.empty()) {
+				if (in_eof) { if (lo != hi) die(name, "truncated BGZF block"); return false; }
+				more_input();
+				continue;
+			}
+			const size_t before = plain.size();
+			plain.resize(out);
+			int nt = io_threads(); if ((size_t)nt > blk.size()) nt = (int)blk.size();
+			std::vector<int> bad(nt, 0);
+			std::vector<std::thread> th;
+			for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() {
+				z_stream z; memset(&z, 0, sizeof(z));
+				if (inflateInit2(&z, -15) != Z_OK) { bad[t] = 1; return; }
+				for (size_t k = blk.size() * t / nt; k < blk.size() * (t + 1) / nt; ++k) {
+					const Blk &b = blk[k];
+					z.next_in = cmp.data() + b.src; z.avail_in = (uInt)b.n_src; z.next_out = plain.data() + b.dst; z.avail_out = b.isize;
+					const int r = inflate(&z, Z_FINISH);
+					if (r != Z_STREAM_END || z.avail_out != 0 || (uint32_t)crc32(crc32(0, 0, 0), plain.data() + b.dst, b.isize) != b.crc) bad[t] = 1;
+					inflateReset(&z);
+				}
+				inflateEnd(&z);
+			});
+			for (auto &x : th) x.join();
+			for (int x : bad) if (x) die(name, "a BGZF block does not inflate to what its trailer says");
+			lo = o;
+			if (out != before) return true;           /* only empty blocks (the end-of-file marker): look further */
+		}
+	}
+	bool fill_stream()
+	{
+		const size_t STEP = (size_t)16 << 20;
+		const size_t before = plain.size();
+		plain.resize(before + STEP);
+		zs.next_out = plain.data() + before; zs.avail_out = (uInt)STEP;
+		while (zs.avail_out) {
+			if (lo == hi) { more_input(); if (lo == hi) break; }
+			zs.next_in = cmp.data() + lo; zs.avail_in = (uInt)(hi - lo);
+			const int r = inflate(&zs, Z_NO_FLUSH);
+			lo = hi - zs.avail_in;
+			if (r == Z_STREAM_END) { inflateReset(&zs); continue; }          /* the next member, if there is one */
+			if (r != Z_OK && r != Z_BUF_ERROR) die(name, "not a gzip stream, or a damaged one");
+			if (r == Z_BUF_ERROR && zs.avail_in == 0 && in_eof && lo == hi) break;
+		}
+		plain.resize(before + STEP - zs.avail_out);
+		return plain.size() != before;
+	}
+	/* at least n unconsumed bytes if the stream has them; returns how many there are */
+	size_t need(size_t n) { while (plain.size() - pos < n) if (!fill()) break; return plain.size() - pos; }
+	bool read(void *dst, size_t n) { if (need(n) < n) return false; memcpy(dst, plain.data() + pos, n); pos += n; return true; }
+};
+
+/* a bounded queue between two threads */
+template <class T> struct Chan {
+	std::mutex m; std::condition_variable cv; std::deque<T> q; size_t cap; bool closed;
+	explicit Chan(size_t cap_) : cap(cap_), closed(false) {}
+	void put(T &&x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(x)); cv.notify_all(); }
+	bool get(T &x) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; x = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+	void close() { std::unique_lock<std::mutex> l(m); closed = true; cv.notify_all(); }
+};
+
 /* ---------------------------------------------------------------- the header (bam2bam.c:164-301) */
 static void find_pp_tag(const std::string &h, std::string &pp, std::string &id, bool &has_pp)
 {
@@ -119,6 +262,7 @@ static std::string header_text(nabwa_index_t *ix, const std::string &old, int ar
 
 int main(int argc, char **argv)
 {
+	const double t_main = now_s();
 	uint32_t rec_flags = 0;                                    /* NABWA_BAM_*: --only-aligned, --drop-aligned, --debug-bam, --broken-input, --skip-duplicates */
 	static struct option longopts[] = {
 		{ "num-diff", 1, 0, 'n' }, { "max-gap-open", 1, 0, 'o' }, { "max-gap-extensions", 1, 0, 'e' }, { "indel-near-end", 1, 0, 'i' },
@@ -185,17 +329,17 @@ int main(int argc, char **argv)
 	fprintf(stderr, "[nabwa_bam2bam] genome length is %ld\n", (long)genome_len);
 
 	/* ---- input: magic, header text, reference list (bamlite.c: bam_header_read) */
-	gzFile in = strcmp(argv[optind], "-") ? gzopen(argv[optind], "r") : gzdopen(0, "r");
-	if (!in) die(argv[optind], "cannot open");
-	gzbuffer(in, 1 << 20);
-	auto rd = [&](void *p, size_t n) -> bool { return gzread(in, p, (unsigned)n) == (int)n; };
+	FILE *inf = strcmp(argv[optind], "-") ? fopen(argv[optind], "rb") : stdin;
+	if (!inf) die(argv[optind], "cannot open");
+	BamIn in(inf, argv[optind]);
+	auto rd = [&](void *p, size_t n) -> bool { return in.read(p, n); };
 	char magic[4]; int32_t l_text = 0, n_ref = 0;
 	if (!rd(magic, 4) || memcmp(magic, "BAM\1", 4) || !rd(&l_text, 4) || l_text < 0) die(argv[optind], "not a BAM file");
 	std::string old(l_text, '\0');
 	if (l_text && !rd(&old[0], l_text)) die(argv[optind], "truncated header");
 	old.resize(strlen(old.c_str()));
 	if (!rd(&n_ref, 4)) die(argv[optind], "truncated header");
-	for (int i = 0; i < n_ref; ++i) { int32_t ln, tl; if (!rd(&ln, 4)) die(argv[optind], "truncated header"); std::vector<char> nm(ln); if (!rd(nm.data(), ln) || !rd(&tl, 4)) die(argv[optind], "truncated header"); }
+	for (int i = 0; i < n_ref; ++i) { int32_t ln, tl; if (!rd(&ln, 4) || ln < 0) die(argv[optind], "truncated header"); std::vector<char> nm(ln); if (!rd(nm.data(), ln) || !rd(&tl, 4)) die(argv[optind], "truncated header"); }
 
 	FILE *of = ofile ? fopen(ofile, "wb") : stdout;
 	if (!of) die(ofile, "cannot create");
@@ -207,66 +351,126 @@ int main(int argc, char **argv)
 		for (int i = 0; i < ns; ++i) { char name[1024]; int64_t off; int32_t len; nabwa_index_contig(ix, i, name, sizeof name, &off, &len); const int32_t nl = (int32_t)strlen(name) + 1; out.write(&nl, 4); out.write(name, nl); out.write(&len, 4); }
 	}
 
-	/* ---- pass 1 over batches of records (mates stay together); single-end batches are finished and written at once */
+	/* ---- a pipeline of threads: one reads and inflates the input and cuts it into batches of records (mates stay together), one
+	 * parses them (create), this one runs the passes, one collects the output records, one deflates and writes.  Pass 1 over the batches in input order; single-end batches are
+	 * finished and written at once */
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double t_loop = now_s();
 	nabwa_isize_table_t *tab = nabwa_isize_table_create(po.ap_prior, genome_len);
 	uint64_t rng = ((uint64_t)seed << 16) | 0x330E;            /* srand48(bns->seed), bam2bam.c:1745 */
 	const long BATCH = getenv("NABWA_BAM_BATCH") ? atol(getenv("NABWA_BAM_BATCH")) : (1L << 20);
+	struct InBatch { std::vector<uint8_t> buf; std::vector<int64_t> off; };
+	Chan<InBatch> in_ch(2);
+	struct OutBytes { std::unique_ptr<uint8_t[]> p; size_t n; };      /* no zero fill: the library writes every byte */
+	Chan<OutBytes> out_ch(2);
+	double t_read = 0, t_write = 0, t_wait_in = 0, t_lib = 0, t_wait_out = 0, t_call[5] = { 0, 0, 0, 0, 0 };      /* create, pass 1, pass 2, output, destroy */
+	std::thread reader([&]() {
+		const double t0 = now_s();
+		InBatch cur; cur.off.assign(1, 0);
+		bool hold_mate = false;                                   /* the last record is a paired read that waits for the record after it */
+		size_t held_at = 0;                                       /* where it starts in buf */
+		double t_blocked = 0;
+		auto hand_over = [&]() {
+			if (cur.off.size() > 1) { const double tb = now_s(); in_ch.put(std::move(cur)); t_blocked += now_s() - tb; }
+			cur = InBatch(); cur.off.assign(1, 0);
+		};
+		for (;;) {
+			if (in.need(4) == 0) break;
+			uint32_t bs = 0;
+			if (!in.read(&bs, 4) || bs < 32) die(argv[optind], "truncated record");
+			std::vector<uint8_t> &buf = cur.buf;
+			const size_t at = buf.size();
+			if (buf.capacity() < at + 4 + bs) buf.reserve(buf.capacity() ? 2 * buf.capacity() + 4 + bs : (size_t)256 << 20);
+			buf.resize(at + 4 + bs); memcpy(&buf[at], &bs, 4);
+			if (!in.read(&buf[at + 4], bs)) die(argv[optind], "truncated record");
+			uint32_t z; memcpy(&z, &buf[at + 16], 4);
+			const bool paired = (z >> 16) & 1;
+			cur.off.push_back((int64_t)buf.size());
+			/* read_bam_pair_core's view of the stream (bwaseqio.c:345-410): a paired read takes the next record as its mate if the names
+			 * agree; if they do not it is a lone mate (an error, or dropped with --broken-input) and the next record starts afresh */
+			const bool mates = hold_mate && !strcmp((const char*)&buf[held_at + 36], (const char*)&buf[at + 36]);
+			hold_mate = mates ? false : paired;
+			held_at = at;
+			if ((long)cur.off.size() - 1 >= BATCH && !hold_mate) hand_over();
+		}
+		hand_over();
+		in_ch.close();
+		t_read = now_s() - t0 - t_blocked;
+	});
+	std::thread writer([&]() {
+		OutBytes o;
+		while (out_ch.get(o)) { const double t0 = now_s(); out.write(o.p.get(), o.n); o.p.reset(); t_write += now_s() - t0; }
+	});
+	/* create (host work only) runs a batch ahead of the passes, output + destroy (host work only) a batch behind: everything that
+	 * touches the GPU or draws random numbers stays on this thread, in input order */
+	Chan<nabwa_bam_batch_t*> made_ch(1), done_ch(1);
+	std::thread creator([&]() {
+		InBatch ib;
+		while (in_ch.get(ib)) {
+			const double t0 = now_s();
+			nabwa_bam_batch_t *b = 0;
+			if (nabwa_bam_batch_create_ex(ix, &go, &po, rec_flags, (int)ib.off.size() - 1, ib.buf.data(), ib.off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
+			std::vector<uint8_t>().swap(ib.buf);
+			t_call[0] += now_s() - t0;
+			made_ch.put(std::move(b));
+		}
+		made_ch.close();
+	});
+	auto emit = [&](nabwa_bam_batch_t *b) {
+		int64_t nb = 0;
+		const double ta = now_s();
+		nabwa_bam_batch_output(b, 0, 0, 0, &nb);
+		OutBytes o; o.p.reset(new uint8_t[(size_t)(nb ? nb : 1)]); o.n = (size_t)nb;
+		if (nabwa_bam_batch_output(b, o.p.get(), nb, 0, &nb) != NABWA_OK) die("output", nabwa_last_error());
+		const double tb = now_s();
+		nabwa_bam_batch_destroy(b);
+		const double t0 = now_s();
+		t_call[3] += tb - ta; t_call[4] += t0 - tb;
+		out_ch.put(std::move(o));
+		t_wait_out += now_s() - t0;
+	};
+	std::thread finisher([&]() { nabwa_bam_batch_t *b; while (done_ch.get(b)) emit(b); });
 	std::vector<nabwa_bam_batch_t*> waiting;
 	uint64_t n_tot[2] = { 0, 0 }, n_mapped[2] = { 0, 0 };
 	long tot_seqs = 0; bool any_pairs = false;
-	auto emit = [&](nabwa_bam_batch_t *b) {
-		int64_t nb = 0;
-		nabwa_bam_batch_output(b, 0, 0, 0, &nb);
-		std::vector<uint8_t> o((size_t)(nb ? nb : 1));
-		if (nabwa_bam_batch_output(b, o.data(), nb, 0, &nb) != NABWA_OK) die("output", nabwa_last_error());
-		out.write(o.data(), (size_t)nb);
-		nabwa_bam_batch_destroy(b);
-	};
-	std::vector<uint8_t> buf; std::vector<int64_t> off(1, 0);
-	bool hold_mate = false;                                   /* the last record is a paired read that waits for the record after it */
-	size_t held_at = 0;                                       /* where it starts in buf */
-	auto flush = [&]() {
-		const long n_rec = (long)off.size() - 1;
-		if (n_rec <= 0) return;
+	for (;;) {
 		nabwa_bam_batch_t *b = 0;
-		if (nabwa_bam_batch_create_ex(ix, &go, &po, rec_flags, (int)n_rec, buf.data(), off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
+		const double t0 = now_s();
+		if (!made_ch.get(b)) break;
+		const double t1 = now_s();
+		t_wait_in += t1 - t0;
 		if (nabwa_bam_batch_pass1(b, &rng, tab) != NABWA_OK) die("pass 1", nabwa_last_error());
+		const double td = now_s();
+		t_call[1] += td - t1;
 		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
+		any_pairs |= nr != nl;
 		tot_seqs += nr;
 		fprintf(stderr, "[nabwa_bam2bam] pass 1: %ld sequences processed\n", tot_seqs);
 		/* a batch of singletons needs no insert-size estimate: it is finished now, and written now unless pairs came before it */
 		if (nr == nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
-		if (nr == nl && !any_pairs) emit(b); else waiting.push_back(b);
-		buf.clear(); off.assign(1, 0);
-	};
-	for (;;) {
-		uint32_t bs = 0;
-		const int r = gzread(in, &bs, 4);
-		if (r == 0) break;
-		if (r != 4 || bs < 32) die(argv[optind], "truncated record");
-		const size_t at = buf.size();
-		buf.resize(at + 4 + bs); memcpy(&buf[at], &bs, 4);
-		if (!rd(&buf[at + 4], bs)) die(argv[optind], "truncated record");
-		uint32_t z; memcpy(&z, &buf[at + 16], 4);
-		const bool paired = (z >> 16) & 1;
-		off.push_back((int64_t)buf.size());
-		/* read_bam_pair_core's view of the stream (bwaseqio.c:345-410): a paired read takes the next record as its mate if the names
-		 * agree; if they do not it is a lone mate (an error, or dropped with --broken-input) and the next record starts afresh */
-		const bool mates = hold_mate && !strcmp((const char*)&buf[held_at + 36], (const char*)&buf[at + 36]);
-		hold_mate = mates ? false : paired;
-		held_at = at;
-		any_pairs |= paired;
-		if ((long)off.size() - 1 >= BATCH && !hold_mate) flush();
+		const double t2 = now_s();
+		if (nr == nl) t_call[2] += t2 - td;
+		if (nr == nl && !any_pairs) done_ch.put(std::move(b)); else waiting.push_back(b);
+		t_lib += t2 - t1;
 	}
-	flush();
-	gzclose(in);
+	reader.join(); creator.join();
+	if (inf != stdin) fclose(inf);
+	done_ch.close(); finisher.join();
 	/* ---- the barrier (infer_all_isizes), then pass 2 in input order */
 	nabwa_isize_table_infer_all(tab);
 	for (nabwa_bam_batch_t *b : waiting) {
+		const double t1 = now_s();
 		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
 		if (nr != nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
+		t_lib += now_s() - t1; t_call[2] += now_s() - t1;
 		emit(b);
 	}
+	out_ch.close();
+	writer.join();
+	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: start-up (device, index, headers) %.3f s, records %.3f s\n", t_loop - t_main, now_s() - t_loop);
+	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: library calls: create %.3f s, pass 1 %.3f s, pass 2 %.3f s, output %.3f s, destroy %.3f s\n", t_call[0], t_call[1], t_call[2], t_call[3], t_call[4]);
+	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: reader thread %.3f s busy (%.3f s of it inflate, %s), passes 1 and 2 on this thread %.3f s (+ %.3f s waiting for input; the output thread waited %.3f s for the writer), writer thread %.3f s busy (deflate + write)\n",
+						t_read, in.t_inflate, in.bgzf ? "BGZF blocks in parallel" : "one gzip stream", t_lib, t_wait_in, t_wait_out, t_write);
 	fprintf(stderr, "[nabwa_bam2bam] %ld sequences processed\n[nabwa_bam2bam] finished cleanly, shutting down.\n"
 			"[bwa_paired_sw] %lld out of %lld Q%d singletons are mated.\n[bwa_paired_sw] %lld out of %lld Q%d discordant pairs are fixed.\n",
 			tot_seqs, (long long)n_mapped[1], (long long)n_tot[1], 17, (long long)n_mapped[0], (long long)n_tot[0], 17);

@@ -161,16 +161,49 @@ extern "C" int nabwa_isize_table_decode(nabwa_isize_table_t *t, const uint8_t *i
 
 /* ------------------------------------------------------------------ BAM records */
 
+/* The bytes of one record.  They start out in the batch's arena, with room for what pass 2 adds (a million records = one
+ * allocation, not a million), and move to the heap only if they outgrow that room. */
+struct RecBuf {
+	uint8_t *p; uint32_t n, cap; bool heap;
+	RecBuf() : p(0), n(0), cap(0), heap(false) {}
+	~RecBuf() { if (heap) free(p); }
+	RecBuf(const RecBuf&) = delete;
+	RecBuf &operator=(const RecBuf&) = delete;
+	RecBuf(RecBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), heap(o.heap) { o.p = 0; o.n = o.cap = 0; o.heap = false; }
+	RecBuf &operator=(RecBuf &&o) noexcept
+	{
+		if (this != &o) { if (heap) free(p); p = o.p; n = o.n; cap = o.cap; heap = o.heap; o.p = 0; o.n = o.cap = 0; o.heap = false; }
+		return *this;
+	}
+	uint8_t *data() { return p; }
+	const uint8_t *data() const { return p; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	void place(uint8_t *at, size_t room, const uint8_t *src, size_t len) { if (heap) free(p); p = at; cap = (uint32_t)room; heap = false; n = (uint32_t)len; if (len) memcpy(p, src, len); }
+	void grow(size_t need)
+	{
+		const size_t nc = need > 2 * (size_t)cap + 64 ? need : 2 * (size_t)cap + 64;
+		uint8_t *q = (uint8_t*)malloc(nc);
+		if (!q) throw std::bad_alloc();
+		if (n) memcpy(q, p, n);
+		if (heap) free(p);
+		p = q; cap = (uint32_t)nc; heap = true;
+	}
+	void resize(size_t m) { if (m > cap) grow(m); n = (uint32_t)m; }
+	void append(const void *b, size_t len) { if ((size_t)n + len > cap) grow((size_t)n + len); memcpy(p + n, b, len); n += (uint32_t)len; }
+};
+#define REC_ROOM 160u              /* bytes of room behind a record for the tags and the CIGAR pass 2 adds */
+
 struct BamRec {                    /* one record, parsed: offsets are into `data` (everything after the 32 bytes of core) */
 	int32_t tid, pos; uint32_t bin, mapq, l_qname, flag, n_cigar; int32_t l_qseq, mtid, mpos, isize;
-	std::vector<uint8_t> data;     /* qname, cigar, seq, qual, tags */
+	RecBuf data;                   /* qname, cigar, seq, qual, tags */
 	size_t off_cigar() const { return l_qname; }
 	size_t off_seq() const { return l_qname + 4 * (size_t)n_cigar; }
 	size_t off_qual() const { return off_seq() + ((size_t)l_qseq + 1) / 2; }
 	size_t off_aux() const { return off_qual() + (size_t)l_qseq; }
 };
 
-static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r)
+static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r, uint8_t *room)       /* room: len - 36 + REC_ROOM bytes of the arena */
 {
 	if (len < 36) return false;
 	uint32_t bs; memcpy(&bs, p, 4);
@@ -179,8 +212,7 @@ static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r)
 	memcpy(&r.tid, p + 4, 4); memcpy(&r.pos, p + 8, 4); memcpy(&y, p + 12, 4); memcpy(&z, p + 16, 4);
 	memcpy(&r.l_qseq, p + 20, 4); memcpy(&r.mtid, p + 24, 4); memcpy(&r.mpos, p + 28, 4); memcpy(&r.isize, p + 32, 4);
 	r.bin = y >> 16; r.mapq = y >> 8 & 0xff; r.l_qname = y & 0xff; r.flag = z >> 16; r.n_cigar = z & 0xffff;
-	r.data.reserve((size_t)(len - 36) + 160);      /* room for the tags and the CIGAR pass 2 adds: no regrowth there */
-	r.data.assign(p + 36, p + len);
+	r.data.place(room, (size_t)(len - 36) + REC_ROOM, p + 36, (size_t)(len - 36));
 	if (r.l_qseq < 0 || r.off_aux() > r.data.size() || r.l_qname == 0) return false;
 	return true;
 }
@@ -278,9 +310,9 @@ static inline uint32_t reg2bin(uint32_t beg, uint32_t end)      /* bam_reg2bin (
 	return 0;
 }
 
-static void push_int(BamRec &r, char u, char v, int x) { const uint8_t b[7] = { (uint8_t)u, (uint8_t)v, 'i', (uint8_t)x, (uint8_t)(x >> 8), (uint8_t)(x >> 16), (uint8_t)(x >> 24) }; r.data.insert(r.data.end(), b, b + 7); }
-static void push_char(BamRec &r, char u, char v, char c) { const uint8_t b[4] = { (uint8_t)u, (uint8_t)v, 'A', (uint8_t)c }; r.data.insert(r.data.end(), b, b + 4); }
-static void push_str(BamRec &r, char u, char v, const char *s) { const uint8_t b[3] = { (uint8_t)u, (uint8_t)v, 'Z' }; r.data.insert(r.data.end(), b, b + 3); r.data.insert(r.data.end(), (const uint8_t*)s, (const uint8_t*)s + strlen(s) + 1); }
+static void push_int(BamRec &r, char u, char v, int x) { const uint8_t b[7] = { (uint8_t)u, (uint8_t)v, 'i', (uint8_t)x, (uint8_t)(x >> 8), (uint8_t)(x >> 16), (uint8_t)(x >> 24) }; r.data.append(b, 7); }
+static void push_char(BamRec &r, char u, char v, char c) { const uint8_t b[4] = { (uint8_t)u, (uint8_t)v, 'A', (uint8_t)c }; r.data.append(b, 4); }
+static void push_str(BamRec &r, char u, char v, const char *s) { const uint8_t b[3] = { (uint8_t)u, (uint8_t)v, 'Z' }; r.data.append(b, 3); r.data.append(s, strlen(s) + 1); }
 
 static void set_cigar(BamRec &r, int n, const uint32_t *c)       /* bam_resize_cigar + the copy (bam2bam.c:411-420,467-477) */
 {
@@ -401,6 +433,7 @@ static void res_give(void *p, size_t bytes)
 
 struct nabwa_bam_batch {
 	nabwa_index *ix; nabwa_gap_opt_t opt; nabwa_pe_opt_t popt;
+	uint8_t *arena; size_t arena_bytes;            /* where the records' bytes live (pooled like res); declared before rec: it outlives the records */
 	std::vector<BamRec> rec;                       /* in logical-record order: singletons, and pairs as read 1, read 2 */
 	std::vector<int> kind;                         /* per logical record: 1 or 2 */
 	std::vector<int> first;                        /* per logical record: index of its first read */
@@ -412,8 +445,8 @@ struct nabwa_bam_batch {
 	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
 	size_t res_bytes;
-	nabwa_bam_batch() : flags(0), res(0), phase(0), res_bytes(0) {}
-	~nabwa_bam_batch() { res_give(res, res_bytes); }
+	nabwa_bam_batch() : arena(0), arena_bytes(0), flags(0), res(0), phase(0), res_bytes(0) {}
+	~nabwa_bam_batch() { res_give(res, res_bytes); rec.clear(); res_give(arena, arena_bytes); }
 };
 
 static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };      /* bam_nt16_nt4_table (bwaseqio.c:10) */
@@ -436,9 +469,14 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 	const double tc0 = bam_now();
 	b->rec.resize(n_rec);
 	{
+		for (int i = 0; i < n_rec; ++i) if (in_off[i + 1] - in_off[i] < 36 || in_off[i + 1] - in_off[i] > (int64_t)1 << 28) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
+		b->arena_bytes = (size_t)(n_rec ? in_off[n_rec] - in_off[0] : 0) + (size_t)n_rec * (REC_ROOM - 36) + 64;
+		b->arena = (uint8_t*)res_take(b->arena_bytes);
+		if (!b->arena) { b->arena_bytes = 0; delete b; return nabwa_fail(NABWA_ENOMEM, "out of memory for the records"); }
 		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
 		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) {
-			for (size_t i = lo; i < hi; ++i) if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i])) bad[t] = 1;
+			for (size_t i = lo; i < hi; ++i)
+				if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i], b->arena + (in_off[i] - in_off[0]) + i * (size_t)(REC_ROOM - 36))) bad[t] = 1;
 		});
 		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
 	}

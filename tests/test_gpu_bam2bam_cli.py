@@ -23,7 +23,15 @@ OLD_HEADER = "@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:stale\tLN:5\n@RG\tID:lib1\tSM:x\
 def write_bam(path, records, bgzf):
     text = OLD_HEADER.encode()
     raw = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 6) + b"stale\0" + struct.pack("<i", 5) + b"".join(records)
-    if bgzf:                                      # several gzip members, as BGZF is
+    if bgzf == "blocks":                          # true BGZF: members of <= 0xff00 bytes that carry their size in a BC extra field
+        import zlib
+        with open(path, "wb") as f:
+            for o in range(0, len(raw), 0xff00):
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                d = c.compress(raw[o:o + 0xff00]) + c.flush()
+                f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(raw[o:o + 0xff00]), min(0xff00, len(raw) - o)))
+            f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    elif bgzf:                                    # several gzip members without that field
         with open(path, "wb") as f:
             for o in range(0, len(raw), 40000):
                 f.write(gzip.compress(raw[o:o + 40000], 1))
@@ -136,6 +144,23 @@ def test_only_aligned_drops_logical_records_with_an_unmapped_read(tmp_path):
         i += k
     assert 0 < len(want) < len(full)
     assert [(r["name"], r["flag"], r["pos"], r["cigar"]) for r in only] == [(r["name"], r["flag"], r["pos"], r["cigar"]) for r in want]
+
+
+def test_bgzf_blocks_are_inflated_in_parallel_and_damage_is_noticed(tmp_path):
+    """a true BGZF file (blocks with the BC field: inflated several at a time), the same bytes as members without the field and as
+    one gzip stream give the same records; a block cut short or with a wrong checksum ends the run"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    recs = [B.make_record(n, s, q, 4, B.tag_z("ZZ", "x" * 300)) for n, s, q in reads] * 3          # 500 KB: several blocks
+    outs = [core(run(tmp_path, recs, [], bgzf=kind, env={"NABWA_BAM_BATCH": "700"})[2]) for kind in ("blocks", True, False)]
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == len(recs)
+    inp = str(tmp_path / "in.bam")
+    write_bam(inp, recs, "blocks")
+    raw = open(inp, "rb").read()
+    for name, damaged in (("cut", raw[:len(raw) // 2]), ("flip", raw[:30000] + bytes([raw[30000] ^ 0x55]) + raw[30001:])):
+        bad = str(tmp_path / (name + ".bam"))
+        open(bad, "wb").write(damaged)
+        r = subprocess.run([EXE, "-g", T.TOY, "-f", str(tmp_path / "bad_out.bam"), bad], capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and ("BGZF" in r.stderr or "truncated" in r.stderr), r.stderr[-500:]
 
 
 def reflag(rec, flag):
