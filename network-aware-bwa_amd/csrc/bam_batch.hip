@@ -82,16 +82,14 @@ extern "C" void nabwa_isize_table_destroy(nabwa_isize_table_t *t) { delete t; }
 
 /* improve_isize_est (insert_size.c:141-165): one logical record's contribution.  The 16-bit bins wrap as the reference's do
  * (its "hit the ceiling" test compares an unsigned short with -1 and never fires). */
-static void isize_add(nabwa_isize_table *t, const std::string &rg, int bin)
+static nabwa_isize_table::Rg *isize_slot(nabwa_isize_table *t, const std::string &rg)       /* the read group's entry, made on first use */
 {
-	if (bin < 0) return;
 	auto it = t->rg.find(rg);
 	if (it == t->rg.end()) {
 		nabwa_isize_table::Rg r; memset(&r.ii, 0, sizeof(r.ii)); r.hist.assign(100000, 0); r.has_hist = true;
 		it = t->rg.emplace(rg, std::move(r)).first;
 	}
-	if (!it->second.has_hist) return;
-	it->second.hist[bin] = (uint16_t)(it->second.hist[bin] + 1);
+	return &it->second;
 }
 
 /* infer_all_isizes (insert_size.c:167-173): every read group that still has its histogram gets its estimate */
@@ -256,13 +254,13 @@ static bool erase_tags(BamRec &r)
 }
 
 /* bam_get_rg (bamlite.c:157-190): the read group of a record, "" when it has none */
-static std::string get_rg(const BamRec &r)
+static std::pair<const uint8_t*, size_t> get_rg(const BamRec &r)       /* a view into the record */
 {
 	size_t p = r.off_aux(); const size_t end = r.data.size(); const uint8_t *d = r.data.data();
 	while (p + 4 < end) {
 		if (d[p] == 'R' && d[p + 1] == 'G') {
-			if (d[p + 2] == 'Z') return std::string((const char*)d + p + 3, strnlen((const char*)d + p + 3, end - p - 3));
-			if (d[p + 2] == 'A') return std::string(1, (char)d[p + 3]);
+			if (d[p + 2] == 'Z') return { d + p + 3, strnlen((const char*)d + p + 3, end - p - 3) };
+			if (d[p + 2] == 'A') return { d + p + 3, (size_t)1 };
 		}
 		switch (d[p + 2]) {
 			case 'A': case 'C': case 'c': p += 4; break;
@@ -271,15 +269,15 @@ static std::string get_rg(const BamRec &r)
 			case 'd': p += 11; break;
 			case 'Z': case 'H': p += 3; while (p < end && d[p]) ++p; ++p; break;
 			case 'B': {
-				if (p + 8 > end) return "";
+				if (p + 8 > end) return { d, (size_t)0 };
 				const size_t count = (size_t)d[p + 4] | (size_t)d[p + 5] << 8 | (size_t)d[p + 6] << 16 | (size_t)d[p + 7] << 24;
 				size_t w = 1; switch (d[p + 3]) { case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; case 'd': w = 8; break; }
 				p += 8 + w * count; break;
 			}
-			default: return "";
+			default: return { d, (size_t)0 };
 		}
 	}
-	return "";
+	return { d, (size_t)0 };
 }
 
 static inline int nib4(uint8_t v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }   /* complement of a 4-bit base code = its bits reversed */
@@ -437,7 +435,8 @@ struct nabwa_bam_batch {
 	std::vector<BamRec> rec;                       /* in logical-record order: singletons, and pairs as read 1, read 2 */
 	std::vector<int> kind;                         /* per logical record: 1 or 2 */
 	std::vector<int> first;                        /* per logical record: index of its first read */
-	std::vector<std::string> rg;                   /* per logical record */
+	std::vector<int> rg;                           /* per logical record: its read group, an index into rg_names */
+	std::vector<std::string> rg_names;
 	std::vector<uint8_t> skip;                     /* per logical record: a flagged duplicate that passes through untouched (--skip-duplicates; unique(), bam2bam.c:595-606) */
 	uint32_t flags;                                /* NABWA_BAM_* */
 	std::vector<int64_t> off; RawBytes seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
@@ -488,7 +487,7 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 	 * (read_bam_pair's ignore_aligned, bwaseqio.c:466-474) leaves out logical records any read of which is already mapped. */
 	{
 		const bool broken = (flags & NABWA_BAM_BROKEN_INPUT) != 0, drop = (flags & NABWA_BAM_DROP_ALIGNED) != 0, nodup = (flags & NABWA_BAM_SKIP_DUPLICATES) != 0;
-		std::vector<int> src; src.reserve(n_rec);
+		std::vector<int> src; src.reserve(n_rec); b->kind.reserve(n_rec); b->first.reserve(n_rec); b->skip.reserve(n_rec);
 		for (int i = 0; i < n_rec; ) {
 			BamRec &r0 = b->rec[i];
 			int k = 1;
@@ -525,12 +524,26 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 			n_rec = (int)src.size();
 		}
 	}
+	const double tc1a = bam_now();
 	{
 		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
 		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (!erase_tags(b->rec[i])) bad[t] = 1; });
 		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed tags in a BAM record"); }
 	}
-	for (size_t k = 0; k < b->kind.size(); ++k) b->rg.push_back(get_rg(b->rec[b->first[k]]));
+	const double tc1b = bam_now();
+	{
+		const size_t nk = b->kind.size();
+		std::vector<std::pair<const uint8_t*, size_t>> view(nk);
+		bam_parallel(nk, [&](int, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) view[k] = get_rg(b->rec[b->first[k]]); });
+		b->rg.resize(nk);
+		std::map<std::string, int> ids;
+		for (size_t k = 0; k < nk; ++k) {
+			if (k && view[k].second == view[k - 1].second && !memcmp(view[k].first, view[k - 1].first, view[k].second)) { b->rg[k] = b->rg[k - 1]; continue; }
+			auto ins = ids.emplace(std::string((const char*)view[k].first, view[k].second), (int)b->rg_names.size());
+			if (ins.second) b->rg_names.push_back(ins.first->first);
+			b->rg[k] = ins.first->second;
+		}
+	}
 	const double tc2 = bam_now();
 	/* bam1_to_seq (bwaseqio.c:272-307): the (trimmed) lengths first, then every thread encodes its slice of the reads in place */
 	b->off.assign(n_rec + 1, 0); b->full_len.assign(n_rec ? n_rec : 1, 0);
@@ -579,8 +592,8 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 		});
 		b->seq.data()[b->off[n_rec]] = 0; b->rseq.data()[b->off[n_rec]] = 0;
 	}
-	if (timing) fprintf(stderr, "[nabwa] bam_batch_create %d records: parse %.3f s, pairing + tag erase + read groups %.3f s, bam1_to_seq %.3f s (%d threads)\n",
-						n_rec, tc1 - tc0, tc2 - tc1, bam_now() - tc2, bam_threads((size_t)n_rec));
+	if (timing) fprintf(stderr, "[nabwa] bam_batch_create %d records: parse %.3f s, pairing %.3f s, tag erase %.3f s, read groups %.3f s, bam1_to_seq %.3f s (%d threads)\n",
+						n_rec, tc1 - tc0, tc1a - tc1, tc1b - tc1a, tc2 - tc1b, bam_now() - tc2, bam_threads((size_t)n_rec));
 	*out = b;
 	return NABWA_OK;
 }
@@ -631,13 +644,26 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	bam_parallel((size_t)n, [&](int, size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) { nabwa_pe_t &r = b->res[i]; r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.mapQ_paired = 0; r.m_rpos = 0; r.isize = 0; }
 	});
-	/* improve_isize_est (insert_size.c:141-165) */
-	for (size_t k = 0; k < b->kind.size(); ++k) {
-		const int i = b->first[k];
-		if (b->skip[k]) continue;
-		const nabwa_se_t &s0 = b->res[i].se;
-		const nabwa_se_t &s1 = b->kind[k] == 2 ? b->res[i + 1].se : s0;
-		isize_add(tab, b->rg[k], nabwa_isize_bin(b->kind[k], s0.mapQ, s1.mapQ, s0.pos, s0.len, s1.pos, s1.len));
+	/* improve_isize_est (insert_size.c:141-165): the bins by many threads, the counts in record order */
+	{
+		const size_t nk = b->kind.size();
+		std::vector<int> bin(nk ? nk : 1, -1);
+		bam_parallel(nk, [&](int, size_t lo, size_t hi) {
+			for (size_t k = lo; k < hi; ++k) {
+				if (b->skip[k]) continue;
+				const int i = b->first[k];
+				const nabwa_se_t &s0 = b->res[i].se;
+				const nabwa_se_t &s1 = b->kind[k] == 2 ? b->res[i + 1].se : s0;
+				bin[k] = nabwa_isize_bin(b->kind[k], s0.mapQ, s1.mapQ, s0.pos, s0.len, s1.pos, s1.len);
+			}
+		});
+		std::vector<nabwa_isize_table::Rg*> slot(b->rg_names.size(), (nabwa_isize_table::Rg*)0);
+		for (size_t k = 0; k < nk; ++k) {
+			if (bin[k] < 0) continue;
+			nabwa_isize_table::Rg *&r = slot[b->rg[k]];
+			if (!r) r = isize_slot(tab, b->rg_names[b->rg[k]]);
+			if (r->has_hist) r->hist[bin[k]] = (uint16_t)(r->hist[bin[k]] + 1);
+		}
 	}
 	b->phase = 1;
 	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass1 %d records: search (upload, kernels, rows back) %.3f s, posn + insert-size bins %.3f s\n", n, tp1 - tp0, bam_now() - tp1);
@@ -676,7 +702,7 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	/* ---- pairs, one read group at a time with that group's estimate (pass 2 draws no random numbers: its order is free) */
 	{
 		std::map<std::string, std::vector<int>> groups;
-		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2 && !b->skip[k]) groups[b->rg[k]].push_back(b->first[k]);
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2 && !b->skip[k]) groups[b->rg_names[b->rg[k]]].push_back(b->first[k]);
 		for (auto &g : groups) {
 			nabwa_isize_t ii;
 			nabwa_isize_table_get(tab, g.first.c_str(), &ii);
