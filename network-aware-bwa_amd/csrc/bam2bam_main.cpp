@@ -16,6 +16,7 @@
 #include <string.h>
 #include <zlib.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -28,7 +29,8 @@
 
 static const char *VERSION = "0.5.10-evan.6.3+nabwa";
 
-static void die(const char *what, const char *why) { fprintf(stderr, "[nabwa_bam2bam] %s: %s\n", what, why); exit(1); }
+/* any thread of the pipeline may end the run: no exit handlers (they would tear the GPU runtime down under the other threads) */
+static void die(const char *what, const char *why) { fprintf(stderr, "[nabwa_bam2bam] %s: %s\n", what, why); fflush(stderr); _exit(1); }
 
 /* ---------------------------------------------------------------- BGZF out (bgzf.c: blocks of <= 0xff00 input bytes, level 2) */
 static void bgzf_block(const uint8_t *in, size_t n, int level, std::vector<uint8_t> &out)

@@ -443,6 +443,7 @@ struct nabwa_bam_batch {
 	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
 	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
+	std::vector<uint8_t> parked; std::vector<uint64_t> parked_at;     /* what pass 1 left in res, packed, while a batch with pairs waits for pass 2 */
 	size_t res_bytes;
 	nabwa_bam_batch() : arena(0), arena_bytes(0), flags(0), res(0), phase(0), res_bytes(0) {}
 	~nabwa_bam_batch() { res_give(res, res_bytes); rec.clear(); res_give(arena, arena_bytes); }
@@ -600,6 +601,47 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 
 extern "C" void nabwa_bam_batch_destroy(nabwa_bam_batch_t *b) { delete b; }
 
+/* A batch with pairs waits between the passes for the insert-size estimates of the whole input, and of its 3 KB per read pass 1
+ * has filled some 70 bytes (the scalar head and, for singletons, the heads of the other hits).  These are packed and the block
+ * goes back to the pool until pass 2 asks for it again: a file of 20 M paired reads waits in 1.4 GB instead of 64 GB. */
+#define PARK_HEAD offsetof(nabwa_se_t, cigar)
+#define PARK_MULTI offsetof(nabwa_multi_t, cigar)
+static void park(nabwa_bam_batch *b)
+{
+	const size_t n = b->rec.size();
+	b->parked_at.assign(n + 1, 0);
+	for (size_t i = 0; i < n; ++i) b->parked_at[i + 1] = b->parked_at[i] + PARK_HEAD + 4 + PARK_MULTI * (size_t)b->res[i].se.n_multi;
+	b->parked.resize(b->parked_at[n] ? b->parked_at[n] : 1);
+	bam_parallel(n, [&](int, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const nabwa_se_t &s = b->res[i].se;
+			uint8_t *o = b->parked.data() + b->parked_at[i];
+			memcpy(o, &s, PARK_HEAD); memcpy(o + PARK_HEAD, &s.n_multi, 4);
+			for (int j = 0; j < s.n_multi; ++j) memcpy(o + PARK_HEAD + 4 + PARK_MULTI * (size_t)j, &s.multi[j], PARK_MULTI);
+		}
+	});
+	res_give(b->res, b->res_bytes);
+	b->res = 0;
+}
+static bool unpark(nabwa_bam_batch *b)
+{
+	const size_t n = b->rec.size();
+	b->res = (nabwa_pe_t*)res_take(b->res_bytes);
+	if (!b->res) return false;
+	bam_parallel(n, [&](int, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			nabwa_pe_t &r = b->res[i]; nabwa_se_t &s = r.se;
+			const uint8_t *o = b->parked.data() + b->parked_at[i];
+			memcpy(&s, o, PARK_HEAD); memcpy(&s.n_multi, o + PARK_HEAD, 4);
+			for (int j = 0; j < s.n_multi; ++j) memcpy(&s.multi[j], o + PARK_HEAD + 4 + PARK_MULTI * (size_t)j, PARK_MULTI);
+			s.nm = 0; s.md[0] = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;          /* as nabwa_se_posn leaves them */
+			r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.mapQ_paired = 0; r.m_rpos = 0; r.isize = 0;
+		}
+	});
+	std::vector<uint8_t>().swap(b->parked); std::vector<uint64_t>().swap(b->parked_at);
+	return true;
+}
+
 /* pass 1: pair_aln + pair_posn + improve_isize_est of every logical record (bam2bam.c:1143-1176) */
 extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab)
 {
@@ -665,6 +707,7 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 			if (r->has_hist) r->hist[bin[k]] = (uint16_t)(r->hist[bin[k]] + 1);
 		}
 	}
+	if (b->kind.size() != b->rec.size()) park(b);
 	b->phase = 1;
 	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass1 %d records: search (upload, kernels, rows back) %.3f s, posn + insert-size bins %.3f s\n", n, tp1 - tp0, bam_now() - tp1);
 	return NABWA_OK;
@@ -678,6 +721,7 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	const nabwa_reference *R = b->ix->ref;
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	const double tq0 = bam_now();
+	if (!b->res && !unpark(b)) return nabwa_fail(NABWA_ENOMEM, "out of memory for the batch's records");
 	/* ---- singletons: bwa_refine_gapped + what bwa_update_bam1 derives */
 	{
 		std::vector<int> idx;
@@ -738,6 +782,8 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 		}
 	});
 	b->phase = 2;
+	/* the records are complete: the 3 KB per read that led to them go back to the pool (a batch may wait long for its turn to be written) */
+	res_give(b->res, b->res_bytes); b->res = 0;
 	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass2 %zu records: finishing chains %.3f s, bwa_update_bam1 %.3f s\n", b->rec.size(), tq1 - tq0, bam_now() - tq1);
 	return NABWA_OK;
 }

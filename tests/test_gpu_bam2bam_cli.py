@@ -118,6 +118,10 @@ def test_pairs_and_singletons_in_one_file(tmp_path):
     assert len(out) == 100 + 2 * n_pairs
     assert [o["name"] for o in out[:50]] == [r[0] for r in reads] == [o["name"] for o in out[-50:]]
     assert all(o["flag"] & 1 for o in out[50:-50]) and not any(o["flag"] & 1 for o in out[:50])
+    # the first singletons share their batch with pairs: that batch waits for pass 2 with its pass-1 state packed away, and they
+    # must come out of it as they come out of a file of singletons (same random stream up to there, other hits and all)
+    _, _, alone = run(tmp_path, singles, [])
+    assert core(out[:50]) == core(alone) and any("XA" in o["tags"] for o in alone)
     # the pairs: same answers as one library batch under bam2bam's own estimate (tests/test_gpu_bam.py pins that route);
     # here: mates are consistent with each other
     for i in range(50, 50 + 2 * n_pairs, 2):
