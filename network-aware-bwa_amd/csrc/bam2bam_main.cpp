@@ -457,16 +457,16 @@ int main(int argc, char **argv)
 	}
 	reader.join(); creator.join();
 	if (inf != stdin) fclose(inf);
-	done_ch.close(); finisher.join();
-	/* ---- the barrier (infer_all_isizes), then pass 2 in input order */
+	/* ---- the barrier (infer_all_isizes), then pass 2 in input order; the output thread collects a batch while the next is finished */
 	nabwa_isize_table_infer_all(tab);
 	for (nabwa_bam_batch_t *b : waiting) {
 		const double t1 = now_s();
 		int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
 		if (nr != nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
 		t_lib += now_s() - t1; t_call[2] += now_s() - t1;
-		emit(b);
+		done_ch.put(std::move(b));
 	}
+	done_ch.close(); finisher.join();
 	out_ch.close();
 	writer.join();
 	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: start-up (device, index, headers) %.3f s, records %.3f s\n", t_loop - t_main, now_s() - t_loop);

@@ -713,6 +713,23 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	return NABWA_OK;
 }
 
+/* one working record to another: the scalars, and of the arrays what their counts say is filled */
+static void copy_filled(nabwa_pe_t &d, const nabwa_pe_t &r)
+{
+	const nabwa_se_t &s = r.se; nabwa_se_t &o = d.se;
+	memcpy(&o, &s, offsetof(nabwa_se_t, cigar));
+	if (s.n_cigar > 0) memcpy(o.cigar, s.cigar, sizeof(uint16_t) * (size_t)(s.n_cigar < NABWA_MAX_CIGAR ? s.n_cigar : NABWA_MAX_CIGAR));
+	o.nm = s.nm;
+	memcpy(o.md, s.md, strnlen(s.md, NABWA_MAX_MD - 1) + 1);
+	o.n_multi = s.n_multi;
+	for (int j = 0; j < s.n_multi && j < NABWA_MAX_MULTI; ++j) {
+		memcpy(&o.multi[j], &s.multi[j], offsetof(nabwa_multi_t, cigar));
+		if (s.multi[j].n_cigar > 0) memcpy(o.multi[j].cigar, s.multi[j].cigar, sizeof(uint16_t) * (size_t)(s.multi[j].n_cigar < NABWA_MAX_CIGAR ? s.multi[j].n_cigar : NABWA_MAX_CIGAR));
+	}
+	o.flag = s.flag; o.seqid = s.seqid; o.nn = s.nn; o.rpos = s.rpos; o.xt = s.xt;
+	d.extra_flag = r.extra_flag; d.m_seqid = r.m_seqid; d.am = r.am; d.mapQ_paired = r.mapQ_paired; d.m_rpos = r.m_rpos; d.isize = r.isize;
+}
+
 /* pass 2: pair_finish of every logical record (bam2bam.c:1178-1216, 643-658, 705-811) */
 extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2])
 {
@@ -752,19 +769,37 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 			nabwa_isize_table_get(tab, g.first.c_str(), &ii);
 			const std::vector<int> &idx = g.second;
 			const int np = (int)idx.size();
-			std::vector<int64_t> off(2 * (size_t)np + 1, 0); std::vector<uint8_t> sq, rq; std::vector<nabwa_pe_t> pe(2 * (size_t)np);
-			std::vector<int32_t> na(2 * (size_t)np); std::vector<nabwa_aln1_t> rows;
-			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) {
-				const int i = idx[t] + e; const int64_t L = b->off[i + 1] - b->off[i];
-				sq.insert(sq.end(), b->seq.begin() + b->off[i], b->seq.begin() + b->off[i] + L);
-				rq.insert(rq.end(), b->rseq.begin() + b->off[i], b->rseq.begin() + b->off[i] + L);
-				off[2 * t + e + 1] = off[2 * t + e] + L; memcpy(&pe[2 * t + e], &b->res[i], sizeof(nabwa_pe_t)); na[2 * t + e] = b->n_aln[i];
-				rows.insert(rows.end(), b->rows.begin() + b->row0[i], b->rows.begin() + b->row0[i + 1]);
+			if (2 * (size_t)np == b->rec.size()) {           /* the whole batch is pairs of this one group: in place */
+				int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, b->off.data(), b->seq.data(), b->rseq.data(), b->n_aln.data(), b->rows.data(), b->res, n_tot, n_mapped);
+				if (rc != NABWA_OK) return rc;
+				continue;
 			}
-			sq.push_back(0); rq.push_back(0); rows.push_back(nabwa_aln1_t());
-			int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows.data(), pe.data(), n_tot, n_mapped);
+			/* otherwise the group's reads are gathered, by all threads; of a 3 KB record only what is filled travels */
+			const size_t nr = 2 * (size_t)np;
+			std::vector<int64_t> off(nr + 1, 0), r0(nr + 1, 0); std::vector<int32_t> na(nr);
+			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) {
+				const int i = idx[t] + e; const size_t q = 2 * (size_t)t + e;
+				off[q + 1] = off[q] + (b->off[i + 1] - b->off[i]); na[q] = b->n_aln[i]; r0[q + 1] = r0[q] + b->n_aln[i];
+			}
+			RawBytes sq, rq, rowb;
+			const size_t pe_bytes = sizeof(nabwa_pe_t) * nr;
+			nabwa_pe_t *pe = (nabwa_pe_t*)res_take(pe_bytes);
+			if (!pe || !sq.alloc((size_t)off[nr] + 1) || !rq.alloc((size_t)off[nr] + 1) || !rowb.alloc(sizeof(nabwa_aln1_t) * ((size_t)r0[nr] + 1))) { res_give(pe, pe_bytes); return nabwa_fail(NABWA_ENOMEM, "out of memory for a read group's pairs"); }
+			nabwa_aln1_t *rows = (nabwa_aln1_t*)rowb.data();
+			bam_parallel(nr, [&](int, size_t lo, size_t hi) {
+				for (size_t q = lo; q < hi; ++q) {
+					const int i = idx[q >> 1] + (int)(q & 1);
+					memcpy(sq.data() + off[q], b->seq.data() + b->off[i], (size_t)(off[q + 1] - off[q]));
+					memcpy(rq.data() + off[q], b->rseq.data() + b->off[i], (size_t)(off[q + 1] - off[q]));
+					if (na[q]) memcpy(rows + r0[q], b->rows.data() + b->row0[i], sizeof(nabwa_aln1_t) * (size_t)na[q]);
+					copy_filled(pe[q], b->res[i]);
+				}
+			});
+			sq.data()[off[nr]] = 0; rq.data()[off[nr]] = 0; memset(&rows[r0[nr]], 0, sizeof(nabwa_aln1_t));
+			int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows, pe, n_tot, n_mapped);
+			if (rc == NABWA_OK) bam_parallel(nr, [&](int, size_t lo, size_t hi) { for (size_t q = lo; q < hi; ++q) copy_filled(b->res[idx[q >> 1] + (int)(q & 1)], pe[q]); });
+			res_give(pe, pe_bytes);
 			if (rc != NABWA_OK) return rc;
-			for (int t = 0; t < np; ++t) for (int e = 0; e < 2; ++e) memcpy(&b->res[idx[t] + e], &pe[2 * t + e], sizeof(nabwa_pe_t));
 		}
 	}
 	/* ---- bwa_update_bam1 */

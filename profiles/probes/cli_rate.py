@@ -6,6 +6,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+PAIRED = os.environ.get("CLI_RATE_PAIRED") == "1"        # reads 2k and 2k+1 are mates: same name, 300 bp apart, second one reverse-complemented
 OUT = sys.argv[2] if len(sys.argv) > 2 else "/tmp/cli_rate"
 os.makedirs(OUT, exist_ok=True)
 
@@ -33,8 +34,13 @@ def main():
     g16 = code[g]
     rng = np.random.default_rng(7)
     L = 100
-    start = rng.integers(0, len(g16) - L, N)
+    start = rng.integers(0, len(g16) - L - 400, N)
+    if PAIRED:
+        start[1::2] = start[0::2] + 300 + rng.integers(-30, 30, N // 2)
     reads = g16[start[:, None] + np.arange(L)[None, :]]
+    if PAIRED:
+        comp = np.zeros(16, np.uint8); comp[[1, 2, 4, 8, 15]] = [8, 4, 2, 1, 15]
+        reads[1::2] = comp[reads[1::2, ::-1]]
     sub = rng.random((N, L)) < 0.01
     reads[sub] = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, int(sub.sum()))]
     rec_len = 36 + 10 + L // 2 + L
@@ -42,7 +48,10 @@ def main():
     rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec_len - 4), np.uint8)
     rec[:, 4:36] = np.frombuffer(struct.pack("<iiIIiiii", -1, -1, (4680 << 16) | 10, 4 << 16, L, -1, -1, 0), np.uint8)
     rec[:, 36] = ord("r")
-    rec[:, 37:45] = np.frombuffer("".join(np.char.zfill(np.arange(N).astype("U8"), 8)).encode(), np.uint8).reshape(N, 8)
+    ids = np.arange(N) // 2 * 2 if PAIRED else np.arange(N)
+    rec[:, 37:45] = np.frombuffer("".join(np.char.zfill(ids.astype("U8"), 8)).encode(), np.uint8).reshape(N, 8)
+    if PAIRED:
+        rec[0::2, 18] = 1 | 4 | 8 | 64; rec[1::2, 18] = 1 | 4 | 8 | 128
     rec[:, 46:46 + L // 2] = (reads[:, 0::2] << 4) | reads[:, 1::2]
     rec[:, 46 + L // 2:] = 40
     text = b"@HD\tVN:1.0\n"
@@ -76,7 +85,7 @@ def main():
     while p < len(body):
         bs, = struct.unpack_from("<I", body, p)
         if cnt % 100000 == 0:
-            assert body[p + 36:p + 45] == b"r%08d" % cnt, (cnt, body[p + 36:p + 46])
+            assert body[p + 36:p + 45] == b"r%08d" % (cnt // 2 * 2 if PAIRED else cnt), (cnt, body[p + 36:p + 46])
         mapped += not (struct.unpack_from("<I", body, p + 16)[0] >> 16 & 4)
         p += 4 + bs; cnt += 1
     print("output records: %d (%d mapped)" % (cnt, mapped))
