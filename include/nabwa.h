@@ -336,6 +336,10 @@ int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const 
 #define NABWA_BAM_ALL_FLAGS       31u
 int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, uint32_t flags, int n_rec,
 							  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out);
+/* optional, before pass 1 and from any thread: the FM search of the batch (the part of pass 1 that needs neither the random stream
+ * nor the batches before it) on the GPU of the index the batch was created with; pass 1 then goes on from its rows.  This is how
+ * one process keeps several GPUs busy: batches are dealt to index replicas, searched as they come, and passed in input order. */
+int nabwa_bam_batch_search(nabwa_bam_batch_t *b);
 int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab);
 int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2]);
 int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes);

@@ -8,7 +8,8 @@
 // lines kept; bam2bam.c:164-301).  Host code only; the GPU work is the library's.  Not provided: the 0MQ master / worker modes
 // (-p, `bwa worker`: libzmq is absent from the build image) and resuming from .sai files (-0 -1 -2) -- each is refused, none is
 // silently ignored.  --only-aligned, --drop-aligned, --skip-duplicates, --broken-input and --debug-bam are the library's NABWA_BAM_* flags.
-// -t is accepted and ignored (one GPU; NABWA_DEVICE picks it), --temp-dir likewise (the records wait in memory between the passes).
+// -t is accepted and ignored (NABWA_DEVICES=0,1,... names the GPUs: an index replica on each, batches dealt to them in turn, searched as
+// they come and passed in input order; default one GPU, NABWA_DEVICE or 0), --temp-dir likewise (the records wait in memory between the passes).
 #include <getopt.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -323,9 +324,21 @@ int main(int argc, char **argv)
 		fprintf(stderr, "\nUsage:   nabwa_bam2bam -g PREFIX [options of bwa bam2bam] [-f out.bam] <in.bam>\n\n");
 		return 1;
 	}
-	const int device = getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0;
-	nabwa_index_t *ix = 0;
-	if (nabwa_index_load(prefix, device, 1, 1, &ix) != NABWA_OK) die("genome index", nabwa_last_error());
+	/* one index replica per GPU of NABWA_DEVICES ("0,1,2,3"; default: NABWA_DEVICE or 0); batches are dealt to them in turn */
+	std::vector<int> devices;
+	if (getenv("NABWA_DEVICES"))
+		for (const char *q = getenv("NABWA_DEVICES"); *q; ) { char *e; const long d = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)d); q = *e == ',' ? e + 1 : e; }
+	if (devices.empty()) devices.push_back(getenv("NABWA_DEVICE") ? atoi(getenv("NABWA_DEVICE")) : 0);
+	std::vector<nabwa_index_t*> ixs(devices.size(), (nabwa_index_t*)0);
+	{
+		std::vector<std::string> err(devices.size());
+		std::vector<std::thread> th;
+		for (size_t g = 0; g < devices.size(); ++g)
+			th.emplace_back([&, g]() { if (nabwa_index_load(prefix, devices[g], 1, 1, &ixs[g]) != NABWA_OK) { err[g] = nabwa_last_error(); ixs[g] = 0; } });
+		for (auto &x : th) x.join();
+		for (size_t g = 0; g < devices.size(); ++g) if (!ixs[g]) die("genome index", err[g].c_str());
+	}
+	nabwa_index_t *ix = ixs[0];
 	int64_t genome_len = 0; uint32_t seed = 0;
 	nabwa_index_reference_info(ix, &genome_len, &seed);
 	fprintf(stderr, "[nabwa_bam2bam] genome length is %ld\n", (long)genome_len);
@@ -405,19 +418,37 @@ int main(int argc, char **argv)
 	});
 	/* create (host work only) runs a batch ahead of the passes, output + destroy (host work only) a batch behind: everything that
 	 * touches the GPU or draws random numbers stays on this thread, in input order */
-	Chan<nabwa_bam_batch_t*> made_ch(1), done_ch(1);
+	const size_t n_dev = ixs.size();
+	Chan<nabwa_bam_batch_t*> done_ch(1);
+	std::vector<std::unique_ptr<Chan<nabwa_bam_batch_t*>>> made_ch, found_ch;       /* per GPU: parsed batches, searched batches */
+	for (size_t g = 0; g < n_dev; ++g) { made_ch.emplace_back(new Chan<nabwa_bam_batch_t*>(1)); found_ch.emplace_back(new Chan<nabwa_bam_batch_t*>(1)); }
 	std::thread creator([&]() {
 		InBatch ib;
-		while (in_ch.get(ib)) {
+		for (size_t k = 0; in_ch.get(ib); ++k) {
 			const double t0 = now_s();
 			nabwa_bam_batch_t *b = 0;
-			if (nabwa_bam_batch_create_ex(ix, &go, &po, rec_flags, (int)ib.off.size() - 1, ib.buf.data(), ib.off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
+			if (nabwa_bam_batch_create_ex(ixs[k % n_dev], &go, &po, rec_flags, (int)ib.off.size() - 1, ib.buf.data(), ib.off.data(), &b) != NABWA_OK) die("input records", nabwa_last_error());
 			std::vector<uint8_t>().swap(ib.buf);
 			t_call[0] += now_s() - t0;
-			made_ch.put(std::move(b));
+			made_ch[k % n_dev]->put(std::move(b));
 		}
-		made_ch.close();
+		for (auto &c : made_ch) c->close();
 	});
+	/* one thread per GPU searches that GPU's batches as they come (no random numbers, no order: the kernels of batch k + 1 run
+	 * while batch k is positioned and finished); the main thread takes the searched batches in input order */
+	std::vector<double> t_search(n_dev, 0.0);
+	std::vector<std::thread> searchers;
+	for (size_t g = 0; g < n_dev; ++g)
+		searchers.emplace_back([&, g]() {
+			nabwa_bam_batch_t *b;
+			while (made_ch[g]->get(b)) {
+				const double t0 = now_s();
+				if (nabwa_bam_batch_search(b) != NABWA_OK) die("search", nabwa_last_error());
+				t_search[g] += now_s() - t0;
+				found_ch[g]->put(std::move(b));
+			}
+			found_ch[g]->close();
+		});
 	auto emit = [&](nabwa_bam_batch_t *b) {
 		int64_t nb = 0;
 		const double ta = now_s();
@@ -435,10 +466,10 @@ int main(int argc, char **argv)
 	std::vector<nabwa_bam_batch_t*> waiting;
 	uint64_t n_tot[2] = { 0, 0 }, n_mapped[2] = { 0, 0 };
 	long tot_seqs = 0; bool any_pairs = false;
-	for (;;) {
+	for (size_t k = 0; ; ++k) {
 		nabwa_bam_batch_t *b = 0;
 		const double t0 = now_s();
-		if (!made_ch.get(b)) break;
+		if (!found_ch[k % n_dev]->get(b)) break;
 		const double t1 = now_s();
 		t_wait_in += t1 - t0;
 		if (nabwa_bam_batch_pass1(b, &rng, tab) != NABWA_OK) die("pass 1", nabwa_last_error());
@@ -456,6 +487,7 @@ int main(int argc, char **argv)
 		t_lib += t2 - t1;
 	}
 	reader.join(); creator.join();
+	for (auto &x : searchers) x.join();
 	if (inf != stdin) fclose(inf);
 	/* ---- the barrier (infer_all_isizes), then pass 2 in input order; the output thread collects a batch while the next is finished */
 	nabwa_isize_table_infer_all(tab);
@@ -470,6 +502,7 @@ int main(int argc, char **argv)
 	out_ch.close();
 	writer.join();
 	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: start-up (device, index, headers) %.3f s, records %.3f s\n", t_loop - t_main, now_s() - t_loop);
+	if (timing) { double ts = 0; for (double x : t_search) ts += x; fprintf(stderr, "[nabwa_bam2bam] timing: search threads (%zu GPU%s) %.3f s busy\n", n_dev, n_dev > 1 ? "s" : "", ts); }
 	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: library calls: create %.3f s, pass 1 %.3f s, pass 2 %.3f s, output %.3f s, destroy %.3f s\n", t_call[0], t_call[1], t_call[2], t_call[3], t_call[4]);
 	if (timing) fprintf(stderr, "[nabwa_bam2bam] timing: reader thread %.3f s busy (%.3f s of it inflate, %s), passes 1 and 2 on this thread %.3f s (+ %.3f s waiting for input; the output thread waited %.3f s for the writer), writer thread %.3f s busy (deflate + write)\n",
 						t_read, in.t_inflate, in.bgzf ? "BGZF blocks in parallel" : "one gzip stream", t_lib, t_wait_in, t_wait_out, t_write);
@@ -478,7 +511,7 @@ int main(int argc, char **argv)
 			tot_seqs, (long long)n_mapped[1], (long long)n_tot[1], 17, (long long)n_mapped[0], (long long)n_tot[0], 17);
 	out.close();
 	nabwa_isize_table_destroy(tab);
-	nabwa_index_destroy(ix);
+	for (nabwa_index_t *p : ixs) nabwa_index_destroy(p);
 	/* final_rename (utils.c:159-173): "out.bam_" becomes "out.bam" once it is complete */
 	if (ofile) { const size_t l = strlen(ofile); if (l > 1 && ofile[l - 1] == '_') { std::string to(ofile, l - 1); if (rename(ofile, to.c_str()) != 0) die(ofile, "cannot rename"); } }
 	return 0;

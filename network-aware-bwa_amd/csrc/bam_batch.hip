@@ -443,9 +443,10 @@ struct nabwa_bam_batch {
 	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
 	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
+	bool searched;                                 /* nabwa_bam_batch_search ran */
 	std::vector<uint8_t> parked; std::vector<uint64_t> parked_at;     /* what pass 1 left in res, packed, while a batch with pairs waits for pass 2 */
 	size_t res_bytes;
-	nabwa_bam_batch() : arena(0), arena_bytes(0), flags(0), res(0), phase(0), res_bytes(0) {}
+	nabwa_bam_batch() : arena(0), arena_bytes(0), flags(0), res(0), phase(0), searched(false), res_bytes(0) {}
 	~nabwa_bam_batch() { res_give(res, res_bytes); rec.clear(); res_give(arena, arena_bytes); }
 };
 
@@ -642,34 +643,43 @@ static bool unpark(nabwa_bam_batch *b)
 	return true;
 }
 
+/* the FM search of the batch's reads: the part of pass 1 that needs neither the random stream nor the other batches, so a caller
+ * may run it ahead, from another thread and on the batch's own GPU, while pass 1 and pass 2 of earlier batches go on
+ * (bwa_cal_sa_reg_gap is called with one read at a time in the reference, bam2bam.c:616,676 -> per_read = 1) */
+extern "C" int nabwa_bam_batch_search(nabwa_bam_batch_t *b)
+{
+	if (!b) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (b->phase != 0 || b->searched) return nabwa_fail(NABWA_EINVAL, "the batch has been searched already");
+	const int n = (int)b->rec.size();
+	b->n_aln.assign(n ? n : 1, 0); b->max_ent.assign(n ? n : 1, 0); b->row0.assign(n + 1, 0);
+	int64_t n_rows = 0;
+	nabwa_batch_t *sb = 0;
+	int rc = nabwa_batch_create(b->ix, &b->opt, n, b->off.data(), b->seq.data(), b->rseq.data(), 1, &sb);
+	if (rc != NABWA_OK) return rc;
+	rc = nabwa_batch_run(sb);
+	if (rc == NABWA_OK) rc = nabwa_batch_sync(sb, 0);
+	if (rc == NABWA_OK) {
+		rc = nabwa_batch_fetch(sb, b->n_aln.data(), 0, 0, &n_rows, b->max_ent.data());
+		if (rc == NABWA_ECAP || rc == NABWA_OK) {
+			b->rows.resize(n_rows ? (size_t)n_rows : 1);
+			rc = n_rows ? nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data()) : NABWA_OK;
+		}
+	}
+	nabwa_batch_destroy(sb);
+	if (rc == NABWA_OK) b->searched = true;
+	return rc;
+}
+
 /* pass 1: pair_aln + pair_posn + improve_isize_est of every logical record (bam2bam.c:1143-1176) */
 extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab)
 {
 	if (!b || !rng48 || !tab) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (b->phase != 0) return nabwa_fail(NABWA_EINVAL, "pass 1 already ran on this batch");
 	const int n = (int)b->rec.size();
-	b->n_aln.assign(n ? n : 1, 0); b->max_ent.assign(n ? n : 1, 0); b->row0.assign(n + 1, 0);
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	const double tp0 = bam_now();
-	/* bwa_cal_sa_reg_gap, one read per call in the reference (bam2bam.c:616,676) -> per_read = 1 */
-	int64_t n_rows = 0;
-	int rc;
-	{
-		nabwa_batch_t *sb = 0;
-		rc = nabwa_batch_create(b->ix, &b->opt, n, b->off.data(), b->seq.data(), b->rseq.data(), 1, &sb);
-		if (rc != NABWA_OK) return rc;
-		rc = nabwa_batch_run(sb);
-		if (rc == NABWA_OK) rc = nabwa_batch_sync(sb, 0);
-		if (rc == NABWA_OK) {
-			rc = nabwa_batch_fetch(sb, b->n_aln.data(), 0, 0, &n_rows, b->max_ent.data());
-			if (rc == NABWA_ECAP || rc == NABWA_OK) {
-				b->rows.resize(n_rows ? (size_t)n_rows : 1);
-				rc = n_rows ? nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data()) : NABWA_OK;
-			}
-		}
-		nabwa_batch_destroy(sb);
-		if (rc != NABWA_OK) return rc;
-	}
+	int rc = b->searched ? NABWA_OK : nabwa_bam_batch_search(b);
+	if (rc != NABWA_OK) return rc;
 	for (int i = 0; i < n; ++i) b->row0[i + 1] = b->row0[i] + b->n_aln[i];
 	for (size_t k = 0; k < b->kind.size(); ++k) if (b->skip[k]) for (int e = 0; e < b->kind[k]; ++e)
 		if (b->n_aln[b->first[k] + e]) return nabwa_fail(NABWA_EINVAL, "internal: a read without bases came back with hits");

@@ -167,6 +167,21 @@ def test_bgzf_blocks_are_inflated_in_parallel_and_damage_is_noticed(tmp_path):
         assert r.returncode != 0 and ("BGZF" in r.stderr or "truncated" in r.stderr), r.stderr[-500:]
 
 
+def test_two_index_replicas_take_the_batches_in_turn(tmp_path):
+    """NABWA_DEVICES names the GPUs (here GPU 0 twice: two replicas, two search threads): batches are dealt to them in turn and
+    searched as they come, pass 1 and pass 2 still see them in input order on one random stream -- the records do not change"""
+    reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
+    singles = [B.make_record(n, s, q, 4) for n, s, q in reads]
+    pairs, n_pairs = pe_records()
+    recs = singles[:300] + pairs + singles[300:]
+    opts = ["-n", "0.01", "-o", "2", "-l", "16500"]
+    _, _, one = run(tmp_path, recs, opts, env={"NABWA_BAM_BATCH": "96"})
+    _, _, two = run(tmp_path, recs, opts, env={"NABWA_BAM_BATCH": "96", "NABWA_DEVICES": "0,0"})
+    assert core(two) == core(one) and len(one) == len(recs)
+    sam = T.parse_sam(os.path.join(T.GOLDEN, "se_adna.sam"))
+    check_se(two[:300], sam[:300])
+
+
 def reflag(rec, flag):
     """the same record with another FLAG"""
     return rec[:18] + struct.pack("<H", flag) + rec[20:]
