@@ -161,6 +161,40 @@ def test_pe_bam_records_match_the_reference_sam():
     ix.close()
 
 
+def test_pairs_of_two_read_groups_each_under_its_own_estimate():
+    """pairs of two read groups interleaved in one batch: pass 2 gathers each group's pairs and finishes them under that group's
+    estimate (finish_pair looks it up by bam_get_rg, bam2bam.c:712-715).  Group "a" gets the estimate `sampe` made, group "b" none:
+    every pair must come out as in a run of its own kind (pass 1 and its random stream do not depend on the group)"""
+    L = bind()
+    opt, _ = T.read_sai(os.path.join(T.GOLDEN, "pe_1.sai"))
+    v = np.load(os.path.join(T.GOLDEN, "vectors_pe_chain.npz"))
+    ix = nabwa.Index.load(T.TOY, 0, True, True)
+    fq = [T.read_fastq(os.path.join(T.GOLDEN, "reads_pe_%d.fq" % e)) for e in (1, 2)]
+
+    def records(rg_of):
+        recs = []
+        for i in range(len(fq[0])):
+            a, b = fq[0][i], fq[1][i]
+            name = a[0][:-2] if a[0].endswith("/1") else a[0]
+            tag = B.tag_z("RG", rg_of(i))
+            recs += [B.make_record(name, a[1], a[2], 1 | 4 | 8 | 64, tag), B.make_record(name, b[1], b[2], 1 | 4 | 8 | 128, tag)]
+        return recs
+
+    iv = v["ii_sampe"]
+    est = bytes(nabwa.IsizeInfo(iv[0], iv[1], iv[2], int(iv[3]), int(iv[4]), int(iv[5])))
+    blob = np.frombuffer(b"a\0" + bytes(8) + est + b"b\0" + bytes(8) + bytes(nabwa.IsizeInfo()), np.uint8).copy()
+    fields = lambda out: [(r["name"], r["flag"], r["rname"], r["pos"], r["mapq"], r["cigar"], r["rnext"], r["pnext"], r["tlen"],
+                           {k: x for k, x in r["tags"].items() if k != "RG"}) for r in out]
+    all_a = fields(run_batches(L, ix, opt, [records(lambda i: "a")], table_blob=blob)[0])
+    all_b = fields(run_batches(L, ix, opt, [records(lambda i: "b")], table_blob=blob)[0])
+    mixed = fields(run_batches(L, ix, opt, [records(lambda i: "ab"[i % 2])], table_blob=blob)[0])
+    assert sum(x != y for x, y in zip(all_a, all_b)) > 20                      # the estimate matters
+    for i in range(len(fq[0])):
+        want = all_a if i % 2 == 0 else all_b
+        assert mixed[2 * i:2 * i + 2] == want[2 * i:2 * i + 2], i
+    ix.close()
+
+
 def test_isize_table_blob_and_merge():
     L = bind()
     a, b = P(L.nabwa_isize_table_create(1e-5, 100000)), P(L.nabwa_isize_table_create(1e-5, 100000))
