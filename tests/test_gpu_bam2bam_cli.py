@@ -31,6 +31,8 @@ def write_bam(path, records, bgzf):
                 d = c.compress(raw[o:o + 0xff00]) + c.flush()
                 f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(raw[o:o + 0xff00]), min(0xff00, len(raw) - o)))
             f.write(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    elif bgzf == "plain":                         # not compressed at all: gzread hands such a file through as it is, and so does the reader here
+        open(path, "wb").write(raw)
     elif bgzf:                                    # several gzip members without that field
         with open(path, "wb") as f:
             for o in range(0, len(raw), 40000):
@@ -155,8 +157,8 @@ def test_bgzf_blocks_are_inflated_in_parallel_and_damage_is_noticed(tmp_path):
     one gzip stream give the same records; a block cut short or with a wrong checksum ends the run"""
     reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))
     recs = [B.make_record(n, s, q, 4, B.tag_z("ZZ", "x" * 300)) for n, s, q in reads] * 3          # 500 KB: several blocks
-    outs = [core(run(tmp_path, recs, [], bgzf=kind, env={"NABWA_BAM_BATCH": "700"})[2]) for kind in ("blocks", True, False)]
-    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == len(recs)
+    outs = [core(run(tmp_path, recs, [], bgzf=kind, env={"NABWA_BAM_BATCH": "700"})[2]) for kind in ("blocks", True, False, "plain")]
+    assert outs[0] == outs[1] == outs[2] == outs[3] and len(outs[0]) == len(recs)
     inp = str(tmp_path / "in.bam")
     write_bam(inp, recs, "blocks")
     raw = open(inp, "rb").read()
