@@ -206,25 +206,30 @@ struct Batch {                      /* what one GPU call (or a few) consumes */
 /* BAM records as bwa_read_bam takes them (bwaseqio.c:125-168 over bamlite.c:73-155): any gzip container (BGZF is a
  * series of gzip members; the reference opens BAM with gzopen as well, bamlite.h:7-11), header skipped, then per record the
  * flag, the 4-bit bases and the qualities.  `which`: 1 = first reads of pairs, 2 = second reads, 4 = unpaired (bwtaln.c:167-172). */
+/* a damaged BGZF block ends the run (the reader inflates blocks on several threads: no exit handlers under them) */
+static void die(const char *what, const char *why) { fprintf(stderr, "[nabwa_aln] %s: %s\n", what, why); fflush(stderr); _exit(2); }
+#include "bgzf_in.hpp"
+
 struct BamReader {
-	gzFile fp = nullptr;
+	FILE *file = nullptr;
+	std::unique_ptr<BamIn> fp;              /* BGZF blocks inflated many at a time; any other gzip stream, or none, as gzread takes it */
 	int which = 7;
 	std::vector<unsigned char> rec;
 
-	bool get(void *dst, size_t n) { return n == 0 || gzread(fp, dst, (unsigned)n) == (int)n; }
+	bool get(void *dst, size_t n) { return n == 0 || fp->read(dst, n); }
 	bool skip(size_t n) { unsigned char tmp[4096]; while (n) { const size_t k = n < sizeof tmp ? n : sizeof tmp; if (!get(tmp, k)) return false; n -= k; } return true; }
 	bool open(const char *fn)
 	{
-		fp = strcmp(fn, "-") == 0 ? gzdopen(fileno(stdin), "r") : gzopen(fn, "r");
-		if (!fp) return false;
-		gzbuffer(fp, 1 << 20);
+		file = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
+		if (!file) return false;
+		fp.reset(new BamIn(file, fn));
 		char magic[4]; int32_t l_text = 0, n_ref = 0;
 		if (!get(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { fprintf(stderr, "[nabwa_aln] invalid BAM binary header (this is not a BAM file).\n"); return false; }
 		if (!get(&l_text, 4) || l_text < 0 || !skip((size_t)l_text) || !get(&n_ref, 4) || n_ref < 0) return false;
 		for (int32_t i = 0; i < n_ref; ++i) { int32_t l_name = 0; if (!get(&l_name, 4) || l_name < 0 || !skip((size_t)l_name + 4)) return false; }
 		return true;
 	}
-	void close() { if (fp) gzclose(fp); fp = nullptr; }
+	void close() { fp.reset(); if (file && file != stdin) fclose(file); file = nullptr; }
 	/* the next record that passes the selection: flag, number of bases, pointers to 4-bit bases and qualities; false at the end */
 	bool next(unsigned *flag, int *l_seq, const unsigned char **bases, const unsigned char **qual)
 	{
