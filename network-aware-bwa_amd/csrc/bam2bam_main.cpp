@@ -2,7 +2,7 @@
 //
 //     nabwa_bam2bam -g PREFIX [alignment options of bwa bam2bam] [-f out.bam] in.bam
 //
-// BAM in (BGZF or plain gzip, as the reference's bamlite reads it) -> both passes of the reference's sequential loop
+// BAM in (BGZF, any other gzip stream or none, as the reference's bamlite reads it; bgzf_in.hpp) -> both passes of the reference's sequential loop
 // (bam2bam.c:1143-1216) through the batch front-end of the library (nabwa_bam_batch_*, bam_batch.hip) -> BGZF BAM out with
 // the header bwa_print_bam_header writes (@HD VN:1.4, a new @PG chained to the old one, @SQ from the .ann file, the other old
 // lines kept; bam2bam.c:164-301).  Host code only; the GPU work is the library's.  Not provided: the 0MQ master / worker modes
@@ -240,8 +240,9 @@ int main(int argc, char **argv)
 	}
 
 	/* ---- a pipeline of threads: one reads and inflates the input and cuts it into batches of records (mates stay together), one
-	 * parses them (create), this one runs the passes, one collects the output records, one deflates and writes.  Pass 1 over the batches in input order; single-end batches are
-	 * finished and written at once */
+	 * parses them (create), one per GPU searches them, this one runs pass 1 over the batches in input order (and pass 2 at once
+	 * for a batch of singletons, which is written at once unless pairs came before it), one collects the output records, one
+	 * deflates and writes */
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	const double t_loop = now_s();
 	nabwa_isize_table_t *tab = nabwa_isize_table_create(po.ap_prior, genome_len);
