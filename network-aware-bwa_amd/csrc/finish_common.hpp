@@ -1,6 +1,7 @@
 // finish_common.hpp -- host pieces shared by the single-end and paired-end finishing chains.
 // Records are nabwa_se_t laid out with a caller-given stride (nabwa_pe_t starts with a nabwa_se_t).
 #pragma once
+#include <sys/time.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,6 +23,28 @@ static inline double rng48_next(uint64_t *x)          /* drand48: X' = 0x5DEECE6
 }
 
 static inline int pac_at(const nabwa_reference *R, int64_t k) { return R->pac[k >> 2] >> ((~k & 3) << 1) & 3; }
+
+/* the four bases of a .pac byte as four bytes, the first base lowest: eight reference bases are compared with eight read codes
+ * (one byte each) in one 64-bit XOR -- the MD string of a read that matches costs an eighth of the base-by-base walk */
+struct PacExpand { uint32_t t[256]; PacExpand() { for (int b = 0; b < 256; ++b) t[b] = (uint32_t)(b >> 6 & 3) | (uint32_t)(b >> 4 & 3) << 8 | (uint32_t)(b >> 2 & 3) << 16 | (uint32_t)(b & 3) << 24; } };
+static inline const uint32_t *pac_expand() { static const PacExpand x; return x.t; }
+/* how many of the next n bases (n >= 0) from reference position pos on equal the read codes q[0..] before the first that does
+ * not (an N in the read never equals); pos + n <= l_pac and no .amb hole in the stretch are the caller's */
+static inline int pac_match_run(const nabwa_reference *R, int64_t pos, const uint8_t *q, int n)
+{
+	const uint32_t *const X = pac_expand();
+	int z = 0;
+	while (z < n && ((pos + z) & 3)) { if (pac_at(R, pos + z) != q[z]) return z; ++z; }
+	for (; z + 8 <= n; z += 8) {
+		const uint8_t *pb = R->pac.data() + ((pos + z) >> 2);
+		const uint64_t r = (uint64_t)X[pb[0]] | (uint64_t)X[pb[1]] << 32;
+		uint64_t qq; memcpy(&qq, q + z, 8);
+		const uint64_t x = r ^ qq;
+		if (x) return z + (__builtin_ctzll(x) >> 3);
+	}
+	while (z < n) { if (pac_at(R, pos + z) != q[z]) return z; ++z; }
+	return n;
+}
 
 /* base of the reference at pos with the ambiguity codes of the .amb holes restored (bwase.c:239-251) */
 static inline int ref_char(const nabwa_reference *R, int64_t pos)
@@ -100,6 +123,12 @@ static inline bool make_md(const nabwa_reference *R, int n_cigar, const uint16_t
 			const int l = CLEN(cigar[k]), op = COP(cigar[k]);
 			if (op == 0) {
 				for (int z = 0; z < l && pos < R->l_pac; ++z, ++y, ++pos) {
+					if (plain) {                                     /* the matching stretch up to the next difference, eight bases at a time */
+						const int64_t left = R->l_pac - pos;
+						const int run = pac_match_run(R, pos, q + y, (int64_t)(l - z) < left ? l - z : (int)left);
+						u += run; z += run; y += run; pos += run;
+						if (z >= l || pos >= R->l_pac) break;
+					}
 					const int c = MD_REF(pos);
 					if (c > 3 || q[y] > 3 || c != q[y]) { flush_num(); put(base_chr(c)); ++nm; u = 0; } else ++u;
 				}
@@ -112,6 +141,11 @@ static inline bool make_md(const nabwa_reference *R, int n_cigar, const uint16_t
 		}
 	} else {
 		for (int z = 0; z < len; ++z, ++pos) {
+			if (plain && pos + (len - z) <= R->l_pac) {
+				const int run = pac_match_run(R, pos, q + z, len - z);
+				u += run; z += run; pos += run;
+				if (z >= len) break;
+			}
 			const int c = MD_REF(pos);
 			if (c > 3 || q[z] > 3 || c != q[z]) { flush_num(); put(base_chr(c)); ++nm; u = 0; } else ++u;
 		}
@@ -124,6 +158,7 @@ static inline bool make_md(const nabwa_reference *R, int n_cigar, const uint16_t
 }
 
 
+static inline double fin_now() { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + 1e-6 * tv.tv_usec; }
 static inline nabwa_se_t *rec_at(void *base, size_t stride, int i) { return (nabwa_se_t*)((char*)base + (size_t)i * stride); }
 
 /* bwa_aln2seq_core with set_main (bwase.c:28-46): reservoir choice among the best-score rows with the caller's
@@ -215,6 +250,8 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 							   const uint8_t *rseq, size_t *n_jobs)
 {
 	const nabwa_reference *R = ix->ref;
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double tr0 = fin_now();
 	const int nt = fin_threads((size_t)n);
 	std::vector<std::vector<RefineJob>> part((size_t)nt);
 	fin_parallel(nt, (size_t)n, [&](int t, size_t lo, size_t hi) {
@@ -257,11 +294,13 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 			else for (int k = 0; k < J.len; ++k) qb[k] = src[J.len - 1 - k];
 		}
 	});
+	const double tr1 = fin_now();
 	const int MAXC = NABWA_MAX_CIGAR;
 	std::vector<int32_t> sc(nj), nc(nj); std::vector<uint32_t> c32(nj * (size_t)MAXC);
 	int r = nabwa_global_align(ix->device, (int)nj, ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
 							   sc.data(), nc.data(), c32.data(), MAXC);                       /* aln_param_bwa, stdaln.c:227 */
 	if (r != NABWA_OK) return r;
+	const double tr2 = fin_now();
 	std::vector<int> bad((size_t)ntj, 0);
 	fin_parallel(ntj, nj, [&](int slice, size_t lo_t, size_t hi_t) {
 		for (size_t t = lo_t; t < hi_t; ++t) {
@@ -284,6 +323,7 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 		}
 	});
 	for (int b : bad) if (b) return nabwa_fail(NABWA_ECAP, "refined CIGAR longer than NABWA_MAX_CIGAR");
+	if (timing) fprintf(stderr, "[nabwa] refine_batch %zu jobs: jobs + windows %.3f s, nabwa_global_align %.3f s, CIGARs %.3f s\n", nj, tr1 - tr0, tr2 - tr1, fin_now() - tr2);
 	return NABWA_OK;
 }
 
