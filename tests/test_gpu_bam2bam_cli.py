@@ -184,6 +184,18 @@ def test_two_index_replicas_take_the_batches_in_turn(tmp_path):
     check_se(two[:300], sam[:300])
 
 
+def test_a_file_without_records_gives_a_header_and_nothing_else(tmp_path):
+    for kind in ("blocks", False):
+        text, refs, out = run(tmp_path, [], [], bgzf=kind)
+        assert out == [] and text.startswith("@HD\tVN:1.4\n@PG\tID:bwa-1") and [r[0] for r in refs] == toy_ann()[1]
+    # nothing maps: --only-aligned leaves nothing to write
+    junk = [B.make_record("junk%d" % i, "ACGT" * 9 + "N" * 14, "I" * 50, 4) for i in range(5)]
+    _, _, out = run(tmp_path, junk, ["--only-aligned"])
+    assert out == []
+    _, _, out = run(tmp_path, junk, [])
+    assert len(out) == 5 and all(r["flag"] & 4 for r in out)
+
+
 def reflag(rec, flag):
     """the same record with another FLAG"""
     return rec[:18] + struct.pack("<H", flag) + rec[20:]
