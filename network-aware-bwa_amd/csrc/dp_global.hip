@@ -34,21 +34,34 @@ struct DpParams {
 	int32_t *score, *n_cigar; uint32_t *cigar; int max_cigar;
 };
 
-__global__ __launch_bounds__(256) void dp_global_kernel(const DpParams P)
+// Two forms, as for the local kernel below: LDSV = false keeps the score rows of a wave's 64 tasks interleaved in HBM (tens of
+// thousands of tasks hide each other's round trips); LDSV = true is for a handful of tasks (the paths of mate rescue, a few per
+// batch, each a chain of dependent row reads): eight tasks per block, rows and reference
+// window in LDS.  The traceback matrix and the path stay in HBM in both (written once, read once along the path).
+#define DP_SMALL_LANES 8
+template <bool LDSV>
+__global__ __launch_bounds__(LDSV ? DP_SMALL_LANES : 256) void dp_global_kernel(const DpParams P)
 {
-	const int t = blockIdx.x * 256 + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	extern __shared__ int32_t glo_lds[];             // LDSV: [6][W][8] row words, then 8 windows of W bytes
+	constexpr int BT = LDSV ? DP_SMALL_LANES : 256, RS = LDSV ? DP_SMALL_LANES : 64;
+	const int t = blockIdx.x * BT + threadIdx.x;
+	const int lane = t & 63;
+	const size_t wave = (size_t)(t >> 6);            // task t owns lane t % 64 of region t / 64 of the HBM scratch in either form
 	if (t >= P.n) return;
 	const uint8_t *s1 = P.ref + P.ref_off[t], *s2 = P.qry + P.qry_off[t];
 	const int l1 = (int)(P.ref_off[t + 1] - P.ref_off[t]), l2 = (int)(P.qry_off[t + 1] - P.qry_off[t]);
 	P.n_cigar[t] = 0; P.score[t] = 0;
 	if (l1 == 0 || l2 == 0) return;
 	const int W = P.W;
-	int32_t *R = P.rows + wave * 6 * (size_t)W * 64 + lane;
+	int32_t *R = LDSV ? glo_lds + threadIdx.x : P.rows + wave * 6 * (size_t)W * 64 + lane;
+	if (LDSV) {
+		uint8_t *win = (uint8_t*)(glo_lds + 6 * (size_t)W * DP_SMALL_LANES) + (size_t)threadIdx.x * W;
+		for (int i = 0; i < l1; ++i) win[i] = s1[i];
+		s1 = win;
+	}
 	uint8_t *TB = P.tb + wave * (size_t)P.H * W * 64 + lane;
 	uint8_t *PATH = P.path + wave * (size_t)(W + P.H) * 64 + lane;
-#define ROW(arr, par, i) R[(((arr) * 2 + (par)) * (size_t)W + (i)) * 64]     // arr: 0 M, 1 I, 2 D; par: row parity
+#define ROW(arr, par, i) R[(((arr) * 2 + (par)) * (size_t)W + (i)) * RS]     // arr: 0 M, 1 I, 2 D; par: row parity
 #define TBC(j, i) TB[((size_t)(j) * W + (i)) * 64]
 	const int gap_open = P.gap_open, gap_ext = P.gap_ext;
 	const int end_pen = P.gap_end >= 0 ? P.gap_end : P.gap_ext;
@@ -163,7 +176,12 @@ __global__ __launch_bounds__(256) void dp_global_kernel(const DpParams P)
 extern "C" void nabwa_launch_dp_global(const DpParams *P, hipStream_t s)
 {
 	if (P->n <= 0) return;
-	hipLaunchKernelGGL(dp_global_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
+	const int small_max = getenv("NABWA_DP_SMALL") ? atoi(getenv("NABWA_DP_SMALL")) : 4096;           // tasks up to which the LDS form runs (0: never)
+	const size_t lds = (size_t)P->W * DP_SMALL_LANES * 25;                                            // six rows of words + the window
+	if (P->n <= small_max && lds <= 60000)
+		hipLaunchKernelGGL(dp_global_kernel<true>, dim3((P->n + DP_SMALL_LANES - 1) / DP_SMALL_LANES), dim3(DP_SMALL_LANES), lds, s, *P);
+	else
+		hipLaunchKernelGGL(dp_global_kernel<false>, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -273,9 +291,18 @@ struct LocParams {
 	int32_t *out;          // per task: score_f, score_r, start_i, start_j, end_i, end_j
 };
 
-__global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
+// Two forms.  LDSV = false: 256 tasks per block, the row words of a wave's 64 tasks interleaved in HBM -- right when tens of
+// thousands of tasks hide each other's round trips (100 k tasks: 43 ms).  LDSV = true: a handful of tasks (mate rescue often
+// has a few per batch) would spend a memory round trip per eight cells with nothing to hide it, so eight tasks share a block
+// and keep their rows and their reference windows in LDS.  Measured for two tasks of 446 x 151: 28 -> 21 ms -- what is left is
+// one lane walking 67 k cells by itself; the next step is a wave per task (DESIGN, "Next").
+#define LOC_SMALL_LANES 8
+template <bool LDSV>
+__global__ __launch_bounds__(LDSV ? LOC_SMALL_LANES : 256) void dp_local_kernel(const LocParams P)
 {
-	const int t = blockIdx.x * 256 + threadIdx.x;
+	extern __shared__ int32_t loc_lds[];             // LDSV: [W][8] row words, then 8 windows of W bytes
+	constexpr int BT = LDSV ? LOC_SMALL_LANES : 256, ES = LDSV ? LOC_SMALL_LANES : 64;
+	const int t = blockIdx.x * BT + threadIdx.x;
 	const int lane = threadIdx.x & 63;
 	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (t >= P.n) return;
@@ -284,9 +311,15 @@ __global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
 	int32_t *out = P.out + (size_t)t * 6;
 	out[0] = -1; out[1] = 0; out[2] = out[3] = out[4] = out[5] = 0;
 	if (l1 == 0 || l2 == 0) return;
-	int32_t *EH = P.eh + wave * (size_t)P.W * 64 + lane;
+	int32_t *EH = LDSV ? loc_lds + threadIdx.x : P.eh + wave * (size_t)P.W * 64 + lane;
+	if (LDSV) {
+		uint8_t *win = (uint8_t*)(loc_lds + (size_t)P.W * LOC_SMALL_LANES) + (size_t)threadIdx.x * P.W;
+		win[0] = 4;                                      // (loaded with a block of cells at the window's edge, never used)
+		for (int i = 1; i <= l1; ++i) win[i] = s1[i];
+		s1 = win;
+	}
 	int32_t *suba = P.suba + (size_t)t * P.H;
-#define E(i) EH[(size_t)(i) * 64]
+#define E(i) EH[(size_t)(i) * ES]
 	const int q = P.gap_open, r = P.gap_ext, qr = q + r, qr_shift = (qr + 1) << 16, tmp_len = l1 + 1;
 	int end_i = 0, end_j = 0, score_f = 0, is_overflow = 0, of_base = 0;
 	for (int i = 0; i < tmp_len; ++i) E(i) = 0;
@@ -404,5 +437,10 @@ __global__ __launch_bounds__(256) void dp_local_kernel(const LocParams P)
 extern "C" void nabwa_launch_dp_local(const LocParams *P, hipStream_t s)
 {
 	if (P->n <= 0) return;
-	hipLaunchKernelGGL(dp_local_kernel, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
+	const int small_max = getenv("NABWA_DP_SMALL") ? atoi(getenv("NABWA_DP_SMALL")) : 4096;     // tasks up to which the LDS form runs (0: never)
+	const size_t lds = (size_t)P->W * LOC_SMALL_LANES * 5;                                            // row words + windows
+	if (P->n <= small_max && lds <= 60000)
+		hipLaunchKernelGGL(dp_local_kernel<true>, dim3((P->n + LOC_SMALL_LANES - 1) / LOC_SMALL_LANES), dim3(LOC_SMALL_LANES), lds, s, *P);
+	else
+		hipLaunchKernelGGL(dp_local_kernel<false>, dim3((P->n + 255) / 256), dim3(256), 0, s, *P);
 }

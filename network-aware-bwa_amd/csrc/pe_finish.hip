@@ -76,12 +76,14 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 	uint64_t tot_dummy[2] = { 0, 0 }, map_dummy[2] = { 0, 0 };
 	if (!n_tot) n_tot = tot_dummy;
 	if (!n_mapped) n_mapped = map_dummy;
-	size_t n_hit_rows = 0, n_sw = 0, n_refine = 0;
+	size_t n_hit_rows = 0, n_sw = 0, n_refine = 0, n_cand = 0;
 
 	/* ---- A. pairing: text positions of every hit row of both ends, chunked so one bwt_sa batch stays bounded
 	 *         (bam2bam.c:726-770; the position cache there only memoises bwt_sa and is not needed) */
 	const size_t CHUNK_ROWS = 1u << 25;
+	double ta[3] = { 0, 0, 0 }, tc[4] = { 0, 0, 0, 0 };
 	for (int p0 = 0; p0 < n_pairs;) {
+		const double tA0 = now();
 		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<size_t> pair_lo; std::vector<int> pairs;
 		int p1 = p0;
 		for (; p1 < n_pairs && (rows.size() < CHUNK_ROWS || pairs.empty()); ++p1) {
@@ -102,8 +104,10 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 		}
 		pair_lo.push_back(rows.size());
 		n_hit_rows += rows.size();
+		const double tA1 = now();
 		std::vector<uint32_t> sa(rows.size());
 		if (!rows.empty()) { int r = nabwa_sa_lookup(ix, (int)rows.size(), which.data(), rows.data(), sa.data()); if (r != NABWA_OK) return r; }
+		const double tA2 = now();
 		fin_parallel(fin_threads(pairs.size()), pairs.size(), [&](int, size_t t_lo, size_t t_hi) {      /* pairs are independent of each other */
 		std::vector<uint64_t> hits;
 		for (size_t t = t_lo; t < t_hi; ++t) {
@@ -133,6 +137,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 			}
 		}
 		});
+		ta[0] += tA1 - tA0; ta[1] += tA2 - tA1; ta[2] += now() - tA2;
 		p0 = p1;
 	}
 	t1 = now();
@@ -195,6 +200,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 			});
 			for (int t = 0; t < ntc; ++t) { n_tot[0] += tot0[(size_t)t]; n_tot[1] += tot1[(size_t)t]; cand.insert(cand.end(), cparts[(size_t)t].begin(), cparts[(size_t)t].end()); }
 		}
+		tc[0] = now() - t2; n_cand = cand.size();
 		for (int pr : cand) {
 			for (int k = 0; k < 2; ++k) {
 				const nabwa_se_t &ref = PE(out, pr, 1 - k).se, &mate = PE(out, pr, k).se;
@@ -228,6 +234,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 				jobs.push_back({ pr, k, a, l, ref.strand != 0 });
 			}
 		}
+		tc[1] = now() - t2;
 		n_sw = jobs.size();
 		const int MAXC = NABWA_MAX_CIGAR - 2;
 		std::vector<int32_t> sc(jobs.size()), co(jobs.size() * 4), nc(jobs.size()); std::vector<uint32_t> c32(jobs.size() * (size_t)MAXC);
@@ -237,6 +244,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 									  sc.data(), co.data(), 0, nc.data(), c32.data(), MAXC);
 			if (r != NABWA_OK) return r;
 		}
+		tc[2] = now() - t2;
 		const int sw_isize_term = (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * 1.5) + .499));     /* bwape.c:593 */
 		for (int pr : cand) {
 			int n_cig[2] = { 0, 0 }, mq_adjust[2] = { 255, 255 }; uint16_t cig[2][NABWA_MAX_CIGAR]; uint32_t cnt[2] = { 0, 0 };
@@ -377,6 +385,8 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 		for (auto &x : th) x.join();
 	}
 	if (md_over) return nabwa_fail(NABWA_ECAP, "MD string longer than NABWA_MAX_MD");
+	if (timing) fprintf(stderr, "[nabwa] pe_finish pairing: rows collected %.3f s, bwt_sa %.3f s, pairing %.3f s; rescue: scan %.3f s, windows %.3f s (%zu candidates), local alignments %.3f s, applied %.3f s\n",
+						ta[0], ta[1], ta[2], tc[0], tc[1] - tc[0], n_cand, tc[2] - tc[1], (t3 - t2) - tc[2]);
 	if (timing) fprintf(stderr, "[nabwa] pe_finish %d pairs: pairing (%zu hit rows) %.3f s, multi %.3f s, mate rescue (%zu alignments) %.3f s, "
 						"refinement (%zu jobs) %.3f s, md/flags %.3f s\n", n_pairs, n_hit_rows, t1 - t0, t2 - t1, n_sw, t3 - t2, n_refine, t4 - t3, now() - t4);
 	return NABWA_OK;

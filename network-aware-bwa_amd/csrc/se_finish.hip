@@ -223,6 +223,10 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 	if (n == 0) return NABWA_OK;
 	if (nabwa_device_count() <= device) return nabwa_fail(NABWA_ENODEV, "no such HIP device");
 	SCHK(hipSetDevice(device));
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const bool timing = getenv("NABWA_TIMING") != 0;
+	const double tl0 = now();
+	double tl1 = 0, tl2 = 0, tl3 = 0;
 	int W = 2, H = 2, max_score = 0;
 	for (int i = 0; i < n; ++i) { W = std::max<int64_t>(W, ref_off[i + 1] - ref_off[i] + 2); H = std::max<int64_t>(H, qry_off[i + 1] - qry_off[i] + 1); }
 	for (int i = 0; i < 25; ++i) max_score = std::max(max_score, matrix25[i]);
@@ -243,11 +247,14 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 		if (qry_off[n]) SCHK(hipMemcpy(d_qry, qry, qry_off[n], hipMemcpyHostToDevice));
 		P.n = n; P.ref_off = d_ro; P.qry_off = d_qo; P.ref = d_ref; P.qry = d_qry;
 		P.gap_open = gap_open; P.gap_ext = gap_ext; P.thres = thres; memcpy(P.matrix, matrix25, 100); P.max_score = max_score; P.W = W; P.H = H;
+		tl1 = now();
 		nabwa_launch_dp_local(&P, 0);
 		SCHK(hipGetLastError());
+		if (timing) { SCHK(hipDeviceSynchronize()); tl2 = now(); }
 		SCHK(hipMemcpy(o.data(), P.out, (size_t)n * 24, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(sub.data(), P.suba, (size_t)n * H * 4, hipMemcpyDeviceToHost));
 	}
+	tl3 = now();
 	std::vector<int> act;
 	for (int i = 0; i < n; ++i) {
 		const int32_t *v = &o[(size_t)i * 6];
@@ -293,6 +300,7 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 		}
 		act.swap(next);
 	}
+	if (timing) fprintf(stderr, "[nabwa] local_align %d tasks (window %d x %d): set-up + upload %.4f s, kernel %.4f s, download %.4f s, paths (global alignments) %.4f s\n", n, W, H, tl1 - tl0, tl2 - tl1, tl3 - tl2, now() - tl3);
 	return NABWA_OK;
 }
 

@@ -21,7 +21,9 @@ SM = [np.array([11, -19, -19, -19, -13, -19, 11, -19, -19, -13, -19, -19, 11, -1
                 -3, -3, -3, 1, -2, -2, -2, -2, -2, -2], np.int32)]
 
 
-def test_global_align_golden():
+@pytest.mark.parametrize("small", ["4096", "0"])
+def test_global_align_golden(monkeypatch, small):
+    monkeypatch.setenv("NABWA_DP_SMALL", small)       # both forms of the kernel: rows in LDS for a handful of tasks, in HBM for many
     vec = np.load(os.path.join(T.GOLDEN, "vectors.npz"))
     n = int(vec["dp_n"])
     for pid in range(len(vec["dp_params"])):
@@ -121,7 +123,9 @@ def test_se_chain_matches_reference_sam(name):
     ix.close()
 
 
-def test_extend_align_golden():
+@pytest.mark.parametrize("small", ["4096", "0"])
+def test_extend_align_golden(monkeypatch, small):
+    monkeypatch.setenv("NABWA_DP_SMALL", small)
     """aln_extend_core (named by the north star; reached from bwasw in the reference): known answers from the reference"""
     v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
     n = len(v["pid"])
@@ -140,8 +144,12 @@ def test_extend_align_golden():
             assert list(cigs[j]) == list(want), (pid, t)
 
 
-def test_local_align_golden():
-    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference"""
+@pytest.mark.parametrize("small", ["4096", "0"])
+def test_local_align_golden(monkeypatch, small):
+    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference; both forms
+    of the kernel -- rows in LDS for a handful of tasks, rows in HBM for many (NABWA_DP_SMALL = the task count up to which the
+    first one runs)"""
+    monkeypatch.setenv("NABWA_DP_SMALL", small)
     v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
     n = len(v["pid"])
     for pid in range(len(v["params"])):
