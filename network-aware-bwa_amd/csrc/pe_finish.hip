@@ -82,26 +82,43 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 	 *         (bam2bam.c:726-770; the position cache there only memoises bwt_sa and is not needed) */
 	const size_t CHUNK_ROWS = 1u << 25;
 	double ta[3] = { 0, 0, 0 }, tc[4] = { 0, 0, 0, 0 };
+	/* which pairs are paired here -- both ends mapped, neither with more than max_occ hit rows -- and how many rows each brings:
+	 * the records are read by all threads, the chunks are then cut from the counts alone */
+	std::vector<uint32_t> prow((size_t)(n_pairs ? n_pairs : 1), 0);
+	fin_parallel(fin_threads((size_t)n_pairs), (size_t)n_pairs, [&](int, size_t p_lo, size_t p_hi) {
+		for (size_t pr = p_lo; pr < p_hi; ++pr) {
+			const nabwa_se_t &e0 = PE(out, pr, 0).se, &e1 = PE(out, pr, 1).se;
+			if (!((e0.type == 1 || e0.type == 2) && (e1.type == 1 || e1.type == 2))) continue;
+			long long n_occ[2] = { 0, 0 };
+			for (int j = 0; j < 2; ++j) {
+				const nabwa_aln1_t *A = aln + a_off[2 * pr + j];
+				for (int k = 0; k < n_aln[2 * pr + j]; ++k) n_occ[j] += (long long)A[k].l - A[k].k + 1;
+			}
+			if (n_occ[0] > popt->max_occ || n_occ[1] > popt->max_occ) continue;
+			prow[pr] = (uint32_t)(n_occ[0] + n_occ[1]);
+		}
+	});
 	for (int p0 = 0; p0 < n_pairs;) {
 		const double tA0 = now();
 		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<size_t> pair_lo; std::vector<int> pairs;
 		int p1 = p0;
-		for (; p1 < n_pairs && (rows.size() < CHUNK_ROWS || pairs.empty()); ++p1) {
-			const nabwa_se_t &e0 = PE(out, p1, 0).se, &e1 = PE(out, p1, 1).se;
-			if (!((e0.type == 1 || e0.type == 2) && (e1.type == 1 || e1.type == 2))) continue;
-			long long n_occ[2] = { 0, 0 };
-			for (int j = 0; j < 2; ++j) {
-				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)p1 + j];
-				for (int k = 0; k < n_aln[2 * p1 + j]; ++k) n_occ[j] += (long long)A[k].l - A[k].k + 1;
-			}
-			if (n_occ[0] > popt->max_occ || n_occ[1] > popt->max_occ) continue;
-			pairs.push_back(p1); pair_lo.push_back(rows.size());
-			for (int j = 0; j < 2; ++j) {
-				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)p1 + j];
-				for (int k = 0; k < n_aln[2 * p1 + j]; ++k)
-					for (uint32_t l = A[k].k; ; ++l) { which.push_back((A[k].info >> 24 & 1) ? 0 : 1); rows.push_back(l); if (l == A[k].l) break; }
-			}
+		size_t n_rows = 0;
+		for (; p1 < n_pairs && (n_rows < CHUNK_ROWS || pairs.empty()); ++p1) {
+			if (!prow[(size_t)p1]) continue;
+			pairs.push_back(p1); pair_lo.push_back(n_rows); n_rows += prow[(size_t)p1];
 		}
+		which.resize(n_rows); rows.resize(n_rows);
+		fin_parallel(fin_threads(pairs.size()), pairs.size(), [&](int, size_t t_lo, size_t t_hi) {
+			for (size_t t = t_lo; t < t_hi; ++t) {
+				const int pr = pairs[t];
+				size_t u = pair_lo[t];
+				for (int j = 0; j < 2; ++j) {
+					const nabwa_aln1_t *A = aln + a_off[2 * (size_t)pr + j];
+					for (int k = 0; k < n_aln[2 * pr + j]; ++k)
+						for (uint32_t l = A[k].k; ; ++l) { which[u] = (A[k].info >> 24 & 1) ? 0 : 1; rows[u] = l; ++u; if (l == A[k].l) break; }
+				}
+			}
+		});
 		pair_lo.push_back(rows.size());
 		n_hit_rows += rows.size();
 		const double tA1 = now();
