@@ -156,17 +156,19 @@ __global__ __launch_bounds__(LDSV ? DP_SMALL_LANES : 256) void dp_global_kernel(
 	} while (i || j);
 	--plen;                        // the entry written at (0,0) is not part of the path
 	// run-length encode from the path's end: cigar32 = len<<4 | op
-	uint32_t *cg = P.cigar + (size_t)t * P.max_cigar;
+	// (operation k of task t at cigar[k * n_tasks + t]: the host fetches only as many operation slots as the longest CIGAR has)
+	uint32_t *cg = P.cigar + t;
+	const size_t cs = (size_t)P.n;
 	int n = 0; uint32_t curc = 0;
 	for (int p = plen - 1; p >= 0; --p) {
 		const uint32_t op = PATH[(size_t)p * 64];
 		if (n && (curc & 0xf) == op) curc += 1u << 4;
 		else {
-			if (n && n <= P.max_cigar) cg[n - 1] = curc;
+			if (n && n <= P.max_cigar) cg[(size_t)(n - 1) * cs] = curc;
 			curc = 1u << 4 | op; ++n;
 		}
 	}
-	if (n && n <= P.max_cigar) cg[n - 1] = curc;
+	if (n && n <= P.max_cigar) cg[(size_t)(n - 1) * cs] = curc;
 	P.n_cigar[t] = n;              // n > max_cigar signals truncation to the host
 	P.score[t] = score;
 #undef ROW

@@ -114,7 +114,18 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		SCHK(hipGetLastError());
 		SCHK(hipMemcpy(score + c0, P.score, (size_t)m * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(n_cigar + c0, P.n_cigar, (size_t)m * 4, hipMemcpyDeviceToHost));
-		SCHK(hipMemcpy(cigar32 + (size_t)c0 * max_cigar, P.cigar, (size_t)m * max_cigar * 4, hipMemcpyDeviceToHost));
+		/* the operations come slot by slot (dp_global_kernel): only the slots in use travel */
+		int slots = 0;
+		for (int i = 0; i < m; ++i) slots = std::max(slots, std::min(n_cigar[c0 + i], max_cigar));
+		if (slots) {
+			std::vector<uint32_t> cs((size_t)slots * m);
+			SCHK(hipMemcpy(cs.data(), P.cigar, cs.size() * 4, hipMemcpyDeviceToHost));
+			for (int i = 0; i < m; ++i) {
+				uint32_t *dst = cigar32 + (size_t)(c0 + i) * max_cigar;
+				const int k_n = std::min(n_cigar[c0 + i], max_cigar);
+				for (int k = 0; k < k_n; ++k) dst[k] = cs[(size_t)k * m + i];
+			}
+		}
 	}
 	return NABWA_OK;
 }
