@@ -83,7 +83,11 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 	if (nabwa_device_count() <= device) return nabwa_fail(NABWA_ENODEV, "no such HIP device");
 	SCHK(hipSetDevice(device));
 	const int CHUNK = 1 << 16;                     // tasks per launch: bounds the traceback scratch
+	const bool timing = getenv("NABWA_TIMING") != 0 && n >= 1024;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tg[4] = { 0, 0, 0, 0 };              // set-up, upload, kernel, download
 	for (int c0 = 0; c0 < n; c0 += CHUNK) {
+		const double tg0 = now();
 		const int m = std::min(CHUNK, n - c0);
 		int W = 1, H = 1;
 		for (int i = c0; i < c0 + m; ++i) {
@@ -102,6 +106,7 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
 		P.rows = A.take<int32_t>(sz[4]); P.tb = A.take<uint8_t>(sz[5]); P.path = A.take<uint8_t>(sz[6]);
 		P.score = A.take<int32_t>(sz[7]); P.n_cigar = A.take<int32_t>(sz[8]); P.cigar = A.take<uint32_t>(sz[9]);
+		const double tg1 = now();
 		SCHK(hipMemcpy(d_ro, ro.data(), (m + 1) * 8, hipMemcpyHostToDevice));
 		SCHK(hipMemcpy(d_qo, qo.data(), (m + 1) * 8, hipMemcpyHostToDevice));
 		if (ro[m]) SCHK(hipMemcpy(d_ref, ref + ref_off[c0], ro[m], hipMemcpyHostToDevice));
@@ -110,8 +115,11 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		P.gap_open = gap_open; P.gap_ext = gap_ext; P.gap_end = gap_end; P.band = band;
 		memcpy(P.matrix, matrix25, sizeof(P.matrix));
 		P.W = W; P.H = H; P.max_cigar = max_cigar;
+		const double tg2 = now();
 		nabwa_launch_dp_global(&P, 0);
 		SCHK(hipGetLastError());
+		if (timing) SCHK(hipDeviceSynchronize());
+		const double tg3 = now();
 		SCHK(hipMemcpy(score + c0, P.score, (size_t)m * 4, hipMemcpyDeviceToHost));
 		SCHK(hipMemcpy(n_cigar + c0, P.n_cigar, (size_t)m * 4, hipMemcpyDeviceToHost));
 		/* the operations come slot by slot (dp_global_kernel): only the slots in use travel */
@@ -126,7 +134,9 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 				for (int k = 0; k < k_n; ++k) dst[k] = cs[(size_t)k * m + i];
 			}
 		}
+		tg[0] += tg1 - tg0; tg[1] += tg2 - tg1; tg[2] += tg3 - tg2; tg[3] += now() - tg3;
 	}
+	if (timing) fprintf(stderr, "[nabwa] global_align %d tasks: set-up %.4f s, upload %.4f s, kernel %.4f s, download %.4f s\n", n, tg[0], tg[1], tg[2], tg[3]);
 	return NABWA_OK;
 }
 
