@@ -144,12 +144,52 @@ def test_extend_align_golden(monkeypatch, small):
             assert list(cigs[j]) == list(want), (pid, t)
 
 
-@pytest.mark.parametrize("small", ["4096", "0"])
-def test_local_align_golden(monkeypatch, small):
-    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference; both forms
-    of the kernel -- rows in LDS for a handful of tasks, rows in HBM for many (NABWA_DP_SMALL = the task count up to which the
-    first one runs)"""
-    monkeypatch.setenv("NABWA_DP_SMALL", small)
+def test_local_align_forms_agree_on_rescue_sized_tasks(monkeypatch):
+    """400 tasks shaped like mate rescue (a window of 300 - 620 bases, a read of 70 - 250 with substitutions, an indel now and
+    then, some reads that are not in their window at all, N runs): the wave-per-task form, the LDS form and the HBM form give
+    the same scores, cells, sub-optimal scores and CIGARs (the HBM form is the one the reference's golden vectors pin at size)"""
+    rng = np.random.default_rng(77)
+    refs, qrys = [], []
+    for t in range(400):
+        lw, lr = int(rng.integers(300, 620)), int(rng.integers(70, 250))
+        w = rng.integers(0, 4, lw).astype(np.uint8)
+        if t % 9 == 0:
+            r = rng.integers(0, 4, lr).astype(np.uint8)                    # not there
+        else:
+            p = int(rng.integers(0, lw - lr)) if lw > lr else 0
+            r = w[p:p + lr].copy()
+            sub = rng.random(len(r)) < 0.04
+            r[sub] = rng.integers(0, 4, int(sub.sum()))
+            if t % 4 == 0 and len(r) > 40:
+                c = int(rng.integers(20, len(r) - 20))
+                r = np.concatenate([r[:c], r[c + int(rng.integers(1, 4)):]]) if t % 8 == 0 else np.concatenate([r[:c], rng.integers(0, 4, int(rng.integers(1, 4))).astype(np.uint8), r[c:]])
+        if t % 13 == 0:
+            w[10:14] = 4; r[5:7] = 4
+        refs.append(w); qrys.append(r.astype(np.uint8))
+    ro = np.concatenate([[0], np.cumsum([len(x) for x in refs])]).astype(np.int64)
+    qo = np.concatenate([[0], np.cumsum([len(x) for x in qrys])]).astype(np.int64)
+    maq = SM[0]
+    got = {}
+    for form in ("wave", "lds", "hbm"):
+        monkeypatch.setenv("NABWA_DP_SMALL", "0" if form == "hbm" else "4096")
+        if form == "lds":
+            monkeypatch.setenv("NABWA_DP_NO_WAVE", "1")
+        else:
+            monkeypatch.delenv("NABWA_DP_NO_WAVE", raising=False)
+        score, coords, subo, cigs = nabwa.local_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, 26, 9, maq, 50, 1, max_cigar=62)
+        got[form] = (list(score), [tuple(c) for c in coords], list(subo), [list(c) for c in cigs])
+    assert sum(1 for x in got["hbm"][0] if x > 0) > 300
+    assert got["wave"] == got["hbm"] and got["lds"] == got["hbm"]
+
+
+@pytest.mark.parametrize("form", ["wave", "lds", "hbm"])
+def test_local_align_golden(monkeypatch, form):
+    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference; the three
+    forms of the kernel -- a wave per task and a lane per task with its row in LDS for a handful of tasks, a lane per task with the
+    rows in HBM for many (NABWA_DP_SMALL = the task count up to which the first two run)"""
+    monkeypatch.setenv("NABWA_DP_SMALL", "0" if form == "hbm" else "4096")
+    if form == "lds":
+        monkeypatch.setenv("NABWA_DP_NO_WAVE", "1")
     v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
     n = len(v["pid"])
     for pid in range(len(v["params"])):
