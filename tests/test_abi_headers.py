@@ -75,9 +75,10 @@ def test_struct_layouts_match_the_reference_headers(tmp_path):
 
 def test_integration_md_snippets_compile_against_the_reference_headers(tmp_path):
     """every ```c block of INTEGRATION.md, in order, as one translation unit after the reference's headers and nabwa.h; the
-    globals bam2bam.c keeps (bam2bam.c:88-92) are declared extern, as a maintainer's file would see them"""
+    globals bam2bam.c keeps (bam2bam.c:88-101) are declared extern, as a maintainer's file would see them"""
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```c\n(.*?)```", text, re.S)
     assert len(blocks) >= 4
-    glue = PRELUDE + "extern gap_opt_t *gap_opt; extern pe_opt_t *pe_opt; extern bntseq_t *bns; extern bwt_t *bwt[2];\n"
+    glue = (PRELUDE + "extern gap_opt_t *gap_opt; extern pe_opt_t *pe_opt; extern bntseq_t *bns; extern bwt_t *bwt[2];\n"
+            "extern int only_aligned, debug_bam, broken_input, drop_aligned, skip_duplicates;      /* bam2bam.c:96-101 */\n")
     cc(glue + "\n".join(blocks) + "\nint main(void) { return 0; }\n", tmp_path, "integration.c")
