@@ -196,6 +196,48 @@ def test_a_file_without_records_gives_a_header_and_nothing_else(tmp_path):
     assert len(out) == 5 and all(r["flag"] & 4 for r in out)
 
 
+def test_three_hundred_thousand_reads_through_the_pipeline_in_order(tmp_path):
+    """size-independent properties of the command at a size where every queue of its pipeline is in use (13 batches, two search
+    threads, BGZF blocks in, BGZF blocks out): every record comes out exactly once, in input order, with its own bases; reads cut
+    from the genome map where they were cut (unique places: mapping quality 37 there), and a second run gives the same bytes"""
+    rng = np.random.default_rng(99)
+    fa = "".join(l.strip() for l in open(os.path.join(T.GOLDEN, "toy.fa")) if not l.startswith(">")).upper()
+    g = np.frombuffer(fa.encode(), np.uint8)
+    code = np.full(256, 15, np.uint8); code[ord("A")] = 1; code[ord("C")] = 2; code[ord("G")] = 4; code[ord("T")] = 8
+    g16 = code[g]
+    N, L = 300_000, 64
+    start = rng.integers(0, len(g16) - L, N)
+    reads = g16[start[:, None] + np.arange(L)[None, :]]
+    rec_len = 36 + 10 + L // 2 + L
+    rec = np.zeros((N, rec_len), np.uint8)
+    rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec_len - 4), np.uint8)
+    rec[:, 4:36] = np.frombuffer(struct.pack("<iiIIiiii", -1, -1, (4680 << 16) | 10, 4 << 16, L, -1, -1, 0), np.uint8)
+    rec[:, 36] = ord("r")
+    rec[:, 37:45] = np.frombuffer("".join(np.char.zfill(np.arange(N).astype("U8"), 8)).encode(), np.uint8).reshape(N, 8)
+    rec[:, 46:46 + L // 2] = (reads[:, 0::2] << 4) | reads[:, 1::2]
+    rec[:, 46 + L // 2:] = 30
+    recs = [rec.tobytes()]                                        # write_bam joins the records: one blob will do
+    env = {"NABWA_BAM_BATCH": "24000", "NABWA_DEVICES": "0,0"}
+    _, _, out = run(tmp_path, recs, [], bgzf="blocks", env=env)
+    first = open(str(tmp_path / "out.bam"), "rb").read()
+    assert len(out) == N
+    assert [o["name"] for o in out] == ["r%08d" % i for i in range(N)]
+    fwd = np.array([not (o["flag"] & 16) for o in out])
+    assert all(o["seq"] == "".join("=ACMGRSVTWYHKDBN"[c] for c in reads[i]) for i, o in enumerate(out[:2000]) if fwd[i])
+    unique = [i for i, o in enumerate(out) if o["mapq"] == 37 and not (o["flag"] & 4)]
+    assert len(unique) > 0.8 * N
+    l_pac, names = toy_ann()
+    offs = {}
+    lines = open(T.TOY + ".ann").read().split("\n")
+    for k in range(len(names)):
+        offs[names[k]] = int(lines[2 + 2 * k].split()[0])
+    wrong = [i for i in unique[:50000] if offs[out[i]["rname"]] + out[i]["pos"] - 1 != start[i]]
+    assert not wrong, wrong[:5]
+    _, _, again = run(tmp_path, recs, [], bgzf="blocks", env=env)
+    second = open(str(tmp_path / "out.bam"), "rb").read()
+    assert gzip.decompress(first).split(b"\n@SQ", 1)[1] == gzip.decompress(second).split(b"\n@SQ", 1)[1]
+
+
 def reflag(rec, flag):
     """the same record with another FLAG"""
     return rec[:18] + struct.pack("<H", flag) + rec[20:]
