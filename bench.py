@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- aligned reads/s of the FM-index search hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): a GRCh38-sized index (3.1 Gbp; synthetic genome, because there is
+Headline workload (BASELINE.json configs[1]): a GRCh38-sized index (3.1 Gbp; synthetic genome, because there is
 no network for the real one -- see DESIGN.md) and 10 M synthetic 100 bp single-end reads per GPU at
 0.2 % substitutions.  One "step" = one pass of bwa_cal_sa_reg_gap over the whole batch, inputs and the
 index resident in HBM.  With --gpus N every rank holds a replica of the index and its own shard of reads
-(no collective on the data path; weak scaling).
+(no collective on the data path; weak scaling).  `python bench.py --gpus N` without a launcher around it starts
+its N ranks itself (a torch.distributed.run child, before anything touches a GPU) and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 with `roofline` (algorithmic Occ-bucket bytes / HIP-event kernel time
-vs. the 8 TB/s HBM peak) and `cpu_baseline` (the reference's own compiled code, oracle/_ref, on the
-host cores of this box, on a bounded sample of the same reads).
+vs. the 8 TB/s HBM peak), `cpu_baseline` (the reference's own compiled code, oracle/_ref, on the
+host cores of this box, on a bounded sample of the same reads), `e2e` (BAM records in -> BAM records out) and, at full
+size, `workloads`: BASELINE configs 5 (--adna) and 3 (--pe) and the repeat-family genome (--repeats) after the headline
+steps, each with its own value / roofline / cpu_baseline / bit-exact sample.
 """
 import argparse
 import ctypes as C
@@ -33,7 +36,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -55,217 +58,317 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the BAM-records-in -> BAM-records-out leg of the headline run")
     ap.add_argument("--e2e-reads", type=int, default=1_000_000)
     ap.add_argument("--pipeline", action="store_true", help="steps alternate between two device-resident batches on two streams (not the headline mode)")
-    args = ap.parse_args()
+    ap.add_argument("--extras", choices=["auto", "on", "off"], default="auto", help="after the headline steps also run configs 5 (--adna), 3 (--pe) and the repeat-family "
+                    "genome and attach them under `workloads` (auto: at the full genome size only)")
+    ap.add_argument("--extra-steps", type=int, default=2, help="timed steps of each extra workload (one warm-up step before them)")
+    ap.add_argument("--extra-adna-reads", type=int, default=6_250_000, help="config 5's share of one GPU: 50 M reads over 8 GPUs")
+    ap.add_argument("--extra-repeat-reads", type=int, default=10_000_000)
+    ap.add_argument("--extra-cpu-seconds", type=float, default=8.0)
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_ranks(args):
+    """`bench.py --gpus N` run directly: start the N ranks as a child `python -m torch.distributed.run` (one process per GPU over RCCL)
+    and pass rank 0's line through.  Nothing in THIS process has touched a GPU (torch is not even imported), so no process that
+    initialised HIP is ever replaced; the child's exit code is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:])))
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Ctx:
+    pass
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    ctx = Ctx()
+    ctx.args = args
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    dist = None
-    backend = os.environ.get("NABWA_BENCH_BACKEND", "nccl")          # "gloo": rehearsal of the N>1 path on one GPU
+    ctx.torch = torch
+    ctx.dist = None
+    ctx.backend = os.environ.get("NABWA_BENCH_BACKEND", "nccl")          # "gloo": rehearsal of the N>1 path on one GPU
     one_dev = os.environ.get("NABWA_BENCH_SINGLE_DEVICE") == "1"
-    dev = local_rank if (world > 1 and not one_dev) else 0
+    ctx.dev = dev = local_rank if (world > 1 and not one_dev) else 0
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if ctx.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(ctx.backend)
+        ctx.dist = dist
 
-    nabwa = importlib.import_module("network-aware-bwa_amd")
-    synth = importlib.import_module("network-aware-bwa_amd.synth")
+    ctx.nabwa = nabwa = importlib.import_module("network-aware-bwa_amd")
+    ctx.synth = synth = importlib.import_module("network-aware-bwa_amd.synth")
     if not os.path.exists(nabwa.LIB_PATH) or not os.path.exists(synth.LIB_PATH):
         nabwa.build()
     import nabwa_testlib as T
+    ctx.T = T
+    ctx.want_cpu = rank == 0 and not args.no_cpu
+    # a CPU leg is taken on rank 0 at N = 1 only (at N > 1 the host cores are the ranks'); the bit-exact sample check stays on at any N
+    t_start = time.time()
 
+    single = args.pe or args.adna or args.repeats
+    extras = [] if (single or args.pipeline or quick_env() or args.extras == "off" or (args.extras == "auto" and args.genome_len != GRCH38_LEN)) \
+        else ["adna", "pe", "repeats"]
+    want_e2e = not args.no_e2e and not args.adna and not args.pe and not quick_env()
+    need_ref = args.pe or want_e2e or "pe" in extras
+    G = build_genome(ctx, args.genome_len, args.repeats, need_ref)
+    if args.pe:
+        out = pe_workload(ctx, G, args.pairs, args.steps, args.warmup, args.cpu_seconds)
+    else:
+        kind = "adna" if args.adna else ("repeats" if args.repeats else "headline")
+        out = se_workload(ctx, G, kind, args.reads, args.steps, args.warmup, True, args.cpu_seconds, want_e2e)
+    if extras:
+        wl = {}
+        es, ecpu = args.extra_steps, args.extra_cpu_seconds
+        t0 = time.time()
+        wl["adna"] = se_workload(ctx, G, "adna", args.extra_adna_reads, es, 1, False, ecpu, False)
+        if rank == 0:
+            log("extra workload adna: %.1f s" % (time.time() - t0))
+        t0 = time.time()
+        wl["pe"] = pe_workload(ctx, G, args.pairs, es, 1, ecpu)
+        if rank == 0:
+            log("extra workload pe: %.1f s" % (time.time() - t0))
+        t0 = time.time()
+        G.close()
+        G = build_genome(ctx, args.genome_len, True, False)
+        wl["repeats"] = se_workload(ctx, G, "repeats", args.extra_repeat_reads, es, 1, False, ecpu, False)
+        if rank == 0:
+            log("extra workload repeats: %.1f s" % (time.time() - t0))
+            out["workloads"] = wl
+    G.close()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+    if rank == 0 and out is not None:
+        out["bench_wall_s"] = round(time.time() - t_start, 1)
+        print(json.dumps(out), flush=True)
+
+
+class Genome:
+    """the synthetic text on the device, both FM-indexes in HBM (nabwa.Index), and -- for the CPU legs -- the index arrays on the host"""
+
+    def close(self):
+        if self.d_text is not None:
+            self.d_text.free()
+            self.d_text = None
+        if self.ix is not None:
+            self.ix.close()
+            self.ix = None
+        self.host_bwt = self.host_sa = self.pac = None
+
+
+def build_genome(ctx, n, repeats, need_ref):
+    nabwa, synth, dev, rank = ctx.nabwa, ctx.synth, ctx.dev, ctx.rank
     t0 = time.time()
-    n = args.genome_len
-    d_text = synth.synth_text_repeats(n, 20261004, device=dev) if args.repeats else synth.synth_text(n, 20261004, n_dup=2000, dup_len=5000, device=dev)
+    G = Genome()
+    G.n, G.repeats = n, repeats
+    G.d_text = synth.synth_text_repeats(n, 20261004, device=dev) if repeats else synth.synth_text(n, 20261004, n_dup=2000, dup_len=5000, device=dev)
     # with the SA samples (.sa/.rsa content): the index derives its full SA / inverse / text from them (text mode)
-    parts = [synth.build_index(d_text, n, rev, 32, True, device=dev, verbose=(rank == 0)) for rev in (0, 1)]
-    ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]),
-                                 (parts[0][2].ptr, parts[0][3]), (parts[1][2].ptr, parts[1][3]), device=dev, device_ptrs=True)
+    parts = [synth.build_index(G.d_text, n, rev, 32, True, device=dev, verbose=(rank == 0)) for rev in (0, 1)]
+    G.ix = nabwa.Index.from_arrays((parts[0][0].ptr, parts[0][1]), (parts[1][0].ptr, parts[1][1]),
+                                   (parts[0][2].ptr, parts[0][3]), (parts[1][2].ptr, parts[1][3]), device=dev, device_ptrs=True)
     if rank == 0:
-        log("index: %d bp x2 FM-indexes built on GPU + re-packed in %.1f s (%.2f GB in HBM)"
-            % (n, time.time() - t0, ix.device_bytes() / 1e9))
-    host_bwt = host_sa = None
-    want_cpu = rank == 0 and not args.no_cpu
-    if want_cpu:
-        host_bwt = [p[0].to_host(np.uint32, p[1]) for p in parts]
-    want_e2e = rank == 0 and not args.no_e2e and not args.adna and not quick_env()
-    if want_cpu and (args.pe or want_e2e):
-        host_sa = [p[2].to_host(np.uint32, p[3]) for p in parts]
+        log("index (%s genome): %d bp x2 FM-indexes built on GPU + re-packed in %.1f s (%.2f GB in HBM)"
+            % ("repeat-family" if repeats else "uniform", n, time.time() - t0, G.ix.device_bytes() / 1e9))
+    G.host_bwt = G.host_sa = G.pac = None
+    if ctx.want_cpu:
+        G.host_bwt = [p[0].to_host(np.uint32, p[1]) for p in parts]
+        if need_ref:
+            G.host_sa = [p[2].to_host(np.uint32, p[3]) for p in parts]
     for p in parts:
         p[0].free()
         p[2].free()
-    pac = None
-    if args.pe or want_e2e:
-        # the finishing chains read the packed reference (.pac layout) and one contig's annotation from the host
-        pac = pack_text(d_text, n)
-        ix.set_reference(n, 11, pac)
-    if args.pe:
-        out = pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backend, host_bwt, host_sa, pac, want_cpu)
-        d_text.free()
-        ix.close()
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        if out is not None:
-            print(json.dumps(out), flush=True)
-        return
+    if need_ref:
+        # the finishing chains read the packed reference (.pac layout) and the contigs' annotation from the host
+        G.pac = pack_text(G.d_text, n)
+        G.ix.set_reference(n, 11, G.pac)
+    return G
 
+
+def barrier(ctx):
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    ctx.torch.cuda.synchronize()
+
+
+def max_over_ranks(ctx, x):
+    if ctx.dist is None:
+        return x
+    t = ctx.torch.tensor([x], device="cuda" if ctx.backend == "nccl" else "cpu", dtype=ctx.torch.float64)
+    ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def se_workload(ctx, G, kind, n_reads, steps, warmup, primary, cpu_seconds, want_e2e):
+    """One single-end workload on genome G: kind = "headline" (configs[1]), "adna" (config 5's reads and options), "repeats" (the headline
+    reads on the repeat-family genome).  primary: the run's main workload (PCIe-inclusive legs, --pipeline, the e2e leg)."""
+    args, nabwa, synth, T, torch = ctx.args, ctx.nabwa, ctx.synth, ctx.T, ctx.torch
+    rank, world, dev, ix, n = ctx.rank, ctx.world, ctx.dev, G.ix, G.n
+    adna = kind == "adna"
+    read_len, sub_ppm, indel_ppm = (76, 10000, args.indel_ppm) if adna else (args.read_len, args.sub_ppm, args.indel_ppm)
     # reads: this rank's shard (seeded by rank)
-    if args.adna:
-        args.read_len, args.sub_ppm = 76, 10000
-    seq, rseq, off = synth.synth_reads(d_text, n, args.reads, args.read_len, args.sub_ppm, args.indel_ppm, 2 + 1000 * rank, device=dev)
-    d_text.free()
+    seq, rseq, off = synth.synth_reads(G.d_text, n, n_reads, read_len, sub_ppm, indel_ppm, 2 + 1000 * rank, device=dev)
     opt = nabwa.gap_init_opt()
-    if args.adna:
-        seq, rseq, off = adna_profile(seq, args.reads, args.read_len, 5 + 1000 * rank)
+    if adna:
+        seq, rseq, off = adna_profile(seq, n_reads, read_len, 5 + 1000 * rank)
         opt.fnr, opt.max_diff, opt.max_gapo, opt.seed_len = 0.01, -1, 2, 16500
-    # one end-to-end pass over host buffers (upload + both kernels + compacted download): the PCIe-inclusive rate
-    ix.cal_sa_reg_gap_flat(opt, seq[:off[1000]], rseq[:off[1000]], off[:1001], per_read=True)   # (loads the kernels' code objects once)
-    torch.cuda.synchronize()
-    quick = os.environ.get("NABWA_BENCH_QUICK") == "1"        # experiments on slow workloads: only the resident steps (no PCIe legs, no touch count)
-    n_pc = 1000 if quick else args.reads
-    seq_pc, rseq_pc, off_pc = (seq[:off[n_pc]], rseq[:off[n_pc]], off[:n_pc + 1]) if quick else (seq, rseq, off)
-    t_pcie_first = time.time()
-    _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq_pc, rseq_pc, off_pc, per_read=True)      # the C one-shot entry on host buffers
-    t_pcie_first = time.time() - t_pcie_first           # first call: the working buffers come from hipMalloc
-    del _na, _rows, _maxe
-    t_pcie = time.time()
-    _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq_pc, rseq_pc, off_pc, per_read=True)      # what a streaming caller sees: buffers from the index's pool
-    t_pcie = time.time() - t_pcie
-    if rank == 0 and os.environ.get("NABWA_BENCH_MAXE"):          # how large the searches' stacks get (bwa_seq_t.max_entries)
-        log("max_entries: percentiles 50/90/99/99.9/100 = %s; reads over 1024/4096/16384/65536/262144: %s"
-            % (np.percentile(_maxe, [50, 90, 99, 99.9, 100]).tolist(), [int((_maxe > c).sum()) for c in (1024, 4096, 16384, 65536, 262144)]))
-    del _na, _rows, _maxe
-    batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    quick = quick_env()        # experiments on slow workloads: only the resident steps (no PCIe legs, no touch count)
+    pipeline = args.pipeline and primary
+    t_pcie = t_pcie_first = None
+    n_pc = 0
+    if primary:
+        # one end-to-end pass over host buffers (upload + both kernels + compacted download): the PCIe-inclusive rate
+        ix.cal_sa_reg_gap_flat(opt, seq[:off[1000]], rseq[:off[1000]], off[:1001], per_read=True)   # (loads the kernels' code objects once)
         torch.cuda.synchronize()
+        n_pc = 1000 if quick else n_reads
+        seq_pc, rseq_pc, off_pc = (seq[:off[n_pc]], rseq[:off[n_pc]], off[:n_pc + 1]) if quick else (seq, rseq, off)
+        t_pcie_first = time.time()
+        _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq_pc, rseq_pc, off_pc, per_read=True)      # the C one-shot entry on host buffers
+        t_pcie_first = time.time() - t_pcie_first           # first call: the working buffers come from hipMalloc
+        del _na, _rows, _maxe
+        t_pcie = time.time()
+        _na, _rows, _maxe = ix.cal_sa_reg_gap_flat(opt, seq_pc, rseq_pc, off_pc, per_read=True)      # what a streaming caller sees: buffers from the index's pool
+        t_pcie = time.time() - t_pcie
+        if rank == 0 and os.environ.get("NABWA_BENCH_MAXE"):          # how large the searches' stacks get (bwa_seq_t.max_entries)
+            log("max_entries: percentiles 50/90/99/99.9/100 = %s; reads over 1024/4096/16384/65536/262144: %s"
+                % (np.percentile(_maxe, [50, 90, 99, 99.9, 100]).tolist(), [int((_maxe > c).sum()) for c in (1024, 4096, 16384, 65536, 262144)]))
+        del _na, _rows, _maxe
+    batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
 
     # Optional double buffering, as a streaming worker does: a second device-resident copy of the batch on its own stream.  Steps
     # alternate between the two, and a step is only waited for after the next one is enqueued, so the width kernel of
     # step k+1 runs in the straggler tail of the search kernel of step k (a launch cannot end before its longest search;
     # for most of that time most CUs are idle).  Every step is still one full pass (both kernels) over one 10 M-read batch.
     # Off by default: the headline number is steps strictly one after the other on one batch (--pipeline: +7 %).
-    batches = [batch, nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)] if args.pipeline else [batch]
+    batches = [batch, nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)] if pipeline else [batch]
     n2 = 0
     kms, wms, dms = [], [], []
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         for b in batches:
             b.run()
             n2 = b.sync()
-        if args.pipeline:                                   # un-pipelined launches: the kernels' own durations
+        if pipeline:                                   # un-pipelined launches: the kernels' own durations
             kms.append(batch.last_kernel_ms())
             wms.append(batch.last_width_ms())
             dms.append(batch.last_deep_ms())
-    barrier()
+    barrier(ctx)
     t1 = time.time()
-    for k in range(args.steps):
+    for k in range(steps):
         batches[k % len(batches)].run()
-        if not args.pipeline:
+        if not pipeline:
             n2 = batch.sync()
             kms.append(batch.last_kernel_ms())
             wms.append(batch.last_width_ms())
             dms.append(batch.last_deep_ms())
         elif k >= 1:
             n2 = max(n2, batches[(k - 1) % 2].sync())
-    if args.pipeline:
-        n2 = max(n2, batches[(args.steps - 1) % 2].sync())
+    if pipeline:
+        n2 = max(n2, batches[(steps - 1) % 2].sync())
         if not kms:
-            kms, wms = [batches[(args.steps - 1) % 2].last_kernel_ms()], [batches[(args.steps - 1) % 2].last_width_ms()]
-            dms = [batches[(args.steps - 1) % 2].last_deep_ms()]
-    barrier()
-    elapsed = time.time() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            kms, wms = [batches[(steps - 1) % 2].last_kernel_ms()], [batches[(steps - 1) % 2].last_width_ms()]
+            dms = [batches[(steps - 1) % 2].last_deep_ms()]
+    barrier(ctx)
+    elapsed = max_over_ranks(ctx, time.time() - t1)
     checksum, n_rows = batch.checksum()
     # the rows of the TIMED run, for the comparison with the CPU (the untimed instrumented run below overwrites the batch's results;
     # until round 2 the comparison read those by mistake)
-    timed_rows = batch.fetch_flat() if want_cpu else None
+    timed_rows = batch.fetch_flat() if ctx.want_cpu else None
 
     e2e = None
     if want_e2e:
-        e2e = e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, want_cpu)
+        e2e = e2e_leg(ctx, G, opt, seq, rseq, off, read_len)
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (fm_search, first pass): algorithmic bytes / event time
         t_search, t_width = (0, 0) if quick else batch.count_touches()
         instrumented_same = True if quick else batch.checksum() == (checksum, n_rows)      # the untimed touch-counting run (tables and text mode off) must give the same rows
         if not instrumented_same:
-            log("WARNING: the instrumented run's rows differ from the timed run's (checksum %016x / %d rows vs %016x / %d)" % (batch.checksum() + (checksum, n_rows)))
-        half_reads = (int(off[-1]) + args.reads) // 2
+            log("ERROR: the instrumented run's rows differ from the timed run's (checksum %016x / %d rows vs %016x / %d): no roofline figure is reported"
+                % (batch.checksum() + (checksum, n_rows)))
+        half_reads = (int(off[-1]) + n_reads) // 2
         s_ms, w_ms, d_ms = float(np.mean(kms)), float(np.mean(wms)), float(np.mean(dms)) if dms else 0.0
         # bwt_match_gap runs in two kernels: S (one read per lane) and, for the searches S hands on (arena outgrown / still running
         # after NABWA_TRIP_BUDGET trips), D (one read per wavefront).  Their event times add up to the search time of a pass.
         k_ms = s_ms + d_ms
-        # the committed counter pass was taken on the headline workload: its bytes say nothing about any other
-        headline = (not args.adna and not args.repeats and n == GRCH38_LEN and args.reads == 10_000_000 and args.read_len == 100
-                    and args.sub_ppm == 2000 and args.indel_ppm == 0)
         deep = d_ms > s_ms                      # deep searches (--adna): most of the work is kernel D's
         # dominant kernel = fm_search (bwt_match_gap): its own algorithmic bytes / its own event time
         bytes_alg = 48 * t_search + half_reads + 16 * n_rows
         bytes_w = 48 * t_width + half_reads
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic() if headline else (pmc_traffic(True) if (args.adna and n == GRCH38_LEN and args.reads == 1_000_000) else None),
+        full = n == GRCH38_LEN and read_len == (76 if adna else 100) and sub_ppm == (10000 if adna else 2000) and indel_ppm == 0
+        traffic = pmc_traffic(kind, n_reads) if full else None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2) if instrumented_same else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5) if instrumented_same else None,
+                    "traffic": traffic,
                     "kernel": ("fm_deep_kernel (one search per wavefront) + fm_search_kernel<false,false> before it" if deep else
                                "fm_search_kernel<false,false> (one read per lane) + fm_deep_kernel for the searches it hands on"),
                     "kernel_ms": round(k_ms, 3), "search_kernel_ms": round(s_ms, 3), "deep_kernel_ms": round(d_ms, 3),
-                    "note": "achieved = the REFERENCE algorithm's bucket bytes / kernel time (an effective rate: the interval tables and text mode skip most of those touches); traffic = HBM bytes the counters saw",
-                    "bytes_per_read": round(bytes_alg / args.reads, 1),
-                    "bucket_touches_per_read": round(t_search / args.reads, 1),
+                    "note": "achieved = the REFERENCE algorithm's bucket bytes / kernel time (an effective rate: the interval tables and text mode skip most of those touches); "
+                            "traffic = HBM bytes per launch the counters saw in the committed pass of this kernel version (profiles/), null where none was taken",
+                    "bytes_per_read": round(bytes_alg / n_reads, 1),
+                    "bucket_touches_per_read": round(t_search / n_reads, 1),
                     "width_kernel": {"kernel": "fm_width_kernel<false>", "kernel_ms": round(w_ms, 3),
                                      "achieved": round(bytes_w / (w_ms * 1e-3) / 1e9, 2),
                                      "frac": round(bytes_w / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                     "bucket_touches_per_read": round(t_width / args.reads, 1)},
+                                     "bucket_touches_per_read": round(t_width / n_reads, 1)},
                     "both_kernels": {"ms": round(k_ms + w_ms, 3),
                                      "achieved": round((bytes_alg + bytes_w) / ((k_ms + w_ms) * 1e-3) / 1e9, 2),
                                      "frac": round((bytes_alg + bytes_w) / ((k_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         cpu = None
         bit_exact = None
-        if want_cpu:
-            cpu, bit_exact = cpu_baseline(T, host_bwt, opt, seq, rseq, off, timed_rows, args)
-        reads_per_s = args.reads * world * args.steps / elapsed
-        what = "50-76 bp damaged SE, ancient-DNA options" if args.adna else "%d bp SE" % args.read_len
-        out = {"metric": "aligned reads/s to GRCh38 (%s), FM-index search (bwa_cal_sa_reg_gap)%s" % (
-                   what, ", bit-exact vs CPU" if bit_exact else (", CPU sample DIFFERS" if bit_exact is False else ", CPU comparison not run")),
-               "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        if ctx.want_cpu:
+            cpu, bit_exact = cpu_baseline(T, G.host_bwt, opt, seq, rseq, off, timed_rows, cpu_seconds if world == 1 else min(cpu_seconds, 3.0))
+            if world > 1:
+                cpu = None          # reported at N = 1 only: at N > 1 the host cores belong to the ranks (the sample check above stays)
+        reads_per_s = n_reads * world * steps / elapsed
+        what = "50-76 bp damaged SE, ancient-DNA options" if adna else "%d bp SE" % read_len
+        out = {"metric": "aligned reads/s to GRCh38 (%s), FM-index search (bwa_cal_sa_reg_gap)%s%s" % (
+                   what, ", bit-exact vs CPU" if bit_exact else (", CPU sample DIFFERS" if bit_exact is False else ", CPU comparison not run"),
+                   "" if instrumented_same else ", INSTRUMENTED RUN DIFFERS (no roofline figure)"),
+               "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                "config": {"workload": (("GRCh38-sized synthetic genome (%d bp) with repeat families (60 k LINE-like copies of a 6 kb consensus at 3-20%% divergence, 1 M Alu-like copies "
-                                       "of a 300 bp consensus at 10-15%%, every tenth at 1-3%%, 200 k tandem repeats), " % n) if args.repeats else
+                                       "of a 300 bp consensus at 10-15%%, every tenth at 1-3%%, 200 k tandem repeats), " % n) if G.repeats else
                                       ("GRCh38-sized synthetic genome (%d bp, uniform ACGT + 2000 planted 5 kb repeats), " % n))
                                       + ("%d SE reads/GPU of 50-76 bases with terminal deamination + 1%% subs (SURVEY 8d C5), "
-                                         "gap_opt_t of -n 0.01 -o 2 -l 16500, index replicated per GPU" % args.reads if args.adna else
+                                         "gap_opt_t of -n 0.01 -o 2 -l 16500, index replicated per GPU" % n_reads if adna else
                                          "%d x %d bp SE reads/GPU at %.1f%% subs, default gap_opt_t, index replicated per GPU"
-                                         % (args.reads, args.read_len, args.sub_ppm / 1e4)),
-                          "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_len": n,
+                                         % (n_reads, read_len, sub_ppm / 1e4)),
+                          "reads_per_gpu": n_reads, "read_len": read_len, "genome_len": n,
                           "parallelism": "reads sharded x%d, index replicated" % world,
-                          "pipelining": "steps alternate between two device-resident batches on two streams" if args.pipeline else "none",
+                          "pipelining": "steps alternate between two device-resident batches on two streams" if pipeline else "none",
                           "single_batch_ms": round(k_ms + w_ms, 3),
-                          "second_pass_reads": n2, "hits": n_rows, "hit_rows_per_read": round(n_rows / args.reads, 4), "checksum": "%016x" % checksum,
-                          "bit_exact_vs_cpu_sample": bit_exact, "instrumented_run_same_rows": instrumented_same,
-                          "pcie_inclusive_reads_per_s": round(n_pc / t_pcie, 1),
-                          "pcie_inclusive_first_call_reads_per_s": round(n_pc / t_pcie_first, 1)},
-               "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e}
+                          "second_pass_reads": n2, "hits": n_rows, "hit_rows_per_read": round(n_rows / n_reads, 4), "checksum": "%016x" % checksum,
+                          "bit_exact_vs_cpu_sample": bit_exact, "instrumented_run_same_rows": instrumented_same},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if primary:
+            out["config"]["pcie_inclusive_reads_per_s"] = round(n_pc / t_pcie, 1)
+            out["config"]["pcie_inclusive_first_call_reads_per_s"] = round(n_pc / t_pcie_first, 1)
+            out["e2e"] = e2e
     for b in batches:
         b.close()
-    ix.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
-        print(json.dumps(out), flush=True)
+    return out
 
 
 def quick_env():
@@ -294,14 +397,17 @@ def ref_full_index(T, host_bwt, host_sa, pac, n):
     return ref, rix
 
 
-def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, want_cpu):
+def e2e_leg(ctx, G, opt, seq, rseq, off, L):
     """End to end on the first e2e_reads reads of the batch: unaligned BAM records in host memory -> the library's batch front-end
     (record parsing, tag erase, bam1_to_seq, FM search, posn_singleton on the drand48 stream, bwt_sa batch, refinement, MD/NM,
     bwa_update_bam1) -> aligned BAM records in host memory.  No BGZF on either side (the reference's bgzf.c is host I/O).
-    A sample is checked against the reference's own bwa_aln2seq_core / bwa_cal_pac_pos_core on the reference's search rows."""
+    Every rank runs its own batch (its shard's reads); the rate is all ranks' reads over the slowest rank's time.  On rank 0 a sample
+    is compared, field by field incl. CIGAR / NM / MD, with the reference's own chain (bwa_cal_sa_reg_gap -> bwa_aln2seq_core ->
+    bwa_cal_pac_pos_core -> bwa_refine_gapped) on the same reads, and that chain's time on the host threads is the leg's CPU baseline."""
     import struct
+    args, nabwa, T, n = ctx.args, ctx.nabwa, ctx.T, G.n
+    ix, pac = G.ix, G.pac
     n_e = min(args.e2e_reads, len(off) - 1)
-    L = args.read_len
     rec_len = 36 + 10 + (L + 1) // 2 + L
     rec = np.zeros((n_e, rec_len), np.uint8)
     rec[:, 0:4] = np.frombuffer(struct.pack("<I", rec_len - 4), np.uint8)
@@ -329,6 +435,7 @@ def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, 
     Lb.nabwa_bam_batch_destroy.argtypes = [P]
     Lb.nabwa_isize_table_destroy.argtypes = [P]
     po = nabwa.pe_opt_default()
+
     def once():
         tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
         st = C.c_uint64(nabwa.srand48_state(11))
@@ -352,63 +459,94 @@ def e2e_leg(args, nabwa, T, ix, opt, seq, rseq, off, host_bwt, host_sa, pac, n, 
         return np.diff(t), ob, oo, nb
 
     dt_first, _, _, _ = once()              # the first batch of a size pays for its working buffers (device pool, host records)
+    barrier(ctx)
+    t0 = time.time()
     dt, ob, oo, nb = once()                 # what a streaming caller sees from then on
-    exact, n_chk = None, 0
-    if want_cpu:
-        ref, rix = ref_full_index(T, host_bwt, host_sa, pac, n)
+    barrier(ctx)
+    elapsed = max_over_ranks(ctx, time.time() - t0)
+    if ctx.rank != 0:
+        return None
+    exact, n_chk, cpu = None, 0, None
+    if ctx.want_cpu:
+        ref, rix = ref_full_index(T, G.host_bwt, G.host_sa, pac, n)
         if ref is not None:
             import bamlib
-            n_chk = min(n_e, 20000)
+            cores = cpu_threads()
+            n_chk = min(n_e, int(os.environ.get("NABWA_BENCH_E2E_SAMPLE", "100000")))
             copt = T.GapOpt()
             C.memmove(C.byref(copt), C.byref(opt), 64)
             ref.ref_cal_sa_reg_gap_mt.restype = C.c_long
             ref.ref_cal_sa_reg_gap_mt.argtypes = [P, P, C.c_int, P, P, P, C.c_int, P, P, C.c_long]
-            ref.ref_aln2pos_se.argtypes = [P, P, C.c_int, C.c_int, P, C.c_int, P, P]
+            ref.ref_se_chain_mt.argtypes = [P, P, C.c_int, C.c_int, P, P, P, P, P, C.c_int, P, P, P, C.c_int, P]
             na = np.zeros(n_chk, np.int32)
             rows = np.zeros(64 * n_chk + 4096, T.ALN_DT)
             o = np.ascontiguousarray(off[:n_chk + 1])
-            assert ref.ref_cal_sa_reg_gap_mt(rix, C.byref(copt), n_chk, T.ptr(o), T.ptr(seq), T.ptr(rseq), 16, T.ptr(na), T.ptr(rows), len(rows)) >= 0
-            bnd = np.concatenate([[0], np.cumsum(na)])
-            dec = bamlib.decode(ob, oo[:n_chk + 1], ["synth%d" % (k + 1) for k in range(16)])
+            t_s = time.time()
+            assert ref.ref_cal_sa_reg_gap_mt(rix, C.byref(copt), n_chk, T.ptr(o), T.ptr(seq), T.ptr(rseq), cores, T.ptr(na), T.ptr(rows), len(rows)) >= 0
+            t_s = time.time() - t_s
+            f = np.zeros((n_chk, 16), np.int64)
+            cg = np.zeros((n_chk, 64), np.uint16)
+            MDC = 256
+            md = np.zeros((n_chk, MDC), np.uint8)
+            secs = (C.c_double * 2)()
             ref.ref_seed48(11)
-            f, mu = np.zeros(12, np.int64), np.zeros(64, np.int64)
+            ref.ref_se_chain_mt(rix, C.byref(copt), po.max_occ_se, n_chk, T.ptr(o), T.ptr(seq), T.ptr(rseq), T.ptr(na), T.ptr(rows), cores,
+                                T.ptr(f), T.ptr(cg), T.ptr(md), MDC, secs)
+            dec = bamlib.decode(ob, oo[:n_chk + 1], ["synth%d" % (k + 1) for k in range(16)])
             exact = True
+            n_bad = 0
             for i in range(n_chk):
-                r = np.ascontiguousarray(rows[bnd[i]:bnd[i + 1]])
-                ref.ref_aln2pos_se(rix, C.byref(copt), L, len(r), T.ptr(r), po.max_occ_se, T.ptr(f), T.ptr(mu))
-                g = dec[i]
-                if f[0] == 0:
+                g, fi = dec[i], f[i]
+                if fi[0] == 0:
                     ok = bool(g["flag"] & 4) and g["rname"] == "*"
                 else:
                     tg = g["tags"]
                     cid = int(g["rname"][5:]) - 1
-                    ok = (g["pos"] + n * cid // 16 == f[9] + 1 and bool(g["flag"] & 16) == bool(f[1]) and (g["mapq"] == f[10] or bool(g["flag"] & 4))
-                          and tg["X0"] == f[7] and tg.get("X1", f[8]) == f[8] and tg["XM"] == f[2] and tg["XO"] == f[3])
+                    bridging = bool(g["flag"] & 4)
+                    ncg = int(fi[12])
+                    cig = "".join("%d%s" % (c & 0x3fff, "MIDS"[c >> 14]) for c in cg[i, :ncg]) if ncg else "%dM" % fi[14]
+                    mds = bytes(md[i]).split(b"\0", 1)[0].decode()
+                    ok = (g["pos"] + n * cid // 16 == fi[9] + 1 and bool(g["flag"] & 16) == bool(fi[1]) and (g["mapq"] == fi[10] or bridging)
+                          and tg["X0"] == fi[7] and tg.get("X1", fi[8]) == fi[8] and tg["XM"] == fi[2] and tg["XO"] == fi[3] and tg["XG"] == fi[3] + fi[4]
+                          and (bridging or (g["cigar"] == cig and tg["NM"] == fi[13] and tg["MD"] == mds and tg["XT"] == " URM"[fi[0]])))
+                if not ok:
+                    n_bad += 1
+                    if n_bad <= 3:
+                        log("e2e sample: record %d differs: %s vs reference %s" % (i, g, fi.tolist()))
                 exact = exact and bool(ok)
+            t_cpu = t_s + secs[0] + secs[1]
+            cpu = {"value": round(n_chk / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
+                   "sample": "first %d reads of the same batch through the reference's own functions: bwa_cal_sa_reg_gap on %d threads (%.2f s), posn_singleton serial "
+                             "on the one drand48 stream (%.2f s), bwa_refine_gapped on %d threads (%.2f s); BAM parsing and bwa_update_bam1 not included (bam2bam.c needs <zmq.h>)"
+                             % (n_chk, cores, t_s, secs[0], cores, secs[1])}
+            if ctx.world > 1:
+                cpu = None
     return {"what": "unaligned BAM records in host memory -> aligned BAM records in host memory (nabwa_bam_batch_*: the whole of bam2bam's two passes for single-end records, without BGZF)",
-            "reads": n_e, "reads_per_s": round(n_e / dt.sum(), 1), "first_batch_reads_per_s": round(n_e / dt_first.sum(), 1), "bam_bytes_out": int(nb.value),
+            "reads": n_e, "n_gpus": ctx.world, "reads_per_s": round(n_e * ctx.world / elapsed, 1), "first_batch_reads_per_s": round(n_e / dt_first.sum(), 1), "bam_bytes_out": int(nb.value),
             "stage_ms": {"parse + erase tags + bam1_to_seq": round(dt[0] * 1e3, 1), "pass 1: search (upload, kernels W / S / D, rows back) + posn_singleton": round(dt[1] * 1e3, 1),
                          "pass 2: bwa_refine_gapped + MD/NM + bwa_update_bam1": round(dt[2] * 1e3, 1), "records out": round(dt[3] * 1e3, 1)},
-            "bit_exact_vs_reference_sample": exact, "sample_reads": n_chk}
+            "bit_exact_vs_reference_sample": exact, "sample_reads": n_chk,
+            "sample_fields": "flag, contig, position, strand, MAPQ, CIGAR, NM, MD, XT, X0, X1, XM, XO, XG", "cpu_baseline": cpu}
 
 
-def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backend, host_bwt, host_sa, pac, want_cpu):
+def cpu_threads():
+    # the GPU box gives one GPU's job a share of 16 host threads (pool-sizing rule of the box); NABWA_BENCH_CPU_THREADS overrides
+    return min(len(os.sched_getaffinity(0)), int(os.environ.get("NABWA_BENCH_CPU_THREADS", "16")))
+
+
+def pe_workload(ctx, G, N, steps, warmup, cpu_seconds):
     """BASELINE config 3: the paired-end path.  One step = both ends searched (kernels W / S / D on 2 N reads, resident), the
     rows fetched, posn_pair on the host's drand48 stream + bwt_sa batch, the insert-size estimate from the histogram
     (infer_isize_hist), finish_pair (pairing, mate rescue and gap refinement as GPU batches).  value = pairs/s."""
-    import torch
-    N, L = args.pairs, 150
-    seq, rseq, off = synth.synth_pairs(d_text, n, N, L, 20000, 100000, 400.0, 40.0, 3 + 1000 * rank, device=dev)
+    nabwa, synth, T = ctx.nabwa, ctx.synth, ctx.T
+    rank, world, dev, ix, n = ctx.rank, ctx.world, ctx.dev, G.ix, G.n
+    L = 150
+    seq, rseq, off = synth.synth_pairs(G.d_text, n, N, L, 20000, 100000, 400.0, 40.0, 3 + 1000 * rank, device=dev)
     opt = nabwa.gap_init_opt()
     po = nabwa.pe_opt_default()
     full = np.full(2 * N, L, np.int32)
     batch = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
     rec_buf = (nabwa.PeRec * (2 * N))()          # the per-end records (3 KB each), allocated once as a streaming caller would
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def step():
         t = [time.time()]
@@ -427,44 +565,45 @@ def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backen
         t.append(time.time())
         return recs, ii, n2, (n_aln, rows), np.diff(t), (tot, mp), (batch.last_kernel_ms(), batch.last_width_ms(), batch.last_deep_ms())
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
+    barrier(ctx)
     t1 = time.time()
     splits, kms = [], []
-    for _ in range(args.steps):
+    for _ in range(steps):
         recs, ii, n2, hits, dt, sw, km = step()
         splits.append(dt)
         kms.append(km)
-    barrier()
-    elapsed = time.time() - t1
-    if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    barrier(ctx)
+    elapsed = max_over_ranks(ctx, time.time() - t1)
     if rank != 0:
         batch.close()
         return None
     sp = np.mean(splits, axis=0) * 1e3
-    t_search, t_width = (0, 0) if quick_env() else batch.count_touches()
-    s_ms, w_ms, d_ms = [float(x) for x in np.mean(kms, axis=0)]
     checksum, n_rows = batch.checksum()
+    t_search, t_width = (0, 0) if quick_env() else batch.count_touches()
+    instrumented_same = True if quick_env() else batch.checksum() == (checksum, n_rows)
+    s_ms, w_ms, d_ms = [float(x) for x in np.mean(kms, axis=0)]
     bytes_alg = 48 * t_search + N * L + 16 * n_rows
     k_ms = s_ms + d_ms
-    roofline = {"bound": "hbm", "achieved": round(bytes_alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+    roofline = {"bound": "hbm", "achieved": round(bytes_alg / (k_ms * 1e-3) / 1e9, 2) if instrumented_same else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if instrumented_same else None,
+                "traffic": pmc_traffic("pe", N) if n == GRCH38_LEN else None,
                 "kernel": "fm_search_kernel<false,false> + fm_deep_kernel (bwt_match_gap of both ends)", "kernel_ms": round(k_ms, 3),
                 "search_kernel_ms": round(s_ms, 3), "deep_kernel_ms": round(d_ms, 3), "width_kernel_ms": round(w_ms, 3),
                 "bytes_per_read": round(bytes_alg / (2 * N), 1), "bucket_touches_per_read": round(t_search / (2 * N), 1),
                 "note": "the FM search is the dominant GPU kernel of the step; the finishing chain is host-bound (stage_ms)"}
     cpu, exact = None, None
-    if want_cpu:
-        cpu, exact = pe_cpu_baseline(args, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, off, hits, recs, ii, L)
+    if ctx.want_cpu:
+        cpu, exact = pe_cpu_baseline(N, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), nabwa, T, G.host_bwt, G.host_sa, G.pac, n, opt, seq, rseq, off, hits, recs, ii, L)
+        if world > 1:
+            cpu = None
     tp = np.frombuffer(recs, np.uint8).reshape(2 * N, C.sizeof(nabwa.PeRec))[:, nabwa.PeRec.se.offset + nabwa.SeRec.type.offset]
-    out = {"metric": "aligned pairs/s to GRCh38 (2 x 150 bp PE at 2%% error), search + posn_pair + insert-size estimate + finish_pair%s"
-                     % (", bit-exact vs CPU" if exact else (", CPU sample DIFFERS" if exact is False else ", CPU comparison not run")),
-           "value": round(N * world * args.steps / elapsed, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    out = {"metric": "aligned pairs/s to GRCh38 (2 x 150 bp PE at 2%% error), search + posn_pair + insert-size estimate + finish_pair%s%s"
+                     % (", bit-exact vs CPU" if exact else (", CPU sample DIFFERS" if exact is False else ", CPU comparison not run"),
+                        "" if instrumented_same else ", INSTRUMENTED RUN DIFFERS (no roofline figure)"),
+           "value": round(N * world * steps / elapsed, 1), "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u32", "data": "synthetic",
            "config": {"workload": "GRCh38-sized synthetic genome (%d bp), %d pairs/GPU of 2 x %d bp, 2%% substitutions, 10%% of the reads with a 1-base indel, "
                                   "inserts ~ N(400, 40), default gap_opt_t / pe_opt_t (BASELINE config 3 at %d of its 10 M pairs per step)" % (n, N, L, N),
@@ -474,17 +613,18 @@ def pe_main(args, nabwa, synth, T, ix, d_text, n, dev, rank, world, dist, backen
                                    "finish_pair (pairing, mate rescue, refinement, MD)": round(float(sp[4]), 1)},
                       "isize": [ii.avg, ii.std, ii.low, ii.high, ii.high_bayesian], "mate_rescued": int(sw[1][0]), "rescue_attempts": int(sw[0][0]),
                       "mapped_ends": int((tp != 0).sum()), "second_pass_reads": n2, "hits": n_rows, "checksum": "%016x" % checksum,
-                      "bit_exact_vs_cpu_sample": exact},
+                      "bit_exact_vs_cpu_sample": exact, "instrumented_run_same_rows": instrumented_same},
            "roofline": roofline, "cpu_baseline": cpu}
     batch.close()
+    del rec_buf
     return out
 
 
-def pe_cpu_baseline(args, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, off, hits, recs, ii, L):
+def pe_cpu_baseline(n_pairs, cpu_seconds, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, off, hits, recs, ii, L):
     """the reference's own functions on a bounded sample of the same pairs: bwa_cal_sa_reg_gap of both ends on all host threads
     (ref_cal_sa_reg_gap_mt), then posn_pair serially and finish_pair on all threads (ref_pe_chain_mt); the GPU records of the
     sample are compared field for field"""
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("NABWA_BENCH_CPU_THREADS", "16")))
+    cores = cpu_threads()
     ref, rix = ref_full_index(T, host_bwt, host_sa, pac, n)
     if ref is None:
         return None, None
@@ -511,7 +651,7 @@ def pe_cpu_baseline(args, nabwa, T, host_bwt, host_sa, pac, n, opt, seq, rseq, o
 
     pilot = 64 * cores
     dt, _, _ = search(pilot)
-    n_s = int(min(args.pairs, max(pilot, pilot / max(dt, 1e-3) * args.cpu_seconds * 0.7)))
+    n_s = int(min(n_pairs, max(pilot, pilot / max(dt, 1e-3) * cpu_seconds * 0.7)))
     t_search, na, rows = search(n_s)
     g_na, g_rows = hits
     b0 = np.concatenate([[0], np.cumsum(na)])
@@ -577,27 +717,35 @@ def adna_profile(seq, n_reads, L, seed):
     return np.ascontiguousarray(s), np.ascontiguousarray(r), off
 
 
-def pmc_traffic(adna=False):
-    """HBM bytes of one search-kernel launch from the committed counter pass of this kernel version (profiles/:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc.sh -> profiles/r02_pmc.json; both are 64-byte fabric requests
-    for this kernel's 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when the
-    file is missing -- counters cannot be collected from inside the timed run."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_adna.json" if adna else "r02_pmc.json")
+def pmc_traffic(kind, units):
+    """HBM bytes of one launch of the workload's dominant kernel from the committed counter pass of this kernel version (profiles/:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/collect_pmc*.sh; both are 64-byte fabric requests
+    for these kernels' 64-byte gathers and 16-byte stores, so no gfx950 half-rate correction applies).  None when there is no pass
+    for this workload at this size -- counters cannot be collected from inside the timed run."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     if any(k in os.environ for k in ("NABWA_KMER_T", "NABWA_TEXT_MODE", "NABWA_TRIP_BUDGET")):
         return None                                          # not the configuration the counter pass was taken on
-    try:
-        d = json.load(open(f))["D" if adna else "S"]        # the dominant kernel: S on the headline workload, D on the ancient-DNA one
-        return round((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, 0)
-    except Exception:
-        return None
+    for name in PMC_FILES.get(kind, ()):
+        try:
+            d = json.load(open(os.path.join(here, name)))
+            if int(d.get("units", units)) != int(units):
+                continue
+            k = d[d.get("dominant", "D" if kind != "headline" else "S")]     # the dominant kernel: S on the headline workload, D on the deep ones
+            return round((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, 0)
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(T, host_bwt, opt, seq, rseq, off, timed_rows, args):
+# newest first; a file may name the launch size it was taken at ("units") and its dominant kernel ("dominant")
+PMC_FILES = {"headline": ("r03_pmc.json", "r02_pmc.json"), "adna": ("r03_pmc_adna.json",), "pe": ("r03_pmc_pe.json",), "repeats": ("r03_pmc_repeats.json",)}
+
+
+def cpu_baseline(T, host_bwt, opt, seq, rseq, off, timed_rows, cpu_seconds):
     """The reference's own bwa_cal_sa_reg_gap (oracle/_ref, compiled from /root/reference) on all host
     cores over a bounded sample of the same reads; falls back to the CPU restatement ("port") when the
     compiled reference did not travel.  Also checks the GPU rows of the sample bit-for-bit."""
-    # the GPU box gives one GPU's job a share of 16 host threads (pool-sizing rule of the box); NABWA_BENCH_CPU_THREADS overrides
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("NABWA_BENCH_CPU_THREADS", "16")))
+    cores = cpu_threads()
     ref = T.load_ref()
     n_all = len(off) - 1
     got, _ = None, None
@@ -635,7 +783,7 @@ def cpu_baseline(T, host_bwt, opt, seq, rseq, off, timed_rows, args):
         kind = "port"
     pilot = min(n_all, 256 * cores)
     dt, _, _ = run(pilot, cores)
-    n_s = int(min(n_all, max(pilot, pilot / max(dt, 1e-3) * args.cpu_seconds)))
+    n_s = int(min(n_all, max(pilot, pilot / max(dt, 1e-3) * cpu_seconds)))
     dt, n_aln, rows = run(n_s, cores)
     log("cpu baseline (%s): %d reads on %d threads in %.2f s" % (kind, n_s, cores, dt))
     # parity of the GPU rows (of the timed run) for the sample

@@ -84,6 +84,7 @@ struct BgzfOut {
 };
 
 #include "bgzf_in.hpp"
+#include "bam_header.hpp"
 
 /* a bounded queue between two threads */
 template <class T> struct Chan {
@@ -94,30 +95,7 @@ template <class T> struct Chan {
 	void close() { std::unique_lock<std::mutex> l(m); closed = true; cv.notify_all(); }
 };
 
-/* ---------------------------------------------------------------- the header (bam2bam.c:164-301) */
-static void find_pp_tag(const std::string &h, std::string &pp, std::string &id, bool &has_pp)
-{
-	std::set<std::string> present, linked;
-	size_t p = 0;
-	while (p < h.size()) {
-		size_t e = h.find('\n', p); if (e == std::string::npos) e = h.size();
-		if (h.compare(p, 3, "@PG") == 0) {
-			size_t q = p;
-			while (q < e) {
-				size_t fe = h.find('\t', q); if (fe == std::string::npos || fe > e) fe = e;
-				if (fe - q > 3 && h[q + 2] == ':' && ((h[q] == 'I' && h[q + 1] == 'D') || (h[q] == 'P' && h[q + 1] == 'P')))
-					(h[q] == 'I' ? present : linked).insert(h.substr(q + 3, fe - q - 3));
-				q = fe + 1;
-			}
-		}
-		p = e + 1;
-	}
-	has_pp = false;
-	for (const auto &x : present) if (!linked.count(x)) { pp = x; has_pp = true; break; }
-	id = "bwa";
-	for (int n = 1; present.count(id); ++n) id = "bwa-" + std::to_string(n);
-}
-
+/* ---------------------------------------------------------------- the header (bam2bam.c:164-301); find_pp_tag: bam_header.hpp */
 static std::string header_text(nabwa_index_t *ix, const std::string &old, int argc, char **argv)
 {
 	std::string pp, id; bool has_pp;
@@ -193,6 +171,10 @@ int main(int argc, char **argv)
 		}
 	}
 	if (opte > 0) { go.max_gape = opte; go.mode &= ~NABWA_MODE_GAPE; }
+	/* the library's limits, said before the index is loaded */
+	if (po.max_occ_se < 0 || po.max_occ_se > NABWA_MAX_MULTI - 1) { fprintf(stderr, "[nabwa_bam2bam] -D %d: at most %d other hits of a single read are listed\n", po.max_occ_se, NABWA_MAX_MULTI - 1); return 1; }
+	if (po.n_multi < 0 || po.n_multi > NABWA_MAX_MULTI || po.N_multi < 0 || po.N_multi > NABWA_MAX_MULTI) { fprintf(stderr, "[nabwa_bam2bam] -h / -H: 0..%d\n", NABWA_MAX_MULTI); return 1; }
+	if (go.s_mm < 1 || go.s_gapo < 1 || go.s_gape < 1) { fprintf(stderr, "[nabwa_bam2bam] -M / -O / -E must be at least 1\n"); return 1; }
 	if (optind + 1 > argc || !prefix) {
 		fprintf(stderr, "\nUsage:   nabwa_bam2bam -g PREFIX [options of bwa bam2bam] [-f out.bam] <in.bam>\n\n");
 		return 1;
@@ -274,6 +256,10 @@ int main(int argc, char **argv)
 			if (!in.read(&buf[at + 4], bs)) die(argv[optind], "truncated record");
 			uint32_t z; memcpy(&z, &buf[at + 16], 4);
 			const bool paired = (z >> 16) & 1;
+			{	/* the name is read as a C string below and by the library: it must lie, terminated, inside the record */
+				const uint32_t l_qname = buf[at + 12];
+				if (l_qname == 0 || bs < 32 + l_qname || buf[at + 36 + l_qname - 1] != 0) die(argv[optind], "damaged record (read name not terminated inside the record)");
+			}
 			cur.off.push_back((int64_t)buf.size());
 			/* read_bam_pair_core's view of the stream (bwaseqio.c:345-410): a paired read takes the next record as its mate if the names
 			 * agree; if they do not it is a lone mate (an error, or dropped with --broken-input) and the next record starts afresh */
@@ -386,7 +372,13 @@ int main(int argc, char **argv)
 	out.close();
 	nabwa_isize_table_destroy(tab);
 	for (nabwa_index_t *p : ixs) nabwa_index_destroy(p);
-	/* final_rename (utils.c:159-173): "out.bam_" becomes "out.bam" once it is complete */
-	if (ofile) { const size_t l = strlen(ofile); if (l > 1 && ofile[l - 1] == '_') { std::string to(ofile, l - 1); if (rename(ofile, to.c_str()) != 0) die(ofile, "cannot rename"); } }
+	/* final_rename (utils.c:159-173): every trailing '_' goes ("out.bam__" becomes "out.bam") once the file is complete -- unless nothing
+	 * would be left of the name or of its last path component */
+	if (ofile) {
+		size_t e = strlen(ofile);
+		const size_t l = e;
+		while (e > 0 && ofile[e - 1] == '_') --e;
+		if (e > 0 && ofile[e - 1] != '/' && e < l) { std::string to(ofile, e); fprintf(stderr, "[nabwa_bam2bam] finished, renaming %s to %s.\n", ofile, to.c_str()); if (rename(ofile, to.c_str()) != 0) die(ofile, "cannot rename"); }
+	}
 	return 0;
 }

@@ -213,6 +213,7 @@ static bool parse_rec(const uint8_t *p, int64_t len, BamRec &r, uint8_t *room)  
 	r.bin = y >> 16; r.mapq = y >> 8 & 0xff; r.l_qname = y & 0xff; r.flag = z >> 16; r.n_cigar = z & 0xffff;
 	r.data.place(room, (size_t)(len - 36) + REC_ROOM, p + 36, (size_t)(len - 36));
 	if (r.l_qseq < 0 || r.off_aux() > r.data.size() || r.l_qname == 0) return false;
+	if (r.data.data()[r.l_qname - 1] != 0) return false;        /* the name is compared as a C string (mates, bwaseqio.c:366): it must end inside l_qname */
 	return true;
 }
 
@@ -472,6 +473,10 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 	if (!ix || !opt || !popt || !out || n_rec < 0 || (n_rec && (!in || !in_off))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (flags & ~(uint32_t)NABWA_BAM_ALL_FLAGS) return nabwa_fail(NABWA_EINVAL, "unknown NABWA_BAM_* flag");
 	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
+	/* limits of the record format, refused here and not after the search: the other hits of a singleton (bam2bam.c:629) fill a fixed list */
+	if (popt->max_occ_se < 0 || popt->max_occ_se + 1 > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "max_occ_se (-D) outside 0..15");
+	if (popt->n_multi < 0 || popt->N_multi < 0 || popt->n_multi > NABWA_MAX_MULTI || popt->N_multi > NABWA_MAX_MULTI) return nabwa_fail(NABWA_EINVAL, "n_multi / N_multi outside 0..16");
+	if (opt->s_mm < 1 || opt->s_gapo < 1 || opt->s_gape < 1) return nabwa_fail(NABWA_EINVAL, "s_mm, s_gapo and s_gape must be >= 1 (-M / -O / -E 0 are not supported)");
 	nabwa_bam_batch *b = new nabwa_bam_batch();
 	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0; b->flags = flags;
 	const bool timing = getenv("NABWA_TIMING") != 0;

@@ -570,6 +570,9 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	 * option blocks beyond that go to kernel D whole */
 	const bool deep_only = mdx > 14 || mgx > 15 || opt->max_gape > 31 || NS1 > 64;
 	if (opt->seed_len < 0) return fail(NABWA_EINVAL, "negative seed_len");
+	/* refused before any work, not when the first read reaches kernel D in the middle of a file: there a chain's matching child must be
+	 * the only child of its own score (fm_deep_body.hpp), so every penalty has to be positive (-M / -O / -E 0 have no use in practice) */
+	if (opt->s_mm < 1 || opt->s_gapo < 1 || opt->s_gape < 1) return fail(NABWA_EINVAL, "s_mm, s_gapo and s_gape must be >= 1 (-M / -O / -E 0 are not supported)");
 
 	const double tc1 = now();
 	nabwa_batch *b = new nabwa_batch();

@@ -53,12 +53,32 @@ extern "C" int nabwa_pe_posn(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int 
 	return NABWA_OK;
 }
 
+/* finish_pair's position cache (my_hash, bam2bam.c:741-757): the text positions of a hit row of MIN_HASH_WIDTH = 1000 suffixes or more are
+ * computed once per file -- keyed by the row's (k, l) ALONE, with the strand and the read length of the read that brought the row first --
+ * and handed to every later read with the same (k, l) as they are.  A later read of another length on the reverse strand (or, should two
+ * rows of the two indexes ever share their numbers, of the other strand) therefore pairs on positions that are not its own: not a mere
+ * memo, and part of what `bwa bam2bam -t 1` writes.  Positions are a function of (k, l, strand, length), so the cache holds only the
+ * strand and length first seen; rows are entered in record order. */
+#include <unordered_map>
+#define MIN_HASH_WIDTH 1000       /* bwape.h:31 */
+struct nabwa_poscache { std::unordered_map<uint64_t, uint32_t> first; };           /* (k << 32 | l) -> strand bit << 31 | read length */
+extern "C" nabwa_poscache_t *nabwa_poscache_create(void) { return new nabwa_poscache(); }
+extern "C" void nabwa_poscache_destroy(nabwa_poscache_t *c) { delete c; }
+extern "C" int64_t nabwa_poscache_size(const nabwa_poscache_t *c) { return c ? (int64_t)c->first.size() : 0; }
+
 /* one mate-rescue attempt: align end `k` of pair `pair` inside [beg, beg+reglen) next to its mate (bwape.c:562-583) */
 struct SwJob { int pair, k; int64_t beg; int ref_n; bool fwd; };
 
 extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 							   int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
 							   const nabwa_aln1_t *aln, nabwa_pe_t *out, uint64_t n_tot[2], uint64_t n_mapped[2])
+{
+	return nabwa_pe_finish_cached(ix, opt, popt, ii, n_pairs, off, seq, rseq, n_aln, aln, out, n_tot, n_mapped, 0);
+}
+
+extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+									  int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
+									  const nabwa_aln1_t *aln, nabwa_pe_t *out, uint64_t n_tot[2], uint64_t n_mapped[2], nabwa_poscache_t *cache)
 {
 	if (!ix || !opt || !popt || !ii || n_pairs < 0 || (n_pairs && (!off || !seq || !rseq || !n_aln || !out))) return nabwa_fail(NABWA_EINVAL, "null argument");
 	if (!ix->ref) return nabwa_fail(NABWA_EINVAL, "index has no reference attached (nabwa_index_attach_reference)");
@@ -79,7 +99,7 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 	size_t n_hit_rows = 0, n_sw = 0, n_refine = 0, n_cand = 0;
 
 	/* ---- A. pairing: text positions of every hit row of both ends, chunked so one bwt_sa batch stays bounded
-	 *         (bam2bam.c:726-770; the position cache there only memoises bwt_sa and is not needed) */
+	 *         (bam2bam.c:726-770; the position cache there: `cache`, above) */
 	const size_t CHUNK_ROWS = 1u << 25;
 	double ta[3] = { 0, 0, 0 }, tc[4] = { 0, 0, 0, 0 };
 	/* which pairs are paired here -- both ends mapped, neither with more than max_occ hit rows -- and how many rows each brings:
@@ -98,6 +118,33 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 			prow[pr] = (uint32_t)(n_occ[0] + n_occ[1]);
 		}
 	});
+	/* the position cache, in record order: for every wide row of a paired pair the (strand, length) its positions are computed with --
+	 * the row's own when it is the first with its (k, l), else those of the first.  Only rows that end up with other values than their
+	 * own are noted (`foreign`, by row index); wide rows are rare, so the pairs that have one are found by all threads first. */
+	std::unordered_map<size_t, uint32_t> foreign;
+	if (cache) {
+		std::vector<uint8_t> wide((size_t)(n_pairs ? n_pairs : 1), 0);
+		fin_parallel(fin_threads((size_t)n_pairs), (size_t)n_pairs, [&](int, size_t p_lo, size_t p_hi) {
+			for (size_t pr = p_lo; pr < p_hi; ++pr) {
+				if (!prow[pr]) continue;
+				for (size_t r = a_off[2 * pr]; r < a_off[2 * pr + 2]; ++r) if (aln[r].l - aln[r].k + 1 >= MIN_HASH_WIDTH) { wide[pr] = 1; break; }
+			}
+		});
+		for (size_t pr = 0; pr < (size_t)n_pairs; ++pr) {
+			if (!wide[pr]) continue;
+			for (int j = 0; j < 2; ++j)
+				for (size_t r = a_off[2 * pr + j]; r < a_off[2 * pr + j + 1]; ++r) {
+					if (aln[r].l - aln[r].k + 1 < MIN_HASH_WIDTH) continue;
+					const uint32_t mine = (aln[r].info >> 24 & 1) << 31 | (uint32_t)PE(out, pr, j).se.len;
+					auto it = cache->first.emplace((uint64_t)aln[r].k << 32 | aln[r].l, mine).first;
+					if (it->second != mine) foreign[r] = it->second;
+				}
+		}
+	}
+	auto row_strand_len = [&](size_t r, uint32_t own_len, uint32_t &a, uint32_t &len) {      /* what the positions of hit row r are computed with */
+		a = aln[r].info >> 24 & 1; len = own_len;
+		if (!foreign.empty()) { auto it = foreign.find(r); if (it != foreign.end()) { a = it->second >> 31; len = it->second & 0x7fffffffu; } }
+	};
 	for (int p0 = 0; p0 < n_pairs;) {
 		const double tA0 = now();
 		std::vector<uint8_t> which; std::vector<uint32_t> rows; std::vector<size_t> pair_lo; std::vector<int> pairs;
@@ -114,8 +161,10 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 				size_t u = pair_lo[t];
 				for (int j = 0; j < 2; ++j) {
 					const nabwa_aln1_t *A = aln + a_off[2 * (size_t)pr + j];
-					for (int k = 0; k < n_aln[2 * pr + j]; ++k)
-						for (uint32_t l = A[k].k; ; ++l) { which[u] = (A[k].info >> 24 & 1) ? 0 : 1; rows[u] = l; ++u; if (l == A[k].l) break; }
+					for (int k = 0; k < n_aln[2 * pr + j]; ++k) {
+						uint32_t a, len_unused; row_strand_len(a_off[2 * (size_t)pr + j] + k, 0, a, len_unused);
+						for (uint32_t l = A[k].k; ; ++l) { which[u] = a ? 0 : 1; rows[u] = l; ++u; if (l == A[k].l) break; }
+					}
 				}
 			}
 		});
@@ -133,13 +182,14 @@ extern "C" int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, co
 			size_t u = pair_lo[t];
 			for (int j = 0; j < 2; ++j) {
 				const nabwa_aln1_t *A = aln + a_off[2 * (size_t)pr + j];
-				const uint32_t len = (uint32_t)PE(out, pr, j).se.len;
-				for (int k = 0; k < n_aln[2 * pr + j]; ++k)
+				for (int k = 0; k < n_aln[2 * pr + j]; ++k) {
+					uint32_t a, len; row_strand_len(a_off[2 * (size_t)pr + j] + k, (uint32_t)PE(out, pr, j).se.len, a, len);
 					for (uint32_t l = A[k].k; ; ++l, ++u) {
-						const uint64_t x = which[u] == 0 ? sa[u] : rlen - (sa[u] + len);
+						const uint64_t x = (uint64_t)(uint32_t)(which[u] == 0 ? sa[u] : rlen - (sa[u] + len));
 						hits.push_back(x << 32 | (uint64_t)(uint32_t)(k << 1) | (uint64_t)j);
 						if (l == A[k].l) { ++u; break; }
 					}
+				}
 			}
 			nabwa_pe_end_t e[2];
 			for (int j = 0; j < 2; ++j) {

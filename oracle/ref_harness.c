@@ -554,3 +554,79 @@ void ref_pe_chain_mt(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, c
 	}
 	secs[1] = ref_now() - t0;
 }
+
+/* The single-end chain of bam2bam after the search, for bench.py's end-to-end CPU leg: posn_singleton (bam2bam.c:622-641) for
+ * every read in order on the one drand48 stream (serial in the reference too), then the bwa_refine_gapped of finish_singleton
+ * (bam2bam.c:649) on n_threads threads over contiguous shares of the reads.  Every call is the reference's.
+ * f rows (16 per read): type,strand,n_mm,n_gapo,n_gape,score,sa,c1,c2,pos,mapQ,n_multi,n_cigar,nm,len,0 ; cigar rows 64 u16 ; md rows
+ * md_cap chars.  secs = seconds of (posn, refine). */
+typedef struct { ref_index_t *ix; bwa_seq_t *s; int n; } ref_se_job_t;
+static void *ref_se_job(void *a) { ref_se_job_t *J = (ref_se_job_t*)a; bwa_refine_gapped(J->ix->bns, J->n, J->s, J->ix->pac, 0); return 0; }
+void ref_se_chain_mt(ref_index_t *ix, const gap_opt_t *opt, int max_occ_se, int n, const int64_t *off, const uint8_t *seq, const uint8_t *rseq,
+					 const int32_t *n_aln, const uint32_t *aln, int n_threads, int64_t *f, uint16_t *cigar, char *md, int md_cap, double *secs)
+{
+	bwa_seq_t *s = (bwa_seq_t*)calloc(n ? n : 1, sizeof(bwa_seq_t)); int i, j, t; size_t row = 0; double t0;
+	bwase_initialize();
+	for (i = 0; i < n; ++i) {
+		bwa_seq_t *p = s + i; const int len = (int)(off[i + 1] - off[i]);
+		p->len = p->full_len = p->clip_len = len;
+		p->seq = (ubyte_t*)malloc(len + 1); memcpy(p->seq, seq + off[i], len);
+		p->rseq = (ubyte_t*)malloc(len + 1); memcpy(p->rseq, rseq + off[i], len);
+		p->n_aln = n_aln[i]; p->aln = (bwt_aln1_t*)calloc(n_aln[i] ? n_aln[i] : 1, sizeof(bwt_aln1_t));
+		if (n_aln[i]) memcpy(p->aln, aln + 4 * row, 16 * (size_t)n_aln[i]);
+		row += n_aln[i];
+	}
+	t0 = ref_now();
+	for (i = 0; i < n; ++i) {
+		bwa_seq_t *p = s + i;
+		bwa_aln2seq_core(p->n_aln, p->aln, p, 1, max_occ_se);
+		bwa_cal_pac_pos_core(ix->bwt[0], ix->bwt[1], p, opt->max_diff, opt->fnr);
+		for (j = 0; j < p->n_multi; ++j) {
+			bwt_multi1_t *q = p->multi + j;
+			if (q->strand) q->pos = bwt_sa(ix->bwt[0], q->pos);
+			else q->pos = ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], q->pos) + p->len);
+		}
+	}
+	secs[0] = ref_now() - t0; t0 = ref_now();
+	{
+		ref_se_job_t *jobs = (ref_se_job_t*)calloc(n_threads, sizeof(*jobs));
+		pthread_t *tid = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+		for (t = 0; t < n_threads; ++t) {
+			const int lo = (int)((long)n * t / n_threads), hi = (int)((long)n * (t + 1) / n_threads);
+			jobs[t].ix = ix; jobs[t].s = s + lo; jobs[t].n = hi - lo;
+			pthread_create(&tid[t], 0, ref_se_job, jobs + t);
+		}
+		for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+		free(jobs); free(tid);
+	}
+	secs[1] = ref_now() - t0;
+	for (i = 0; i < n; ++i) {
+		const bwa_seq_t *p = s + i; int64_t *o = f + 16 * (size_t)i;
+		o[0] = p->type; o[1] = p->strand; o[2] = p->n_mm; o[3] = p->n_gapo; o[4] = p->n_gape; o[5] = p->score; o[6] = p->sa;
+		o[7] = p->c1; o[8] = p->c2; o[9] = p->pos; o[10] = p->mapQ; o[11] = p->n_multi; o[12] = p->cigar ? p->n_cigar : 0; o[13] = p->nm;
+		o[14] = p->len; o[15] = 0;
+		if (p->cigar) memcpy(cigar + 64 * (size_t)i, p->cigar, 2 * (p->n_cigar < 64 ? p->n_cigar : 64));
+		md[(size_t)md_cap * i] = 0;
+		if (p->md) { strncpy(md + (size_t)md_cap * i, p->md, md_cap - 1); md[(size_t)md_cap * i + md_cap - 1] = 0; }
+	}
+	for (i = 0; i < n; ++i) bwa_free_read_seq1(s + i);
+	free(s);
+}
+
+/* The iteration order of the reference's string hash set (khash.h, KHASH_SET_INIT_STR) after the keys are put in the order given:
+ * what find_pp_tag's choice of the PP: value depends on (bam2bam.c:246-255; bam2bam.c itself cannot be compiled here).  order_out
+ * receives the indexes of the distinct keys in slot order; returns their number. */
+#include "khash.h"
+KHASH_SET_INIT_STR(refwords)
+int ref_khash_str_order(int n, const char *const *keys, int *order_out)
+{
+	kh_refwords_t *h = kh_init_refwords(); khint_t it; int r, i, m = 0;
+	for (i = 0; i < n; ++i) kh_put_refwords(h, keys[i], &r);
+	for (it = kh_begin(h); it != kh_end(h); ++it)
+		if (kh_exist(h, it)) {
+			for (i = 0; i < n; ++i) if (keys[i] == kh_key(h, it)) break;
+			order_out[m++] = i;
+		}
+	kh_destroy_refwords(h);
+	return m;
+}

@@ -51,3 +51,28 @@ def test_bench_command_line_parses_without_a_gpu():
     assert r.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--adna", "--pipeline"):
         assert flag in r.stdout
+
+
+def test_gpus_without_a_launcher_starts_the_ranks_as_a_child(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset (the driver's call): one torch.distributed.run child with N ranks on 127.0.0.1,
+    the same arguments passed on, its exit code returned -- and no rank count taken from anywhere else"""
+    b = load_bench()
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = b.parse_args()
+    assert b.launch_ranks(args) == 7
+    c = seen["cmd"]
+    assert c[0] == sys.executable and c[1:3] == ["-m", "torch.distributed.run"]
+    assert c[c.index("--nproc-per-node") + 1] == "4" and c[c.index("--master-addr") + 1] == "127.0.0.1" and "--nnodes=1" in c
+    i = c.index(os.path.join(T.ROOT, "bench.py"))
+    assert c[i + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"

@@ -68,4 +68,24 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1
     assert d["config"]["reads_per_gpu"] == 300000 and d["config"]["bit_exact_vs_cpu_sample"] is True
     assert abs(d["value"] - 2 * 300000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]        # whole-job rate: both ranks' reads over the slowest rank's time
-    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None          # the CPU leg is reported at N = 1 only; the sample check above ran all the same
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it): bench.py starts its two ranks itself, as a child
+    process before anything touches the GPU, and relays ONE line with n_gpus = 2 -- the kernel-only rate and the records-in ->
+    records-out leg, both over both ranks."""
+    e = dict(os.environ, NABWA_BENCH_BACKEND="gloo", NABWA_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-len", "30000000", "--reads", "300000",
+                        "--cpu-seconds", "3", "--e2e-reads", "50000"], env=e, capture_output=True, text=True, timeout=900, cwd=T.ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["bit_exact_vs_cpu_sample"] is True
+    assert abs(d["value"] - 2 * 300000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert d["cpu_baseline"] is None                          # a CPU leg is reported at N = 1 only
+    assert d["e2e"]["n_gpus"] == 2 and d["e2e"]["reads"] == 50000 and d["e2e"]["reads_per_s"] > 0
+    assert d["e2e"]["bit_exact_vs_reference_sample"] is True
