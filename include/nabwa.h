@@ -280,6 +280,17 @@ int nabwa_isize_add_pairs(int n_pairs, const nabwa_pe_t *recs, uint16_t *hist);
 int nabwa_pe_finish(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 					int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
 					const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2]);
+/* finish_pair's per-file position cache (kh_64_t *my_hash, bam2bam.c:707,741-757; one per pass 2 in `bam2bam -t 1`, :1186-1203): hit rows of
+ * MIN_HASH_WIDTH = 1000 suffixes or more get their text positions once per file, under the key (k, l) alone -- later reads with the same
+ * row take the positions of the first read that brought it, computed with THAT read's strand and length.  Pass the same cache to every
+ * batch of a file, batches in input order, to get what the sequential reference writes; NULL = every row on its own (a cold cache). */
+typedef struct nabwa_poscache nabwa_poscache_t;
+nabwa_poscache_t *nabwa_poscache_create(void);
+void nabwa_poscache_destroy(nabwa_poscache_t *c);
+int64_t nabwa_poscache_size(const nabwa_poscache_t *c);      /* rows entered so far */
+int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+						   int n_pairs, const int64_t *off, const uint8_t *seq, const uint8_t *rseq, const int32_t *n_aln,
+						   const nabwa_aln1_t *aln, nabwa_pe_t *inout, uint64_t n_tot[2], uint64_t n_mapped[2], nabwa_poscache_t *cache);
 
 /* ---- the same phases on the reference's own records (bwa_seq_t), one call per phase and batch ---------------------
  * Each replaces the per-record function of the same role in bam2bam.c; fields are left as that function leaves them, and
@@ -295,6 +306,9 @@ int nabwa_bwa_refine_gapped(nabwa_index_t *ix, int n, nabwa_bwa_seq_t *seqs);
 int nabwa_bwa_posn_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t *rng48);
 int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 						int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2]);
+/* the same with finish_pair's my_hash argument (bam2bam.c:707): one cache per pass 2 of a file */
+int nabwa_bwa_finish_pe_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+							   int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2], nabwa_poscache_t *cache);
 
 /* ---- the batching front-end: BAM records in, BAM records out (what sits behind `bwa bam2bam` / `bwa worker`) --------
  * A batch = n_rec records as they stand in an uncompressed BAM stream (u32 block_size + block), in file order, mates adjacent.
@@ -341,6 +355,8 @@ int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, con
  * one process keeps several GPUs busy: batches are dealt to index replicas, searched as they come, and passed in input order. */
 int nabwa_bam_batch_search(nabwa_bam_batch_t *b);
 int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_table_t *tab);
+/* pass 2 keeps finish_pair's position cache (above) in the table: the batches of a file pass in input order, as the records of
+ * `bam2bam -t 1` do */
 int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2]);
 int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes);
 int nabwa_bam_batch_counts(const nabwa_bam_batch_t *b, int *n_records, int *n_logical);

@@ -30,6 +30,8 @@
 #include "nabwa_internal.hpp"
 #include "finish_common.hpp"
 
+void nabwa_poscache_register(nabwa_poscache_t *cache, int max_occ, int n, const int *first, const int32_t *n_aln, const int64_t *row0,
+							 const nabwa_aln1_t *rows, const nabwa_pe_t *res);                                                       /* pe_finish.hip */
 /* the single-end chain on records of any stride whose head is a nabwa_se_t (se_finish.hip): this file works in place */
 int nabwa_se_posn_strided(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, const int64_t *off, const int32_t *full_len,
 						  const int32_t *n_aln, const nabwa_aln1_t *aln, const uint8_t *n_occ_v, uint64_t *rng48, void *out_base, size_t stride);
@@ -71,15 +73,16 @@ struct nabwa_isize_table {
 	struct Rg { nabwa_isize_t ii; std::vector<uint16_t> hist; bool has_hist; };
 	std::map<std::string, Rg> rg;        /* (the reference keeps a khash; its iteration order only decides the order of log lines) */
 	double ap_prior; int64_t L;
+	nabwa_poscache_t *poscache;          /* finish_pair's position cache of the file (bam2bam.c:1186-1203): lives as long as pass 2 does, like this table */
 };
 
 extern "C" nabwa_isize_table_t *nabwa_isize_table_create(double ap_prior, int64_t genome_len)
 {
 	nabwa_isize_table *t = new nabwa_isize_table();
-	t->ap_prior = ap_prior; t->L = genome_len;
+	t->ap_prior = ap_prior; t->L = genome_len; t->poscache = nabwa_poscache_create();
 	return t;
 }
-extern "C" void nabwa_isize_table_destroy(nabwa_isize_table_t *t) { delete t; }
+extern "C" void nabwa_isize_table_destroy(nabwa_isize_table_t *t) { if (t) nabwa_poscache_destroy(t->poscache); delete t; }
 
 /* improve_isize_est (insert_size.c:141-165): one logical record's contribution.  The 16-bit bins wrap as the reference's do
  * (its "hit the ceiling" test compares an unsigned short with -1 and never fires). */
@@ -786,14 +789,17 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	/* ---- pairs, one read group at a time with that group's estimate (pass 2 draws no random numbers: its order is free) */
 	{
 		std::map<std::string, std::vector<int>> groups;
-		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2 && !b->skip[k]) groups[b->rg_names[b->rg[k]]].push_back(b->first[k]);
+		std::vector<int> in_order;
+		for (size_t k = 0; k < b->kind.size(); ++k) if (b->kind[k] == 2 && !b->skip[k]) { groups[b->rg_names[b->rg[k]]].push_back(b->first[k]); in_order.push_back(b->first[k]); }
+		/* who is first with a wide hit row is settled in record order (finish_pair's cache of positions, pe_finish.hip), not in group order */
+		if (groups.size() > 1) nabwa_poscache_register(tab->poscache, b->popt.max_occ, (int)in_order.size(), in_order.data(), b->n_aln.data(), b->row0.data(), b->rows.data(), b->res);
 		for (auto &g : groups) {
 			nabwa_isize_t ii;
 			nabwa_isize_table_get(tab, g.first.c_str(), &ii);
 			const std::vector<int> &idx = g.second;
 			const int np = (int)idx.size();
 			if (2 * (size_t)np == b->rec.size()) {           /* the whole batch is pairs of this one group: in place */
-				int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, b->off.data(), b->seq.data(), b->rseq.data(), b->n_aln.data(), b->rows.data(), b->res, n_tot, n_mapped);
+				int rc = nabwa_pe_finish_cached(b->ix, &b->opt, &b->popt, &ii, np, b->off.data(), b->seq.data(), b->rseq.data(), b->n_aln.data(), b->rows.data(), b->res, n_tot, n_mapped, tab->poscache);
 				if (rc != NABWA_OK) return rc;
 				continue;
 			}
@@ -819,7 +825,7 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 				}
 			});
 			sq.data()[off[nr]] = 0; rq.data()[off[nr]] = 0; memset(&rows[r0[nr]], 0, sizeof(nabwa_aln1_t));
-			int rc = nabwa_pe_finish(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows, pe, n_tot, n_mapped);
+			int rc = nabwa_pe_finish_cached(b->ix, &b->opt, &b->popt, &ii, np, off.data(), sq.data(), rq.data(), na.data(), rows, pe, n_tot, n_mapped, tab->poscache);
 			if (rc == NABWA_OK) bam_parallel(nr, [&](int, size_t lo, size_t hi) { for (size_t q = lo; q < hi; ++q) copy_filled(b->res[idx[q >> 1] + (int)(q & 1)], pe[q]); });
 			res_give(pe, pe_bytes);
 			if (rc != NABWA_OK) return rc;

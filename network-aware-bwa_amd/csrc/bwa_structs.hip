@@ -258,6 +258,12 @@ extern "C" int nabwa_bwa_posn_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, 
 extern "C" int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
 								   int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2])
 {
+	return nabwa_bwa_finish_pe_cached(ix, opt, popt, ii, n_pairs, seqs, n_tot, n_mapped, 0);
+}
+
+extern "C" int nabwa_bwa_finish_pe_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const nabwa_isize_t *ii,
+										  int n_pairs, nabwa_bwa_seq_t *seqs, uint64_t n_tot[2], uint64_t n_mapped[2], nabwa_poscache_t *cache)
+{
 	if (!ix || !opt || !popt || !ii || n_pairs < 0 || (n_pairs && !seqs)) return nabwa_fail(NABWA_EINVAL, "null argument");
 	const int n = 2 * n_pairs;
 	FlatRecs F;
@@ -269,7 +275,7 @@ extern "C" int nabwa_bwa_finish_pe(nabwa_index_t *ix, const nabwa_gap_opt_t *opt
 		se_from_seq(seqs[i], recs[i].se);
 		recs[i].extra_flag = (int)(seqs[i].bits0 >> 24); recs[i].m_seqid = 0; recs[i].am = 0; recs[i].mapQ_paired = 0; recs[i].m_rpos = 0; recs[i].isize = 0;
 	}
-	rc = nabwa_pe_finish(ix, opt, popt, ii, n_pairs, F.off.data(), F.seq.data(), F.rseq.data(), F.n_aln.data(), F.aln.data(), recs.data(), n_tot, n_mapped);
+	rc = nabwa_pe_finish_cached(ix, opt, popt, ii, n_pairs, F.off.data(), F.seq.data(), F.rseq.data(), F.n_aln.data(), F.aln.data(), recs.data(), n_tot, n_mapped, cache);
 	if (rc != NABWA_OK) return rc;
 	for (int i = 0; i < n; ++i) {
 		nabwa_bwa_seq_t &q = seqs[i];

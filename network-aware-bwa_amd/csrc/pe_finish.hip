@@ -66,6 +66,39 @@ extern "C" nabwa_poscache_t *nabwa_poscache_create(void) { return new nabwa_posc
 extern "C" void nabwa_poscache_destroy(nabwa_poscache_t *c) { delete c; }
 extern "C" int64_t nabwa_poscache_size(const nabwa_poscache_t *c) { return c ? (int64_t)c->first.size() : 0; }
 
+/* finish_pair enumerates the hits of a pair only when both ends are mapped and neither has more than max_occ hits (bam2bam.c:726-738) */
+static inline bool pair_is_enumerated(const nabwa_se_t &e0, const nabwa_se_t &e1, const nabwa_aln1_t *a0, int n0, const nabwa_aln1_t *a1, int n1, int max_occ, uint32_t *n_rows)
+{
+	if (!((e0.type == 1 || e0.type == 2) && (e1.type == 1 || e1.type == 2))) return false;
+	long long o0 = 0, o1 = 0;
+	for (int k = 0; k < n0; ++k) o0 += (long long)a0[k].l - a0[k].k + 1;
+	for (int k = 0; k < n1; ++k) o1 += (long long)a1[k].l - a1[k].k + 1;
+	if (o0 > max_occ || o1 > max_occ) return false;
+	if (n_rows) *n_rows = (uint32_t)(o0 + o1);
+	return true;
+}
+
+/* The wide rows of the pairs first[0..n) (record index of end 0; ends adjacent) enter the cache in this order.  The batch front-end calls
+ * it with a batch's pairs in record order before it finishes them read group by read group: who is first with a row is then settled as
+ * the sequential reference settles it, whatever order the groups are taken in. */
+void nabwa_poscache_register(nabwa_poscache_t *cache, int max_occ, int n, const int *first, const int32_t *n_aln, const int64_t *row0,
+							 const nabwa_aln1_t *rows, const nabwa_pe_t *res)
+{
+	if (!cache) return;
+	for (int t = 0; t < n; ++t) {
+		const int i = first[t];
+		bool wide = false;
+		for (int64_t r = row0[i]; r < row0[i] + n_aln[i] + n_aln[i + 1] && !wide; ++r) wide = rows[r].l - rows[r].k + 1 >= MIN_HASH_WIDTH;
+		if (!wide) continue;
+		if (!pair_is_enumerated(res[i].se, res[i + 1].se, rows + row0[i], n_aln[i], rows + row0[i + 1], n_aln[i + 1], max_occ, 0)) continue;
+		for (int j = 0; j < 2; ++j)
+			for (int k = 0; k < n_aln[i + j]; ++k) {
+				const nabwa_aln1_t &r = rows[row0[i + j] + k];
+				if (r.l - r.k + 1 >= MIN_HASH_WIDTH) cache->first.emplace((uint64_t)r.k << 32 | r.l, (r.info >> 24 & 1) << 31 | (uint32_t)res[i + j].se.len);
+			}
+	}
+}
+
 /* one mate-rescue attempt: align end `k` of pair `pair` inside [beg, beg+reglen) next to its mate (bwape.c:562-583) */
 struct SwJob { int pair, k; int64_t beg; int ref_n; bool fwd; };
 
@@ -107,15 +140,9 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	std::vector<uint32_t> prow((size_t)(n_pairs ? n_pairs : 1), 0);
 	fin_parallel(fin_threads((size_t)n_pairs), (size_t)n_pairs, [&](int, size_t p_lo, size_t p_hi) {
 		for (size_t pr = p_lo; pr < p_hi; ++pr) {
-			const nabwa_se_t &e0 = PE(out, pr, 0).se, &e1 = PE(out, pr, 1).se;
-			if (!((e0.type == 1 || e0.type == 2) && (e1.type == 1 || e1.type == 2))) continue;
-			long long n_occ[2] = { 0, 0 };
-			for (int j = 0; j < 2; ++j) {
-				const nabwa_aln1_t *A = aln + a_off[2 * pr + j];
-				for (int k = 0; k < n_aln[2 * pr + j]; ++k) n_occ[j] += (long long)A[k].l - A[k].k + 1;
-			}
-			if (n_occ[0] > popt->max_occ || n_occ[1] > popt->max_occ) continue;
-			prow[pr] = (uint32_t)(n_occ[0] + n_occ[1]);
+			uint32_t rows_here = 0;
+			if (pair_is_enumerated(PE(out, pr, 0).se, PE(out, pr, 1).se, aln + a_off[2 * pr], n_aln[2 * pr], aln + a_off[2 * pr + 1], n_aln[2 * pr + 1], popt->max_occ, &rows_here))
+				prow[pr] = rows_here;
 		}
 	});
 	/* the position cache, in record order: for every wide row of a paired pair the (strand, length) its positions are computed with --

@@ -363,8 +363,21 @@ void ref_pe_posn(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt)
 			bwa_cal_pac_pos_core(ix->bwt[0], ix->bwt[1], p, opt->max_diff, opt->fnr);
 		}
 }
-/* pass 2 of every pair: finish_pair, bam2bam.c:705-811, up to (not including) bwa_update_bam1 */
-void ref_pe_finish(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv)
+/* pass 2 of every pair: finish_pair, bam2bam.c:705-811, up to (not including) bwa_update_bam1.  cache: finish_pair's my_hash
+ * (bam2bam.c:741-757; one per pass 2 of a file, :1186-1203) in the reference's own hash map, or NULL for none: rows of MIN_HASH_WIDTH
+ * suffixes or more take their positions from the first read that brought the same (k, l). */
+KHASH_MAP_INIT_INT64(refpos, poslist_t)
+void *ref_poscache_new(void) { return kh_init(refpos); }
+void ref_poscache_free(void *c)
+{
+	kh_refpos_t *h = (kh_refpos_t*)c; khint_t it;
+	for (it = kh_begin(h); it != kh_end(h); ++it) if (kh_exist(h, it)) free(kh_val(h, it).a);
+	kh_destroy(refpos, h);
+}
+static void ref_pe_finish_impl(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv, kh_refpos_t *my_hash);
+void ref_pe_finish(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv) { ref_pe_finish_impl(b, ix, opt, iiv, 0); }
+void ref_pe_finish_cached(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv, void *cache) { ref_pe_finish_impl(b, ix, opt, iiv, (kh_refpos_t*)cache); }
+static void ref_pe_finish_impl(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, const double *iiv, kh_refpos_t *my_hash)
 {
 	pe_opt_t *po = bwa_init_pe_opt(); isize_info_t ii; uint64_t n_tot[2] = {0, 0}, n_mapped[2] = {0, 0}; int i, j, k;
 	memset(&ii, 0, sizeof(ii));
@@ -381,7 +394,19 @@ void ref_pe_finish(ref_pe_batch_t *b, ref_index_t *ix, const gap_opt_t *opt, con
 				for (j = 0; j < 2; ++j)
 					for (k = 0; k < d.aln[j].n; ++k) {
 						bwt_aln1_t *r = d.aln[j].a + k; bwtint_t l;
-						for (l = r->k; l <= r->l; ++l) {
+						if (my_hash && r->l - r->k + 1 >= MIN_HASH_WIDTH) {
+							int ret; khint_t iter = kh_put(refpos, my_hash, (uint64_t)r->k << 32 | r->l, &ret);
+							if (ret) {
+								poslist_t *z = &kh_val(my_hash, iter);
+								z->n = r->l - r->k + 1; z->a = (bwtint_t*)malloc(sizeof(bwtint_t) * z->n);
+								for (l = r->k; l <= r->l; ++l) z->a[l - r->k] = r->a ? bwt_sa(ix->bwt[0], l) : ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], l) + p[j]->len);
+							}
+							for (l = 0; l < (bwtint_t)kh_val(my_hash, iter).n; ++l) {
+								uint64_t x = kh_val(my_hash, iter).a[l];
+								x = x << 32 | k << 1 | j;
+								kv_push(uint64_t, d.arr, x);
+							}
+						} else for (l = r->k; l <= r->l; ++l) {
 							uint64_t x = r->a ? bwt_sa(ix->bwt[0], l) : ix->bwt[1]->seq_len - (bwt_sa(ix->bwt[1], l) + p[j]->len);
 							x = x << 32 | k << 1 | j;
 							kv_push(uint64_t, d.arr, x);
