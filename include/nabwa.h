@@ -362,6 +362,85 @@ int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap
 int nabwa_bam_batch_counts(const nabwa_bam_batch_t *b, int *n_records, int *n_logical);
 void nabwa_bam_batch_destroy(nabwa_bam_batch_t *b);
 
+/* ---- 0MQ worker compatibility: the wire record, and a worker core that is independent of the transport ----------
+ * `bwa bam2bam -p PORT` hands logical records to `bwa worker` processes as 0MQ messages and takes them back one phase further
+ * (run_worker_thread, bam2bam.c:1387-1442); the same bytes, with a u32 length in front, are the records of its temporary file
+ * between the passes (pair_print_custom / read_pair_custom, bam2bam.c:1099-1135).  One message (msg_init_from_pair, bam2bam.c:951-1006;
+ * inverse pair_init_from_msg, :1040-1097):
+ *    u64 recno (little endian) . u8 kind (0 end marker, 1 single read, 2 pair) . u8 phase (0 pristine, 1 aligned, 2 positioned, 3 finished)
+ *    per read:  bam1_core_t as the HOST lays it out, 32 bytes (bamlite.h:44-53: word 2 = bin | qual << 16 | l_qname << 24, word 3 =
+ *               flag | n_cigar << 16 -- not the order of a BAM file) . i32 data_len . data (name, CIGAR, bases, qualities, tags)
+ *      phase positioned:  u8 strand << 4 | type . u8 n_mm, n_gapo, n_gape, seQ, mapQ . i32 len, clip_len, score, sa, c1, c2, pos, n_multi .
+ *                         n_multi raw bwt_multi1_t of 16 bytes (u32 pos . u32 n_cigar:15 | gap:8 | mm:8 | strand:1 . a dead pointer)
+ *      phases aligned, positioned:  i32 max_entries . i32 n_aln . n_aln raw bwt_aln1_t of 16 bytes
+ * Parity unpinned: libzmq is absent from the image and bam2bam.c cannot be compiled, so no byte of a reference message exists to compare
+ * with; the codec follows the cited lines, and tests/test_wire.py builds messages by hand from them. */
+#define NABWA_KIND_EOF 0
+#define NABWA_KIND_SINGLE 1
+#define NABWA_KIND_PAIR 2
+#define NABWA_PHASE_PRISTINE 0
+#define NABWA_PHASE_ALIGNED 1
+#define NABWA_PHASE_POSITIONED 2
+#define NABWA_PHASE_FINISHED 3
+typedef struct {
+	uint8_t core[32];                       /* bam1_core_t, host layout */
+	int32_t data_len; const uint8_t *data;  /* bam1_t.data */
+	uint8_t strand, type, n_mm, n_gapo, n_gape, seQ, mapQ;                 /* positioned */
+	int32_t len, clip_len, score; uint32_t sa, c1, c2, pos;
+	int32_t n_multi; const uint8_t *multi;                                 /* n_multi x 16 raw bytes (may be unaligned) */
+	int32_t max_entries, n_aln; const uint8_t *aln;                        /* aligned, positioned: n_aln x 16 raw bytes (may be unaligned) */
+} nabwa_wire_read_t;
+typedef struct { uint64_t recno; uint8_t kind, phase; nabwa_wire_read_t read[2]; } nabwa_wire_rec_t;
+/* bytes the message of r takes */
+int64_t nabwa_wire_size(const nabwa_wire_rec_t *r);
+/* msg_init_from_pair: writes the message, returns its size; NABWA_ECAP if cap is too small, NABWA_EINVAL for a kind / phase that does not exist */
+int64_t nabwa_wire_encode(const nabwa_wire_rec_t *r, uint8_t *out, int64_t cap);
+/* pair_init_from_msg: the pointers of *out point into msg.  NABWA_EINVAL unless the message is consumed exactly (the reference exits there) */
+int nabwa_wire_decode(const uint8_t *msg, int64_t len, nabwa_wire_rec_t *out);
+/* a record as it stands in a BAM stream (u32 block_size, 32 bytes of core in file order, data) <-> core in host layout + data */
+void nabwa_wire_core_from_bam(const uint8_t bam_core[32], uint8_t wire_core[32]);
+void nabwa_wire_core_to_bam(const uint8_t wire_core[32], uint8_t bam_core[32]);
+/* the reply to a worker's hello (run_config_service, bam2bam.c:1255-1266; read at :2260-2274): gap_opt_t . pe_opt_t . index prefix, not terminated */
+int64_t nabwa_wire_config_encode(const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, const char *prefix, uint8_t *out, int64_t cap);
+int nabwa_wire_config_decode(const uint8_t *msg, int64_t len, nabwa_gap_opt_t *opt, nabwa_pe_opt_t *popt, char *prefix, int prefix_cap);
+
+/* The state pass 1 leaves a batch in, read by read, and the way back: what lets a positioned record leave the process (the temporary
+ * file between the passes, a worker's reply) and come back into a fresh batch made from the same records.
+ *   nabwa_bam_batch_positioned : after pass 1; fills the positioned and aligned parts of out[0 .. n_records) (core / data are left alone),
+ *                                pointers into the batch, valid until it is destroyed
+ *   nabwa_bam_batch_restore    : on a batch just created from the same records: takes the state from in[0 .. n_records) instead of
+ *                                searching and positioning; the batch is then where pass 1 would have left it (no random numbers drawn, no
+ *                                insert sizes counted).  NABWA_EINVAL if a read's length disagrees with the batch's (other trimming options). */
+int nabwa_bam_batch_positioned(nabwa_bam_batch_t *b, nabwa_wire_read_t *out);
+int nabwa_bam_batch_restore(nabwa_bam_batch_t *b, const nabwa_wire_read_t *in);
+
+/* The worker's side of the exchange without a socket in sight: messages in, messages out.
+ *   pristine / aligned records : pair_aln + pair_posn (bam2bam.c:1414-1416) on the worker's own drand48 stream in arrival order
+ *                                (srand48(bns->seed) at start, bam2bam.c:2284) -> positioned
+ *   positioned records         : pair_finish with the insert-size estimates last set (bam2bam.c:1419) -> finished; without estimates the
+ *                                record goes back as it came and counts as a failure (1024 of them end the worker, :1428-1433)
+ *   finished records, end markers: go back as they came
+ * Records are gathered into batches for the GPU; replies leave in arrival order.  A record sent twice (the master's resend loop,
+ * bam2bam.c:1587-1596) is simply worked on twice, as the reference's workers do -- nothing is remembered between messages but the
+ * random stream, the estimates and finish_pair's position cache. */
+typedef struct nabwa_worker nabwa_worker_t;
+int nabwa_worker_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, nabwa_worker_t **out);
+void nabwa_worker_destroy(nabwa_worker_t *w);
+/* the insert-size broadcast (`\2` + blob, handle_broadcast, bam2bam.c:2079-2097) or the reply to `\1nodename` (:2286-2299): decode_iinfo's blob */
+int nabwa_worker_set_isize(nabwa_worker_t *w, const uint8_t *blob, int64_t n);
+typedef int (*nabwa_send_fn)(void *ctx, const uint8_t *msg, int64_t len);                               /* 0 = sent */
+/* returns 1 with a message (valid until the next call), 0 when none came within timeout_ms, -1 when the transport is closed */
+typedef int (*nabwa_recv_fn)(void *ctx, const uint8_t **msg, int64_t *len, int timeout_ms);
+/* one batch of messages: every one is answered through send, in the order given */
+int nabwa_worker_process(nabwa_worker_t *w, int n_msg, const uint8_t *const *msgs, const int64_t *lens, nabwa_send_fn send, void *ctx);
+/* bwa_worker_core's loop (bam2bam.c:2099-2176) over a transport: gathers up to max_batch messages (waiting linger_ms for more once one
+ * is there), processes them, goes on; returns NABWA_OK when nothing came for idle_timeout_ms (the reference: 90 s) or the transport closed,
+ * NABWA_EIO after 1024 positioned records without estimates */
+typedef struct { int32_t max_batch, linger_ms, idle_timeout_ms; } nabwa_worker_opt_t;
+int nabwa_worker_core(nabwa_worker_t *w, nabwa_recv_fn recv, nabwa_send_fn send, void *ctx, const nabwa_worker_opt_t *wo);
+/* counters: records positioned, finished, bounced (no estimates), passed through */
+void nabwa_worker_counts(const nabwa_worker_t *w, uint64_t out[4]);
+
 /* Read-back of the index parts derived at load time (tests): what 0 = full SA, 1 = inverse SA, 2 = text bases (one per
  * word), 3 = interval-table entries {k, l} of the last level (two words per key), 4 = the table's depth T (one word). */
 int nabwa_index_export(const nabwa_index_t *ix, int which, int what, uint64_t first, uint64_t n, uint32_t *out);

@@ -24,17 +24,8 @@
 #include "nabwa_internal.hpp"
 #include "finish_common.hpp"
 
-struct DpParams {
-	int n;
-	const int64_t *ref_off, *qry_off;
-	const uint8_t *ref, *qry;
-	int gap_open, gap_ext, gap_end, band;
-	int matrix[25];
-	int W, H;
-	int32_t *rows; uint8_t *tb; uint8_t *path;
-	int32_t *score, *n_cigar; uint32_t *cigar; int max_cigar;
-};
-extern "C" void nabwa_launch_dp_global(const DpParams *P, hipStream_t s);
+#include "dp_params.hpp"
+
 
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 	char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -142,18 +133,7 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 
 /* ------------------------------------------------------------------ batched aln_extend_core */
 
-struct ExtParams {
-	int n;
-	const int64_t *ref_off, *qry_off;
-	const uint8_t *ref, *qry;
-	const int32_t *g0;
-	int gap_open, gap_ext, band;
-	int matrix[25];
-	int W;
-	uint32_t *eh;
-	int32_t *score, *end_i, *end_j;
-};
-extern "C" void nabwa_launch_dp_extend_fwd(const ExtParams *P, hipStream_t s);
+
 
 extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
 								  const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, const int32_t *G0,
@@ -170,10 +150,9 @@ extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, con
 	std::vector<int32_t> fs(n), ei(n), ej(n);
 	{
 		ExtParams P; memset(&P, 0, sizeof(P));
-		const size_t waves = (size_t)((n + 255) / 256) * 4;
 		ArenaUse A(device);
 		const size_t sz[9] = { (size_t)(n + 1) * 8, (size_t)(n + 1) * 8, (size_t)ref_off[n] + 16, (size_t)qry_off[n] + 16, (size_t)n * 4,
-							   waves * (size_t)W * 64 * 4, (size_t)n * 4, (size_t)n * 4, (size_t)n * 4 };
+							   nabwa_dp_local_fits_lds(W) ? 256 : (size_t)n * nabwa_dp_local_rows_bytes(W), (size_t)n * 4, (size_t)n * 4, (size_t)n * 4 };
 		size_t need = 0; for (size_t z : sz) need += up256(z);
 		SCHK(A.reserve(need));
 		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
@@ -223,16 +202,7 @@ extern "C" int nabwa_extend_align(int device, int n, const int64_t *ref_off, con
 
 /* ------------------------------------------------------------------ batched aln_local_core */
 
-struct LocParams {
-	int n;
-	const int64_t *ref_off, *qry_off;
-	const uint8_t *ref, *qry;
-	int gap_open, gap_ext, thres;
-	int matrix[25], max_score;
-	int W, H;
-	int32_t *eh, *suba, *out;
-};
-extern "C" void nabwa_launch_dp_local(const LocParams *P, hipStream_t s);
+
 
 extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, const uint8_t *ref, const int64_t *qry_off,
 								 const uint8_t *qry, int gap_open, int gap_ext, const int *matrix25, int band, int thres,
@@ -254,10 +224,9 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 	std::vector<int32_t> o((size_t)n * 6), sub((size_t)n * H);
 	{
 		LocParams P; memset(&P, 0, sizeof(P));
-		const size_t waves = (size_t)((n + 255) / 256) * 4;
 		ArenaUse A(device);
 		const size_t sz[7] = { (size_t)(n + 1) * 8, (size_t)(n + 1) * 8, (size_t)ref_off[n] + 16, (size_t)qry_off[n] + 16,
-							   waves * (size_t)W * 64 * 4, (size_t)n * H * 4, (size_t)n * 24 };
+							   nabwa_dp_local_fits_lds(W) ? 256 : (size_t)n * nabwa_dp_local_rows_bytes(W), (size_t)n * H * 4, (size_t)n * 24 };
 		size_t need = 0; for (size_t z : sz) need += up256(z);
 		SCHK(A.reserve(need));
 		int64_t *d_ro = A.take<int64_t>(sz[0]), *d_qo = A.take<int64_t>(sz[1]); uint8_t *d_ref = A.take<uint8_t>(sz[2]), *d_qry = A.take<uint8_t>(sz[3]);
@@ -268,6 +237,7 @@ extern "C" int nabwa_local_align(int device, int n, const int64_t *ref_off, cons
 		if (qry_off[n]) SCHK(hipMemcpy(d_qry, qry, qry_off[n], hipMemcpyHostToDevice));
 		P.n = n; P.ref_off = d_ro; P.qry_off = d_qo; P.ref = d_ref; P.qry = d_qry;
 		P.gap_open = gap_open; P.gap_ext = gap_ext; P.thres = thres; memcpy(P.matrix, matrix25, 100); P.max_score = max_score; P.W = W; P.H = H;
+		P.row_forward = getenv("NABWA_DP_FORWARD") && !strcmp(getenv("NABWA_DP_FORWARD"), "rows");
 		tl1 = now();
 		nabwa_launch_dp_local(&P, 0);
 		SCHK(hipGetLastError());

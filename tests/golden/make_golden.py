@@ -388,6 +388,128 @@ def make_sw_vectors(lib, sm_maq, sm_blast):
 
 
 
+def rescue_tasks(rng, n=400):
+    """tasks shaped like mate rescue: a window of 300 - 620 bases, a read of 70 - 250 with substitutions, an indel now and then, some
+    reads that are not in their window at all, N runs"""
+    refs, qrys = [], []
+    for t in range(n):
+        lw, lr = int(rng.integers(300, 620)), int(rng.integers(70, 250))
+        w = rng.integers(0, 4, lw).astype(np.uint8)
+        if t % 9 == 0:
+            r = rng.integers(0, 4, lr).astype(np.uint8)                    # not there
+        else:
+            p = int(rng.integers(0, lw - lr)) if lw > lr else 0
+            r = w[p:p + lr].copy()
+            sub = rng.random(len(r)) < 0.04
+            r[sub] = rng.integers(0, 4, int(sub.sum()))
+            if t % 4 == 0 and len(r) > 40:
+                c = int(rng.integers(20, len(r) - 20))
+                r = np.concatenate([r[:c], r[c + int(rng.integers(1, 4)):]]) if t % 8 == 0 else np.concatenate([r[:c], rng.integers(0, 4, int(rng.integers(1, 4))).astype(np.uint8), r[c:]])
+        if t % 13 == 0:
+            w[10:14] = 4; r[5:7] = 4
+        refs.append(w); qrys.append(r.astype(np.uint8))
+    return refs, qrys
+
+
+def long_tasks(rng, n, anchored):
+    """reads of 3000 - 3600 bases whose scores pass 32000: the reference's 16-bit rows drop by 16000 there (stdaln.c:252-253, :583-602,
+    :919-932).  anchored: the read starts where the window starts (extension); else it lies inside a longer window (local)."""
+    refs, qrys = [], []
+    for t in range(n):
+        lr = int(rng.integers(3000, 3600))
+        q = rng.integers(0, 4, lr).astype(np.uint8)
+        r = list(q)
+        for _ in range(int(rng.integers(0, 12))):                            # a few edits; two tasks stay exact
+            if t < 2:
+                break
+            pos = int(rng.integers(50, len(r) - 50))
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                del r[pos]
+            elif k == 1:
+                r.insert(pos, int(rng.integers(0, 4)))
+            else:
+                r[pos] = (r[pos] + 1) % 4
+        if anchored:
+            r = r + list(rng.integers(0, 4, int(rng.integers(0, 80))))
+        else:
+            r = list(rng.integers(0, 4, int(rng.integers(0, 150)))) + r + list(rng.integers(0, 4, int(rng.integers(0, 150))))
+        refs.append(np.array(r, np.uint8)); qrys.append(q)
+    return refs, qrys
+
+
+def make_sw_rescue_vectors(lib=None):
+    """aln_local_core / aln_extend_core known answers at the sizes the kernels are used at -> vectors_sw_rescue.npz:
+    400 rescue-shaped local tasks under aln_param_bwa, 6 local and 6 extension tasks long enough for the 16-bit drop, 40 extension tasks
+    of 100 - 400 bases (band 50 and 12).  For every local task: score, sub-optimal score, the path's first and last cell, the CIGAR."""
+    if lib is None:
+        lib = C.CDLL(REFLIB)
+    lib.ref_extend.restype = C.c_int
+    lib.ref_local.restype = C.c_int
+    sm_maq = np.array([11, -19, -19, -19, -13, -19, 11, -19, -19, -13, -19, -19, 11, -19, -13, -19, -19, -19, 11, -13, -13, -13, -13, -13, -13], np.int32)
+    rng = np.random.default_rng(77)
+    cap = 1 << 15
+    cig = (C.c_uint32 * cap)()
+    path = np.zeros(3 * cap, np.int32)
+    ncig, plen, subo = C.c_int(), C.c_int(), C.c_int()
+    out = {}
+    cat = lambda xs, dt: np.concatenate([np.asarray(x, dt) for x in xs]) if xs else np.zeros(0, dt)
+    offs = lambda xs: np.cumsum([0] + [len(x) for x in xs]).astype(np.int64)
+
+    def run_local(refs, qrys, tag):
+        sc, su, co, cg = [], [], [], []
+        for r, q in zip(refs, qrys):
+            s_ = lib.ref_local(r.ctypes.data_as(C.c_void_p), len(r), q.ctypes.data_as(C.c_void_p), len(q), 26, 9, 5, sm_maq.ctypes.data_as(C.c_void_p), 5, 50, 1,
+                               cig, C.byref(ncig), path.ctypes.data_as(C.c_void_p), C.byref(plen), C.byref(subo))
+            sc.append(s_); su.append(subo.value); cg.append(np.array(cig[:ncig.value], np.uint32))
+            n_p = plen.value
+            # the path runs from the end cell back to the start cell (1-based i on the window, j on the read)
+            co.append([path[3 * (n_p - 1)], path[3 * (n_p - 1) + 1], path[0], path[1]] if n_p > 0 else [0, 0, 0, 0])
+        out[tag + "_ref"], out[tag + "_ref_off"], out[tag + "_qry"], out[tag + "_qry_off"] = cat(refs, np.uint8), offs(refs), cat(qrys, np.uint8), offs(qrys)
+        out[tag + "_score"], out[tag + "_subo"], out[tag + "_coords"] = np.array(sc, np.int32), np.array(su, np.int32), np.array(co, np.int32)
+        out[tag + "_cig"], out[tag + "_cig_off"] = cat(cg, np.uint32), offs(cg)
+
+    def run_extend(refs, qrys, g0s, bands, tag):
+        sc, cg = [], []
+        for r, q, g0, bw in zip(refs, qrys, g0s, bands):
+            s_ = lib.ref_extend(r.ctypes.data_as(C.c_void_p), len(r), q.ctypes.data_as(C.c_void_p), len(q), 26, 9, 5, sm_maq.ctypes.data_as(C.c_void_p), 5, int(bw), int(g0),
+                                cig, C.byref(ncig), None, C.byref(plen))
+            sc.append(s_); cg.append(np.array(cig[:ncig.value], np.uint32))
+        out[tag + "_ref"], out[tag + "_ref_off"], out[tag + "_qry"], out[tag + "_qry_off"] = cat(refs, np.uint8), offs(refs), cat(qrys, np.uint8), offs(qrys)
+        out[tag + "_g0"], out[tag + "_band"], out[tag + "_score"] = np.array(g0s, np.int32), np.array(bands, np.int32), np.array(sc, np.int32)
+        out[tag + "_cig"], out[tag + "_cig_off"] = cat(cg, np.uint32), offs(cg)
+
+    refs, qrys = rescue_tasks(rng)
+    run_local(refs, qrys, "loc")
+    refs, qrys = long_tasks(rng, 6, False)
+    run_local(refs, qrys, "loclong")
+    assert out["loclong_score"].max() > 32000
+    refs, qrys = long_tasks(rng, 6, True)
+    run_extend(refs, qrys, [int(rng.integers(1, 60)) for _ in refs], [50] * len(refs), "extlong")
+    assert out["extlong_score"].max() > 32000
+    refs, qrys = [], []
+    for t in range(40):
+        lr = int(rng.integers(100, 400))
+        q = rng.integers(0, 4, lr).astype(np.uint8)
+        r = list(q)
+        for _ in range(int(rng.integers(0, 8))):
+            pos = int(rng.integers(0, len(r)))
+            k = int(rng.integers(0, 3))
+            if k == 0 and len(r) > 1:
+                del r[pos]
+            elif k == 1:
+                r.insert(pos, int(rng.integers(0, 4)))
+            else:
+                r[pos] = (r[pos] + 1) % 4
+        if t % 5 == 0:                                                      # the read runs off into unrelated sequence half-way
+            r[len(r) // 2:] = list(rng.integers(0, 4, len(r) - len(r) // 2))
+        refs.append(np.array(r + list(rng.integers(0, 4, int(rng.integers(0, 60)))), np.uint8)); qrys.append(q)
+    run_extend(refs, qrys, [int(rng.integers(1, 80)) for _ in refs], [50 if t % 2 else 12 for t in range(40)], "ext")
+    np.savez_compressed(os.path.join(HERE, "vectors_sw_rescue.npz"), **out)
+    print("vectors_sw_rescue.npz: %d local tasks (%d found), long local scores %s, long extension scores %s"
+          % (len(out["loc_score"]), int((out["loc_score"] > 0).sum()), out["loclong_score"].tolist(), out["extlong_score"].tolist()))
+
+
 def make_pe_vectors(lib):
     """insert-size inference (insert_size.c) and pairing (bwape.c:180-293) known answers -> vectors_pe.npz"""
     rng = np.random.default_rng(777)
@@ -715,5 +837,7 @@ if __name__ == "__main__":
         make_pe_chain()
     elif len(sys.argv) > 1 and sys.argv[1] == "pe_chain150":
         make_pe_chain(tag="150", L=150, mu=400, sd=40, heavy=True, seed=150150)
+    elif len(sys.argv) > 1 and sys.argv[1] == "sw_rescue":
+        make_sw_rescue_vectors()
     else:
         main()

@@ -123,10 +123,30 @@ def test_se_chain_matches_reference_sam(name):
     ix.close()
 
 
-@pytest.mark.parametrize("small", ["4096", "0"])
-def test_extend_align_golden(monkeypatch, small):
-    monkeypatch.setenv("NABWA_DP_SMALL", small)
+FORMS = [("lds", "diag"), ("hbm", "diag"), ("lds", "rows"), ("hbm", "rows")]
+
+
+def set_form(monkeypatch, rows, forward="diag"):
+    """the switches of dp_wave.hip: the two rows of a task in LDS or in HBM (NABWA_DP_ROWS), and the forward pass of the local alignment
+    along the anti-diagonals or row by row -- the form that carries the reference's 16-bit drop (NABWA_DP_FORWARD)"""
+    monkeypatch.setenv("NABWA_DP_ROWS", rows)
+    monkeypatch.setenv("NABWA_DP_FORWARD", forward)
+
+
+def flat(v, tag, idx=None):
+    ro, qo = v[tag + "_ref_off"], v[tag + "_qry_off"]
+    idx = range(len(ro) - 1) if idx is None else idx
+    refs = [v[tag + "_ref"][ro[t]:ro[t + 1]] for t in idx]
+    qrys = [v[tag + "_qry"][qo[t]:qo[t + 1]] for t in idx]
+    r_o = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+    q_o = np.concatenate([[0], np.cumsum([len(q) for q in qrys])]).astype(np.int64)
+    return np.concatenate(refs), r_o, np.concatenate(qrys), q_o
+
+
+@pytest.mark.parametrize("rows", ["lds", "hbm"])
+def test_extend_align_golden(monkeypatch, rows):
     """aln_extend_core (named by the north star; reached from bwasw in the reference): known answers from the reference"""
+    set_form(monkeypatch, rows)
     v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
     n = len(v["pid"])
     for pid in range(len(v["params"])):
@@ -144,52 +164,62 @@ def test_extend_align_golden(monkeypatch, small):
             assert list(cigs[j]) == list(want), (pid, t)
 
 
-def test_local_align_forms_agree_on_rescue_sized_tasks(monkeypatch):
+@pytest.mark.parametrize("rows", ["lds", "hbm"])
+@pytest.mark.parametrize("tag", ["ext", "extlong"])
+def test_extend_align_at_size(monkeypatch, rows, tag):
+    """extensions of 100 - 400 bases under two bands, and of 3000 - 3600 bases whose scores pass 32000 -- where the reference's 16-bit rows
+    drop by 16000 (stdaln.c:919-932); answers of the compiled reference (make_golden.py sw_rescue)"""
+    set_form(monkeypatch, rows)
+    v = np.load(os.path.join(T.GOLDEN, "vectors_sw_rescue.npz"))
+    n = len(v[tag + "_score"])
+    for band in sorted(set(v[tag + "_band"].tolist())):
+        idx = [t for t in range(n) if v[tag + "_band"][t] == band]
+        ref, ro, qry, qo = flat(v, tag, idx)
+        score, cigs = nabwa.extend_align(ref, ro, qry, qo, 26, 9, SM[0], int(band), v[tag + "_g0"][idx], max_cigar=512)
+        for j, t in enumerate(idx):
+            assert score[j] == v[tag + "_score"][t], (tag, t)
+            assert list(cigs[j]) == list(v[tag + "_cig"][v[tag + "_cig_off"][t]:v[tag + "_cig_off"][t + 1]]), (tag, t)
+    if tag == "extlong":
+        assert v[tag + "_score"].max() > 32000
+
+
+@pytest.mark.parametrize("rows,forward", FORMS)
+def test_local_align_on_rescue_sized_tasks(monkeypatch, rows, forward):
     """400 tasks shaped like mate rescue (a window of 300 - 620 bases, a read of 70 - 250 with substitutions, an indel now and
-    then, some reads that are not in their window at all, N runs): the wave-per-task form, the LDS form and the HBM form give
-    the same scores, cells, sub-optimal scores and CIGARs (the HBM form is the one the reference's golden vectors pin at size)"""
-    rng = np.random.default_rng(77)
-    refs, qrys = [], []
-    for t in range(400):
-        lw, lr = int(rng.integers(300, 620)), int(rng.integers(70, 250))
-        w = rng.integers(0, 4, lw).astype(np.uint8)
-        if t % 9 == 0:
-            r = rng.integers(0, 4, lr).astype(np.uint8)                    # not there
-        else:
-            p = int(rng.integers(0, lw - lr)) if lw > lr else 0
-            r = w[p:p + lr].copy()
-            sub = rng.random(len(r)) < 0.04
-            r[sub] = rng.integers(0, 4, int(sub.sum()))
-            if t % 4 == 0 and len(r) > 40:
-                c = int(rng.integers(20, len(r) - 20))
-                r = np.concatenate([r[:c], r[c + int(rng.integers(1, 4)):]]) if t % 8 == 0 else np.concatenate([r[:c], rng.integers(0, 4, int(rng.integers(1, 4))).astype(np.uint8), r[c:]])
-        if t % 13 == 0:
-            w[10:14] = 4; r[5:7] = 4
-        refs.append(w); qrys.append(r.astype(np.uint8))
-    ro = np.concatenate([[0], np.cumsum([len(x) for x in refs])]).astype(np.int64)
-    qo = np.concatenate([[0], np.cumsum([len(x) for x in qrys])]).astype(np.int64)
-    maq = SM[0]
-    got = {}
-    for form in ("wave", "lds", "hbm"):
-        monkeypatch.setenv("NABWA_DP_SMALL", "0" if form == "hbm" else "4096")
-        if form == "lds":
-            monkeypatch.setenv("NABWA_DP_NO_WAVE", "1")
-        else:
-            monkeypatch.delenv("NABWA_DP_NO_WAVE", raising=False)
-        score, coords, subo, cigs = nabwa.local_align(np.concatenate(refs), ro, np.concatenate(qrys), qo, 26, 9, maq, 50, 1, max_cigar=62)
-        got[form] = (list(score), [tuple(c) for c in coords], list(subo), [list(c) for c in cigs])
-    assert sum(1 for x in got["hbm"][0] if x > 0) > 300
-    assert got["wave"] == got["hbm"] and got["lds"] == got["hbm"]
+    then, some reads that are not in their window at all, N runs) against the compiled reference's answers (make_golden.py
+    sw_rescue): score, first and last cell of the path, sub-optimal score, CIGAR -- in every form of the kernel"""
+    set_form(monkeypatch, rows, forward)
+    v = np.load(os.path.join(T.GOLDEN, "vectors_sw_rescue.npz"))
+    ref, ro, qry, qo = flat(v, "loc")
+    score, coords, subo, cigs = nabwa.local_align(ref, ro, qry, qo, 26, 9, SM[0], 50, 1, max_cigar=62)
+    assert sum(1 for x in score if x > 0) > 300
+    for t in range(len(score)):
+        assert score[t] == v["loc_score"][t], t
+        assert list(cigs[t]) == list(v["loc_cig"][v["loc_cig_off"][t]:v["loc_cig_off"][t + 1]]), t
+        assert tuple(coords[t]) == tuple(v["loc_coords"][t]), (t, coords[t], v["loc_coords"][t])
+        assert subo[t] == v["loc_subo"][t], t
 
 
-@pytest.mark.parametrize("form", ["wave", "lds", "hbm"])
-def test_local_align_golden(monkeypatch, form):
-    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference; the three
-    forms of the kernel -- a wave per task and a lane per task with its row in LDS for a handful of tasks, a lane per task with the
-    rows in HBM for many (NABWA_DP_SMALL = the task count up to which the first two run)"""
-    monkeypatch.setenv("NABWA_DP_SMALL", "0" if form == "hbm" else "4096")
-    if form == "lds":
-        monkeypatch.setenv("NABWA_DP_NO_WAVE", "1")
+@pytest.mark.parametrize("rows", ["lds", "hbm"])
+def test_local_align_long_reads_take_the_16_bit_drop(monkeypatch, rows):
+    """reads of 3000 - 3600 bases: the forward score passes 32000 and the reference's rows drop by 16000, forward (stdaln.c:583-602) and
+    reverse (:654-666); such tasks go row by row here of themselves"""
+    set_form(monkeypatch, rows)
+    v = np.load(os.path.join(T.GOLDEN, "vectors_sw_rescue.npz"))
+    ref, ro, qry, qo = flat(v, "loclong")
+    score, coords, subo, cigs = nabwa.local_align(ref, ro, qry, qo, 26, 9, SM[0], 50, 1, max_cigar=512)
+    assert v["loclong_score"].max() > 32000
+    for t in range(len(score)):
+        assert score[t] == v["loclong_score"][t], t
+        assert list(cigs[t]) == list(v["loclong_cig"][v["loclong_cig_off"][t]:v["loclong_cig_off"][t + 1]]), t
+        assert tuple(coords[t]) == tuple(v["loclong_coords"][t]) and subo[t] == v["loclong_subo"][t], t
+
+
+@pytest.mark.parametrize("rows,forward", FORMS)
+def test_local_align_golden(monkeypatch, rows, forward):
+    """aln_local_core (mate-rescue Smith-Waterman, bwape.c:456): scores, sub-optimal scores and CIGARs from the reference, in every form
+    of the kernel (a wave per task; rows in LDS or HBM; forward pass along the anti-diagonals or row by row)"""
+    set_form(monkeypatch, rows, forward)
     v = np.load(os.path.join(T.GOLDEN, "vectors_sw.npz"))
     n = len(v["pid"])
     for pid in range(len(v["params"])):
