@@ -457,6 +457,7 @@ struct nabwa_bam_batch {
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
 	bool searched;                                 /* nabwa_bam_batch_search ran */
 	std::vector<uint8_t> parked; std::vector<uint64_t> parked_at;     /* what pass 1 left in res, packed, while a batch with pairs waits for pass 2 */
+	std::vector<uint8_t> wire_multi;                /* nabwa_bam_batch_positioned: the other hits of the reads as raw bwt_multi1_t */
 	size_t res_bytes;
 	nabwa_bam_batch() : arena(0), arena_bytes(0), flags(0), res(0), phase(0), searched(false), res_bytes(0) {}
 	~nabwa_bam_batch() { res_give(res, res_bytes); rec.clear(); res_give(arena, arena_bytes); }
@@ -736,6 +737,68 @@ extern "C" int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabw
 	if (b->kind.size() != b->rec.size()) park(b);
 	b->phase = 1;
 	if (timing) fprintf(stderr, "[nabwa] bam_batch_pass1 %d records: search (upload, kernels, rows back) %.3f s, posn + insert-size bins %.3f s\n", n, tp1 - tp0, bam_now() - tp1);
+	return NABWA_OK;
+}
+
+/* ---- the state pass 1 leaves, out of the batch and back into a fresh one (the wire record's positioned / aligned parts) */
+extern "C" int nabwa_bam_batch_positioned(nabwa_bam_batch_t *b, nabwa_wire_read_t *out)
+{
+	if (!b || !out) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (b->phase != 1) return nabwa_fail(NABWA_EINVAL, "the batch is not between the passes");
+	if (!b->res && !unpark(b)) return nabwa_fail(NABWA_ENOMEM, "out of memory for the batch's records");
+	const size_t n = b->rec.size();
+	std::vector<size_t> m0(n + 1, 0);
+	for (size_t i = 0; i < n; ++i) m0[i + 1] = m0[i] + (size_t)b->res[i].se.n_multi;
+	b->wire_multi.assign(16 * (m0[n] ? m0[n] : 1), 0);
+	for (size_t i = 0; i < n; ++i) {
+		const nabwa_se_t &s = b->res[i].se; nabwa_wire_read_t &w = out[i];
+		w.strand = (uint8_t)s.strand; w.type = (uint8_t)s.type; w.n_mm = (uint8_t)s.n_mm; w.n_gapo = (uint8_t)s.n_gapo; w.n_gape = (uint8_t)s.n_gape;
+		w.seQ = (uint8_t)s.seQ; w.mapQ = (uint8_t)s.mapQ; w.len = s.len; w.clip_len = s.clip_len; w.score = s.score; w.sa = s.sa; w.c1 = s.c1; w.c2 = s.c2; w.pos = s.pos;
+		w.n_multi = s.n_multi; w.multi = b->wire_multi.data() + 16 * m0[i];
+		for (int j = 0; j < s.n_multi; ++j) {                     /* bwt_multi1_t (bwtaln.h:58-62): pos, n_cigar:15 | gap:8 | mm:8 | strand:1, a pointer that means nothing outside its process */
+			uint8_t *o = b->wire_multi.data() + 16 * (m0[i] + (size_t)j);
+			const uint32_t pos = s.multi[j].pos, bits = ((uint32_t)s.multi[j].gap & 0xff) << 15 | ((uint32_t)s.multi[j].mm & 0xff) << 23 | ((uint32_t)s.multi[j].strand & 1) << 31;
+			memcpy(o, &pos, 4); memcpy(o + 4, &bits, 4);
+		}
+		w.max_entries = b->max_ent[i]; w.n_aln = b->n_aln[i]; w.aln = (const uint8_t*)(b->rows.data() + b->row0[i]);
+	}
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_bam_batch_restore(nabwa_bam_batch_t *b, const nabwa_wire_read_t *in)
+{
+	if (!b || !in) return nabwa_fail(NABWA_EINVAL, "null argument");
+	if (b->phase != 0 || b->searched) return nabwa_fail(NABWA_EINVAL, "restore needs a batch that was just created");
+	const int n = (int)b->rec.size();
+	b->n_aln.assign(n ? n : 1, 0); b->max_ent.assign(n ? n : 1, 0); b->row0.assign(n + 1, 0);
+	for (int i = 0; i < n; ++i) {
+		const nabwa_wire_read_t &w = in[i];
+		if (w.n_aln < 0 || w.n_multi < 0 || w.n_multi > NABWA_MAX_MULTI || (w.n_aln && !w.aln) || (w.n_multi && !w.multi)) { char m[96]; snprintf(m, sizeof m, "record %d: counts out of range", i); return nabwa_fail(NABWA_EINVAL, "%s", m); }
+		if ((int64_t)w.len != b->off[i + 1] - b->off[i]) { char m[160]; snprintf(m, sizeof m, "record %d: positioned with a length of %d, the batch has %lld (other trimming options?)", i, w.len, (long long)(b->off[i + 1] - b->off[i])); return nabwa_fail(NABWA_EINVAL, "%s", m); }
+		b->n_aln[i] = w.n_aln; b->max_ent[i] = w.max_entries; b->row0[i + 1] = b->row0[i] + w.n_aln;
+	}
+	b->rows.resize(b->row0[n] ? (size_t)b->row0[n] : 1);
+	res_give(b->res, b->res_bytes);
+	b->res_bytes = sizeof(nabwa_pe_t) * (size_t)(n ? n : 1);
+	b->res = (nabwa_pe_t*)res_take(b->res_bytes);
+	if (!b->res) return nabwa_fail(NABWA_ENOMEM, "out of memory for the batch's records");
+	bam_parallel((size_t)n, [&](int, size_t lo, size_t hi) {
+		for (size_t i = lo; i < hi; ++i) {
+			const nabwa_wire_read_t &w = in[i]; nabwa_pe_t &r = b->res[i]; nabwa_se_t &s = r.se;
+			if (w.n_aln) memcpy(b->rows.data() + b->row0[i], w.aln, 16 * (size_t)w.n_aln);
+			memset(&s, 0, offsetof(nabwa_se_t, cigar));                            /* as nabwa_se_posn leaves a record */
+			s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
+			s.type = w.type & 3; s.strand = w.strand & 1; s.n_mm = w.n_mm; s.n_gapo = w.n_gapo; s.n_gape = w.n_gape; s.score = w.score; s.sa = w.sa; s.pos = w.pos;
+			s.c1 = w.c1 & 0xfffffff; s.c2 = w.c2 & 0xfffffff; s.mapQ = w.mapQ; s.seQ = w.seQ; s.len = w.len; s.clip_len = w.clip_len; s.full_len = b->full_len[i];
+			s.n_multi = w.n_multi;
+			for (int j = 0; j < w.n_multi; ++j) {
+				uint32_t pos, bits; memcpy(&pos, w.multi + 16 * (size_t)j, 4); memcpy(&bits, w.multi + 16 * (size_t)j + 4, 4);
+				s.multi[j].pos = pos; s.multi[j].gap = bits >> 15 & 0xff; s.multi[j].mm = bits >> 23 & 0xff; s.multi[j].strand = bits >> 31; s.multi[j].n_cigar = 0;
+			}
+			r.extra_flag = 0; r.m_seqid = 0; r.am = 0; r.mapQ_paired = 0; r.m_rpos = 0; r.isize = 0;
+		}
+	});
+	b->searched = true; b->phase = 1;
 	return NABWA_OK;
 }
 
