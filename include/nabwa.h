@@ -360,6 +360,8 @@ int nabwa_bam_batch_pass1(nabwa_bam_batch_t *b, uint64_t *rng48, nabwa_isize_tab
 int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_table_t *tab, uint64_t n_tot[2], uint64_t n_mapped[2]);
 int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, int64_t cap, int64_t *out_off, int64_t *n_bytes);
 int nabwa_bam_batch_counts(const nabwa_bam_batch_t *b, int *n_records, int *n_logical);
+/* per logical record: 1 (a single read) or 2 (a pair); n_logical entries */
+int nabwa_bam_batch_kinds(const nabwa_bam_batch_t *b, uint8_t *kind_out);
 void nabwa_bam_batch_destroy(nabwa_bam_batch_t *b);
 
 /* ---- 0MQ worker compatibility: the wire record, and a worker core that is independent of the transport ----------

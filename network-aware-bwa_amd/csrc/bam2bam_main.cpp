@@ -114,6 +114,69 @@ static std::string header_text(nabwa_index_t *ix, const std::string &old, int ar
 	return t;
 }
 
+/* ---------------------------------------------------------------- the temporary file between the passes (bam2bam.c:1099-1135, 1733-1758)
+ * With --temp-dir a batch that has to wait for the insert-size estimates does not wait in memory: its records leave as the reference's
+ * temporary file holds them -- u32 length + the message of msg_init_from_pair, positioned (or finished, for a batch of single reads
+ * that only waits for its turn) -- and come back batch by batch for pass 2.  (Plain, not gzip: one core of deflate would pace the file.) */
+struct Spilled { long at; int n_logical, n_records; bool finished; size_t dev; };
+static void spill_batch(FILE *f, nabwa_bam_batch_t *b, bool finished, Spilled &S)
+{
+	int nr = 0, nl = 0; nabwa_bam_batch_counts(b, &nr, &nl);
+	std::vector<uint8_t> kinds((size_t)(nl ? nl : 1));
+	nabwa_bam_batch_kinds(b, kinds.data());
+	int64_t nb = 0; std::vector<int64_t> oo((size_t)nr + 1, 0);
+	nabwa_bam_batch_output(b, 0, 0, oo.data(), &nb);
+	std::vector<uint8_t> ob((size_t)(nb ? nb : 1));
+	if (nabwa_bam_batch_output(b, ob.data(), nb, oo.data(), &nb) != NABWA_OK) die("temporary file", nabwa_last_error());
+	std::vector<nabwa_wire_read_t> st((size_t)(nr ? nr : 1));
+	memset(st.data(), 0, sizeof(nabwa_wire_read_t) * st.size());
+	if (!finished && nabwa_bam_batch_positioned(b, st.data()) != NABWA_OK) die("temporary file", nabwa_last_error());
+	S.at = ftell(f); S.n_logical = nl; S.n_records = nr; S.finished = finished;
+	std::vector<uint8_t> msg;
+	int at = 0;
+	for (int k = 0; k < nl; ++k) {
+		nabwa_wire_rec_t r; memset(&r, 0, sizeof r);
+		r.recno = (uint64_t)k; r.kind = kinds[(size_t)k]; r.phase = finished ? NABWA_PHASE_FINISHED : NABWA_PHASE_POSITIONED;
+		for (int e = 0; e < r.kind; ++e, ++at) {
+			r.read[e] = st[(size_t)at];
+			const uint8_t *rec = ob.data() + oo[(size_t)at];
+			nabwa_wire_core_from_bam(rec + 4, r.read[e].core);
+			r.read[e].data = rec + 36; r.read[e].data_len = (int32_t)(oo[(size_t)at + 1] - oo[(size_t)at] - 36);
+		}
+		const int64_t need = nabwa_wire_size(&r);
+		msg.resize((size_t)need + 4);
+		const uint32_t len = (uint32_t)need;
+		memcpy(msg.data(), &len, 4);
+		if (nabwa_wire_encode(&r, msg.data() + 4, need) != need || fwrite(msg.data(), 1, msg.size(), f) != msg.size()) die("temporary file", "cannot write");
+	}
+}
+/* one batch back: its records as a BAM stream and, unless it was finished, the state pass 1 left */
+static void unspill_batch(FILE *f, const Spilled &S, std::vector<uint8_t> &stream, std::vector<int64_t> &off, std::vector<nabwa_wire_read_t> &st, std::vector<std::vector<uint8_t>> &keep)
+{
+	if (fseek(f, S.at, SEEK_SET) != 0) die("temporary file", "cannot seek");
+	stream.clear(); off.assign(1, 0); st.clear(); keep.clear();
+	for (int k = 0; k < S.n_logical; ++k) {
+		uint32_t len = 0;
+		if (fread(&len, 4, 1, f) != 1) die("temporary file", "truncated");
+		keep.emplace_back((size_t)len);
+		if (len && fread(keep.back().data(), 1, len, f) != len) die("temporary file", "truncated");
+		nabwa_wire_rec_t r;
+		if (nabwa_wire_decode(keep.back().data(), (int64_t)len, &r) != NABWA_OK) die("temporary file", nabwa_last_error());
+		for (int e = 0; e < r.kind; ++e) {
+			const nabwa_wire_read_t &x = r.read[e];
+			const uint32_t bs = 32u + (uint32_t)x.data_len;
+			const size_t at = stream.size();
+			stream.resize(at + 4 + bs);
+			memcpy(&stream[at], &bs, 4);
+			nabwa_wire_core_to_bam(x.core, &stream[at + 4]);
+			if (x.data_len) memcpy(&stream[at + 36], x.data, (size_t)x.data_len);
+			off.push_back((int64_t)stream.size());
+			st.push_back(x);
+		}
+	}
+	if ((int)st.size() != S.n_records) die("temporary file", "a batch came back with another number of records");
+}
+
 int main(int argc, char **argv)
 {
 	const double t_main = now_s();
@@ -129,7 +192,7 @@ int main(int argc, char **argv)
 		{ "chimeric-rate", 1, 0, 'c' }, { "disable-sw", 0, 0, 's' }, { "disable-isize-estimate", 0, 0, 'A' }, { "listen-port", 1, 0, 'p' }, { 0, 0, 0, 0 } };
 	nabwa_gap_opt_t go; nabwa_gap_init_opt(&go);
 	nabwa_pe_opt_t po; nabwa_pe_opt_default(&po);
-	const char *prefix = 0, *ofile = 0; int c, opte = -1;
+	const char *prefix = 0, *ofile = 0, *temp_dir = 0; int c, opte = -1;
 	while ((c = getopt_long(argc, argv, "g:n:o:e:i:d:l:k:LR:m:t:NM:O:E:q:f:C:D:a:sc:h:H:Ap:0:1:2:", longopts, 0)) >= 0) {
 		switch (c) {
 			case 'g': prefix = optarg; break;
@@ -158,7 +221,7 @@ int main(int argc, char **argv)
 			case 'A': po.force_isize = 1; break;
 			case 'h': po.n_multi = atoi(optarg); break;
 			case 'H': po.N_multi = atoi(optarg); break;
-			case 132: break;
+			case 132: temp_dir = optarg; break;
 			case 128: rec_flags |= NABWA_BAM_ONLY_ALIGNED; break;
 			case 129: rec_flags |= NABWA_BAM_DEBUG; break;
 			case 130: rec_flags |= NABWA_BAM_BROKEN_INPUT; break;
@@ -324,6 +387,14 @@ int main(int argc, char **argv)
 	};
 	std::thread finisher([&]() { nabwa_bam_batch_t *b; while (done_ch.get(b)) emit(b); });
 	std::vector<nabwa_bam_batch_t*> waiting;
+	/* --temp-dir: what waits for pass 2 waits in a file there (made with mkstemp and unlinked at once, as the reference's is at exit) */
+	FILE *spill = 0; std::vector<Spilled> spilled;
+	if (temp_dir) {
+		std::string tn = std::string(temp_dir) + "/nabwa_bam2bam_XXXXXX";
+		const int fd = mkstemp(&tn[0]);
+		if (fd < 0 || !(spill = fdopen(fd, "w+b"))) die(temp_dir, "cannot create a temporary file there");
+		unlink(tn.c_str());
+	}
 	uint64_t n_tot[2] = { 0, 0 }, n_mapped[2] = { 0, 0 };
 	long tot_seqs = 0; bool any_pairs = false;
 	for (size_t k = 0; ; ++k) {
@@ -343,7 +414,9 @@ int main(int argc, char **argv)
 		if (nr == nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
 		const double t2 = now_s();
 		if (nr == nl) t_call[2] += t2 - td;
-		if (nr == nl && !any_pairs) done_ch.put(std::move(b)); else waiting.push_back(b);
+		if (nr == nl && !any_pairs) done_ch.put(std::move(b));
+		else if (spill) { Spilled S; S.dev = k % n_dev; spill_batch(spill, b, nr == nl, S); spilled.push_back(S); nabwa_bam_batch_destroy(b); }
+		else waiting.push_back(b);
 		t_lib += t2 - t1;
 	}
 	reader.join(); creator.join();
@@ -357,6 +430,33 @@ int main(int argc, char **argv)
 		if (nr != nl && nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
 		t_lib += now_s() - t1; t_call[2] += now_s() - t1;
 		done_ch.put(std::move(b));
+	}
+	if (spill) {
+		std::vector<uint8_t> stream; std::vector<int64_t> off; std::vector<nabwa_wire_read_t> st; std::vector<std::vector<uint8_t>> keep;
+		for (const Spilled &S : spilled) {
+			const double t1 = now_s();
+			unspill_batch(spill, S, stream, off, st, keep);
+			if (S.finished) {                                     /* single reads that only waited for their turn: their records as they are */
+				std::vector<int64_t> pick;
+				size_t nb = 0;
+				for (size_t i = 0; i + 1 < off.size(); ++i) {     /* --only-aligned (pair_print_bam, bam2bam.c:911-925) on the finished records */
+					uint32_t z; memcpy(&z, &stream[(size_t)off[i] + 16], 4);
+					if ((rec_flags & NABWA_BAM_ONLY_ALIGNED) && ((z >> 16) & 4)) continue;
+					pick.push_back((int64_t)i); nb += (size_t)(off[i + 1] - off[i]);
+				}
+				OutBytes o; o.p.reset(new uint8_t[nb ? nb : 1]); o.n = nb;
+				size_t w = 0;
+				for (int64_t i : pick) { memcpy(o.p.get() + w, &stream[(size_t)off[(size_t)i]], (size_t)(off[(size_t)i + 1] - off[(size_t)i])); w += (size_t)(off[(size_t)i + 1] - off[(size_t)i]); }
+				out_ch.put(std::move(o));
+				continue;
+			}
+			nabwa_bam_batch_t *b = 0;
+			if (nabwa_bam_batch_create_ex(ixs[S.dev], &go, &po, rec_flags & ~(uint32_t)(NABWA_BAM_BROKEN_INPUT | NABWA_BAM_DROP_ALIGNED), S.n_records, stream.data(), off.data(), &b) != NABWA_OK
+				|| nabwa_bam_batch_restore(b, st.data()) != NABWA_OK || nabwa_bam_batch_pass2(b, tab, n_tot, n_mapped) != NABWA_OK) die("pass 2", nabwa_last_error());
+			t_lib += now_s() - t1; t_call[2] += now_s() - t1;
+			done_ch.put(std::move(b));
+		}
+		fclose(spill);
 	}
 	done_ch.close(); finisher.join();
 	out_ch.close();

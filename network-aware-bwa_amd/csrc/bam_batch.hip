@@ -926,7 +926,7 @@ extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, 
 	for (size_t k = 0; k < b->kind.size(); ++k) {
 		const int i = b->first[k];
 		bool keep = true;
-		if (b->flags & NABWA_BAM_ONLY_ALIGNED) for (int e = 0; e < b->kind[k]; ++e) if (b->rec[i + e].flag & F_SU) keep = false;
+		if ((b->flags & NABWA_BAM_ONLY_ALIGNED) && b->phase == 2) for (int e = 0; e < b->kind[k]; ++e) if (b->rec[i + e].flag & F_SU) keep = false;      /* (before pass 2 the flag is the input's) */
 		if (keep) for (int e = 0; e < b->kind[k]; ++e) pick.push_back(i + e);
 	}
 	const size_t m = pick.size();
@@ -937,6 +937,13 @@ extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, 
 	*n_bytes = at[m];
 	if (!out || cap < at[m]) return nabwa_fail(NABWA_ECAP, "output buffer too small");
 	bam_parallel(m, [&](int, size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) write_rec(b->rec[pick[t]], out + at[t]); });
+	return NABWA_OK;
+}
+
+extern "C" int nabwa_bam_batch_kinds(const nabwa_bam_batch_t *b, uint8_t *kind_out)
+{
+	if (!b || !kind_out) return nabwa_fail(NABWA_EINVAL, "null argument");
+	for (size_t k = 0; k < b->kind.size(); ++k) kind_out[k] = (uint8_t)b->kind[k];
 	return NABWA_OK;
 }
 

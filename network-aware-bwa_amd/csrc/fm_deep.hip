@@ -14,21 +14,24 @@
 
 extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];
 
-template <bool PROF>
+template <bool PROF, bool LDSM>
 __global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
 {
-	deep_wave_body<PROF>(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
+	deep_wave_body<PROF, LDSM>(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
 }
 
 extern "C" void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s)
 {
 	const size_t lds = (size_t)DEEP_LDS_WORDS(P->NS, P->lds_rd) * 4u;
-	if (P->stats || P->S.touch_counter) hipLaunchKernelGGL(fm_deep_kernel<true>, dim3(n_waves), dim3(64), lds, s, *P);
-	else hipLaunchKernelGGL(fm_deep_kernel<false>, dim3(n_waves), dim3(64), lds, s, *P);
+	const bool prof = P->stats || P->S.touch_counter, ldsm = P->lds_rd != 0u;
+	if (prof && ldsm) hipLaunchKernelGGL((fm_deep_kernel<true, true>), dim3(n_waves), dim3(64), lds, s, *P);
+	else if (prof) hipLaunchKernelGGL((fm_deep_kernel<true, false>), dim3(n_waves), dim3(64), lds, s, *P);
+	else if (ldsm) hipLaunchKernelGGL((fm_deep_kernel<false, true>), dim3(n_waves), dim3(64), lds, s, *P);
+	else hipLaunchKernelGGL((fm_deep_kernel<false, false>), dim3(n_waves), dim3(64), lds, s, *P);
 }
 
 extern "C" int nabwa_deep_occupancy(int ns, int lds_rd)
 {
 	int nb = 0;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fm_deep_kernel<false>, 64, (size_t)DEEP_LDS_WORDS((unsigned)ns, (unsigned)lds_rd) * 4u) == hipSuccess ? nb : 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lds_rd ? fm_deep_kernel<false, true> : fm_deep_kernel<false, false>, 64, (size_t)DEEP_LDS_WORDS((unsigned)ns, (unsigned)lds_rd) * 4u) == hipSuccess ? nb : 0;
 }

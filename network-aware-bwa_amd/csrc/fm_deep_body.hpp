@@ -85,7 +85,10 @@ DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u 
 // One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
 // PROF: the statistics (rounds, chains, phase clocks) cost scalar and vector registers, so the build without them is the one that runs
 // unless NABWA_TIMING / NABWA_DEEP_STATS ask for them
-template <bool PROF>
+// LDSM: the read's own data (bound bytes, seed bound bytes, bases) sit in the wave's LDS -- every read that fits (NABWA_DEEP_LDS_MAX); the other
+// instantiation reads them where kernel W / the batch put them.  A template flag, not a runtime one: the chain step consults these
+// bytes six times, and both ways of getting at them were in its code.
+template <bool PROF, bool LDSM>
 DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #ifndef NABWA_EMU
 							, const int ln
@@ -101,7 +104,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	uint32_t *const s_cnt = lds, *const s_top = lds + ns2, *const s_newp = lds + 2 * ns2;
 	uint32_t *const s_off = s_newp + DEEP_NEWP;                           // 4 x 64 words: per lane the offsets of its records and of its children in the three classes (commit)
 	uint8_t *const s_bb = (uint8_t*)(s_off + 256), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
-	const bool lds_mode = P.lds_rd != 0u;
+	constexpr bool lds_mode = LDSM;
 	const uint32_t PL = P.rd_pl;
 	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
 	uint4 *const stage = P.stage + (size_t)wave * 64 * P.stage_k * 4;     // [lane][stage_k] records of 64 bytes
@@ -110,7 +113,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
 	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
-	unsigned long long st_lanesteps = 0;
+	unsigned long long st_lanesteps = 0, st_onerow = 0, st_mixed = 0, st_expand = 0, st_allone = 0;      // (statistics) expanding lane-steps, those on one-row intervals, wave-steps with both kinds / only one-row
 	unsigned long long ph_pop = 0, ph_chain = 0, ph_tail = 0, ph_commit = 0, ph_hit = 0, st_tailit = 0;      // (statistics) time per phase of a round
 	const bool prof = PROF && P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
 	const unsigned long long clk_start = DEEP_CLOCK();
@@ -246,6 +249,11 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// ---------------------------------------------------------------- the chains
 				while (WBALLOT(L(act)) != 0ull) {
 					if (PROF) { ++st_steps; st_lanesteps += (unsigned)__popcll((unsigned long long)WBALLOT(L(act))); }
+					if (PROF) {      // how many of the lanes that will expand stand on ONE row (what a text step would serve)
+						const uint64_t ex_ = WBALLOT(L(act) && L(e).i > 0), on_ = WBALLOT(L(act) && L(e).i > 0 && L(e).k == L(e).l);
+						st_expand += (unsigned)__popcll((unsigned long long)ex_); st_onerow += (unsigned)__popcll((unsigned long long)on_);
+						if (on_ && on_ != ex_) ++st_mixed; else if (on_) ++st_allone;
+					}
 					LANES { if (L(act)) {
 						DeepLane &E = L(e);
 						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
@@ -607,6 +615,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
 			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit); atomicAdd(P.stats + 22, st_lanesteps);
+			atomicAdd(P.stats + 23, st_expand); atomicAdd(P.stats + 24, st_onerow); atomicAdd(P.stats + 25, st_mixed); atomicAdd(P.stats + 26, st_allone);
 			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}

@@ -913,6 +913,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
 				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f; active lanes per chain step %.1f\n",
 						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
+				fprintf(stderr, "[nabwa] kernel D chain steps: %llu lane-steps that reach the expansion test, %llu of them on one-row intervals; wave-steps with only such lanes %llu, with both kinds %llu\n", st[23], st[24], st[26], st[25]);
 			}
 			if (pass == 0 && dump_path) {
 				std::vector<uint32_t> rounds(dump_ids.size());

@@ -198,7 +198,8 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	P.pages = pages.data(); P.page_prev = prev.data(); P.page_bump = &bump; P.own = own.data(); P.stage = stage.data();
 	for (int w = 0; w < n_waves; ++w) {
 		S.n = per_wave > 0 ? ((w + 1) * per_wave < n ? (w + 1) * per_wave : n) : n;
-		deep_wave_body<true>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
+		if (P.lds_rd) deep_wave_body<true, true>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
+		else deep_wave_body<true, false>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
 		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
 	}
 	stats[8] = wt; stats[9] = st;

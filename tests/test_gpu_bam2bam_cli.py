@@ -393,3 +393,37 @@ def test_config1_ecoli_size_genome_10k_reads_against_the_reference_commands(tmp_
     assert len(out) == len(sam) == 10000
     check_se(out, sam)
     assert sum(1 for o in out if not (o["flag"] & 4)) > 9900
+
+
+@pytest.mark.parametrize("switches", [[], ["--only-aligned"], ["--skip-duplicates", "--debug-bam"]])
+def test_temp_dir_keeps_what_waits_for_pass_2_in_a_file(tmp_path, switches):
+    """--temp-dir (bam2bam.c:1733-1758): batches that have to wait for the insert-size estimates leave memory as the reference's temporary
+    file holds them (u32 length + the positioned message of msg_init_from_pair; a batch of single reads that only waits for its turn as
+    finished records) and come back for pass 2.  Same input, small batches, pairs of two read groups between single reads: the output is
+    the output of the run that kept everything in memory, byte for byte."""
+    se = T.read_fastq(os.path.join(T.GOLDEN, "reads_se.fq"))[:150]
+    pe = [T.read_fastq(os.path.join(T.GOLDEN, "reads_pe_%d.fq" % e)) for e in (1, 2)]
+    recs = []
+    for i in range(260):
+        if i % 2 == 0 and i // 2 < len(se):
+            n, s, q = se[i // 2]
+            recs.append(B.make_record(n, s, q, 4 | (0x400 if i % 14 == 0 else 0)))
+        n, s1, q1 = pe[0][i]
+        _, s2, q2 = pe[1][i]
+        rg = B.tag_z("RG", "libA" if i % 3 else "libB")
+        recs.append(B.make_record(n, s1, q1, 1 | 64 | 4 | 8, rg))
+        recs.append(B.make_record(n, s2, q2, 1 | 128 | 4 | 8, rg))
+    a = tmp_path / "a"; b = tmp_path / "b"; tdir = tmp_path / "scratch"
+    for d in (a, b, tdir):
+        d.mkdir()
+    env = {"NABWA_BAM_BATCH": "64"}
+    text_a, refs_a, out_a = run(a, recs, switches, env=env)
+    text_b, refs_b, out_b = run(b, recs, switches + ["--temp-dir", str(tdir)], env=env)
+    assert refs_a == refs_b and len(out_a) == len(out_b) > 0
+    assert out_a == out_b
+    assert os.listdir(str(tdir)) == []                               # the file is gone with the process (unlinked when it was made)
+    raw_a = gzip.decompress(open(str(a / "out.bam"), "rb").read())
+    raw_b = gzip.decompress(open(str(b / "out.bam"), "rb").read())
+    assert raw_a[raw_a.index(b"\n@SQ"):] == raw_b[raw_b.index(b"\n@SQ"):]      # everything after the @PG line (it holds the command line)
+    if not switches:
+        assert len(out_a) == len(recs)
