@@ -199,6 +199,7 @@ struct RecBuf {
 struct BamRec {                    /* one record, parsed: offsets are into `data` (everything after the 32 bytes of core) */
 	int32_t tid, pos; uint32_t bin, mapq, l_qname, flag, n_cigar; int32_t l_qseq, mtid, mpos, isize;
 	RecBuf data;                   /* qname, cigar, seq, qual, tags */
+	const uint8_t *rg_p; uint32_t rg_n;      /* its read group (bam_get_rg), a view into data: found while the record is being parsed */
 	size_t off_cigar() const { return l_qname; }
 	size_t off_seq() const { return l_qname + 4 * (size_t)n_cigar; }
 	size_t off_qual() const { return off_seq() + ((size_t)l_qseq + 1) / 2; }
@@ -464,6 +465,8 @@ struct nabwa_bam_batch {
 };
 
 static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };      /* bam_nt16_nt4_table (bwaseqio.c:10) */
+/* the same for the two bases of a byte at once: low byte = the code of the high nibble (the earlier base), high byte = that of the low nibble */
+static const struct Nt16Pair { uint16_t v[256]; Nt16Pair() { for (int x = 0; x < 256; ++x) v[x] = (uint16_t)(nt16_nt4[x >> 4] | nt16_nt4[x & 15] << 8); } uint16_t operator[](uint8_t x) const { return v[x]; } } nt16_pair;
 
 extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
 									  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out)
@@ -494,9 +497,17 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
 		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) {
 			for (size_t i = lo; i < hi; ++i)
-				if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], b->rec[i], b->arena + (in_off[i] - in_off[0]) + i * (size_t)(REC_ROOM - 36))) bad[t] = 1;
+			{
+				/* one pass over a record while it is in the cache: parse, erase_unwanted_tags, bam_get_rg (neither depends on how the records
+				 * pair up; a record the pairing drops has been cleaned in vain) */
+				BamRec &r = b->rec[i];
+				if (!parse_rec(in + in_off[i], in_off[i + 1] - in_off[i], r, b->arena + (in_off[i] - in_off[0]) + i * (size_t)(REC_ROOM - 36))) { bad[t] = 1; continue; }
+				if (!erase_tags(r)) { bad[t] = 2; continue; }
+				const auto v = get_rg(r);
+				r.rg_p = v.first; r.rg_n = (uint32_t)v.second;
+			}
 		});
-		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
+		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, x == 2 ? "malformed tags in a BAM record" : "malformed BAM record"); }
 	}
 	const double tc1 = bam_now();
 	/* logical records (read_bam_pair_core, bwaseqio.c:346-410): a paired read takes the next record as its mate -- same name,
@@ -544,21 +555,19 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 		}
 	}
 	const double tc1a = bam_now();
-	{
-		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
-		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (!erase_tags(b->rec[i])) bad[t] = 1; });
-		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed tags in a BAM record"); }
-	}
 	const double tc1b = bam_now();
 	{
 		const size_t nk = b->kind.size();
-		std::vector<std::pair<const uint8_t*, size_t>> view(nk);
-		bam_parallel(nk, [&](int, size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) view[k] = get_rg(b->rec[b->first[k]]); });
 		b->rg.resize(nk);
 		std::map<std::string, int> ids;
+		const uint8_t *prev_p = 0; uint32_t prev_n = 0;
 		for (size_t k = 0; k < nk; ++k) {
-			if (k && view[k].second == view[k - 1].second && !memcmp(view[k].first, view[k - 1].first, view[k].second)) { b->rg[k] = b->rg[k - 1]; continue; }
-			auto ins = ids.emplace(std::string((const char*)view[k].first, view[k].second), (int)b->rg_names.size());
+			const BamRec &r0 = b->rec[b->first[k]];
+			const uint8_t *vp = r0.rg_p; const uint32_t vn = r0.rg_n;
+			const bool same = k && vn == prev_n && !memcmp(vp, prev_p, vn);
+			prev_p = vp; prev_n = vn;
+			if (same) { b->rg[k] = b->rg[k - 1]; continue; }
+			auto ins = ids.emplace(std::string((const char*)vp, vn), (int)b->rg_names.size());
 			if (ins.second) b->rg_names.push_back(ins.first->first);
 			b->rg[k] = ins.first->second;
 		}
@@ -601,10 +610,21 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 				uint8_t *s = b->seq.data() + b->off[i], *r = b->rseq.data() + b->off[i];
 				/* base j of the read in its own orientation: a record that carries the reverse flag holds the reverse complement
 				 * (bwaseqio.c:288-291); seq = the (trimmed) read reversed, rseq = its complement (bwaseqio.c:294-297) */
-				for (int j = 0; j < len; ++j) {
-					const int k = len - 1 - j, jj = rev ? L - 1 - k : k;
+				if (!rev) {
+					/* s[j] = code of base len-1-j; a byte of the record holds bases 2m (high nibble) and 2m+1: both codes from one table look-up,
+					 * written back to front */
+					int k = 0;
+					for (; k + 1 < len; k += 2) {
+						const uint16_t two = nt16_pair[sq[k >> 1]];          /* low byte: base k, high byte: base k+1 */
+						const uint8_t v0 = (uint8_t)two, v1 = (uint8_t)(two >> 8);
+						s[len - 1 - k] = v0; s[len - 2 - k] = v1;
+						r[len - 1 - k] = v0 < 4 ? 3 - v0 : v0; r[len - 2 - k] = v1 < 4 ? 3 - v1 : v1;
+					}
+					if (k < len) { const uint8_t v = nt16_nt4[sq[k >> 1] >> 4]; s[len - 1 - k] = v; r[len - 1 - k] = v < 4 ? 3 - v : v; }
+				} else for (int j = 0; j < len; ++j) {
+					const int k = len - 1 - j, jj = L - 1 - k;
 					uint8_t v = nt16_nt4[sq[jj >> 1] >> ((~jj & 1) << 2) & 15];
-					if (rev && v < 4) v = 3 - v;
+					if (v < 4) v = 3 - v;
 					s[j] = v; r[j] = v < 4 ? 3 - v : v;
 				}
 			}

@@ -15,7 +15,11 @@
 extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];
 
 template <bool PROF, bool LDSM>
-__global__ __launch_bounds__(64, NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
+// The statistics instantiation (phase clocks, touch counts: never timed) gets the whole register file: at 128 registers it spilled some 70 of
+// them -- among them the registers that hold spilled SCALAR values lane by lane -- and round 3 saw that build fault on the GPU
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, a pointer read back wrong) while the same source passes in the CPU emulation and in the build
+// without statistics.  With two waves per SIMD nothing of it is spilled to memory.
+__global__ __launch_bounds__(64, PROF ? 2 : NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
 {
 	deep_wave_body<PROF, LDSM>(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
 }

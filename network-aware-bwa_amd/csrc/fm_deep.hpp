@@ -21,7 +21,8 @@
 #define DCL_GO 1u
 #define DCL_GE 2u
 
-#define DEEP_LDS_WORDS(ns_, rd_) (2u * (((ns_) + 1u) & ~1u) + DEEP_NEWP + 256u + ((rd_) + 3u) / 4u)
+#define DEEP_BC_WORDS 16u                       /* per index 8 words: bucket array (2), primary, seq_len, L2[1..3], one spare -- picked from SearchParams.ixtab */
+#define DEEP_LDS_WORDS(ns_, rd_) (2u * (((ns_) + 1u) & ~1u) + DEEP_NEWP + 256u + DEEP_BC_WORDS + ((rd_) + 3u) / 4u)
 
 struct DeepParams {
 	SearchParams S;                  // index, reads, width records, options, outputs (n_aln / max_ent / status / aln by work item or res_slot)

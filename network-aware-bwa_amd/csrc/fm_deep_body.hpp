@@ -36,10 +36,19 @@ struct DeepLane { uint32_t k, l; uint32_t i : 16, ldp : 16; uint32_t mm : 8, go 
 
 #ifdef NABWA_EMU
 #define DEEP_FN static
+DEEP_FN uint4 deep_ld_global16(const uint4 *p) { return *p; }
 #define DEEP_ATOMIC_ADD_U64(p, v) (*(p) += (v))
 #define DEEP_CLOCK() 0ull
 #else
 #define DEEP_FN __device__ __forceinline__
+/* a bucket array reached through a pointer that was rebuilt from two words of the LDS table is, to the compiler, a pointer to anywhere
+ * (flat loads: they wait on two counters and consult the LDS and scratch apertures first); it points to global memory and says so */
+typedef uint32_t deep_u32x4 __attribute__((ext_vector_type(4)));
+DEEP_FN uint4 deep_ld_global16(const uint4 *p)
+{
+	const deep_u32x4 v = *(const deep_u32x4 __attribute__((address_space(1)))*)(uintptr_t)p;
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
 #define DEEP_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 #define DEEP_CLOCK() ((unsigned long long)wall_clock64())      /* 100 MHz */
 #endif
@@ -65,9 +74,11 @@ DEEP_FN void deep_occ4_pair(const DevBwt &B, uint32_t kq, uint32_t lq, Occ4 &ck,
 	const uint32_t bl = lvalid ? lp / NABWA_INTV : 0u, rl = lp - bl * NABWA_INTV;
 	const uint32_t bkk = kvalid ? kp / NABWA_INTV : bl, rk = kp - bkk * NABWA_INTV;
 	const uint4 *const pl = B.bk + (size_t)bl * 4, *const pk = B.bk + (size_t)bkk * 4;
-	const uint4 a0 = pl[0], a1 = pl[1], a2 = pl[2], a3 = pl[3];
+	// (fetching both buckets whether or not they are the same one saves the branch and a dozen moves -- and was 15 % slower on the ancient-DNA
+	// workload: what the chain step pays for is memory requests, not instructions; measured in round 3, profiles/r03_deep_variants.txt)
+	const uint4 a0 = deep_ld_global16(pl), a1 = deep_ld_global16(pl + 1), a2 = deep_ld_global16(pl + 2), a3 = deep_ld_global16(pl + 3);
 	uint4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
-	if (bkk != bl) { b0 = pk[0]; b1 = pk[1]; b2 = pk[2]; b3 = pk[3]; }
+	if (bkk != bl) { b0 = deep_ld_global16(pk); b1 = deep_ld_global16(pk + 1); b2 = deep_ld_global16(pk + 2); b3 = deep_ld_global16(pk + 3); }
 	if (lvalid) cl = nabwa_count4(a0, a1, a2, a3, rl); else { cl.c[0] = cl.c[1] = cl.c[2] = cl.c[3] = 0; }
 	if (kvalid) ck = nabwa_count4(b0, b1, b2, b3, rk); else { ck.c[0] = ck.c[1] = ck.c[2] = ck.c[3] = 0; }
 }
@@ -81,6 +92,15 @@ DEEP_FN uint32_t deep_squeeze(uint64_t v)
 DEEP_FN int deep_ctz64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 // element c of a four-element array by selects: a dynamically indexed register array would live in scratch memory
 DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u ? a[0] : (c == 1u ? a[1] : (c == 2u ? a[2] : a[3])); }
+
+// the constants of the index an entry of strand a is searched on, from the wave's LDS table
+DEEP_FN void deep_index_of(const uint32_t *s_bc, uint32_t a, DevBwt &B)
+{
+	const uint32_t *const c = s_bc + (a ? 0u : 8u);
+	const uint4 lo = *(const uint4*)c, hi = *(const uint4*)(c + 4);
+	B.bk = (const uint4*)(uintptr_t)((uint64_t)lo.y << 32 | lo.x); B.primary = lo.z; B.seq_len = lo.w;
+	B.L2[0] = 0; B.L2[1] = hi.x; B.L2[2] = hi.y; B.L2[3] = hi.z;
+}
 
 // One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
 // PROF: the statistics (rounds, chains, phase clocks) cost scalar and vector registers, so the build without them is the one that runs
@@ -103,7 +123,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	const uint32_t ns2 = (P.NS + 1u) & ~1u;
 	uint32_t *const s_cnt = lds, *const s_top = lds + ns2, *const s_newp = lds + 2 * ns2;
 	uint32_t *const s_off = s_newp + DEEP_NEWP;                           // 4 x 64 words: per lane the offsets of its records and of its children in the three classes (commit)
-	uint8_t *const s_bb = (uint8_t*)(s_off + 256), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
+	// the constants of the two indexes, picked per lane by the strand of its entry: one 16-byte LDS read each instead of a chain of selects
+	// over scalar registers that have long been spilled
+	uint32_t *const s_bc = s_off + 256;
+	uint8_t *const s_bb = (uint8_t*)(s_bc + DEEP_BC_WORDS), *const s_sb = s_bb + 2 * S.WLB, *const s_sq = s_sb + 2 * S.SLB;
 	constexpr bool lds_mode = LDSM;
 	const uint32_t PL = P.rd_pl;
 	uint32_t *const own = P.own + (size_t)wave * 2 * P.own_cap, *const freep = own + P.own_cap;
@@ -113,7 +136,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
 	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
-	unsigned long long st_lanesteps = 0, st_onerow = 0, st_mixed = 0, st_expand = 0, st_allone = 0;      // (statistics) expanding lane-steps, those on one-row intervals, wave-steps with both kinds / only one-row
+	unsigned long long st_lanesteps = 0;
 	unsigned long long ph_pop = 0, ph_chain = 0, ph_tail = 0, ph_commit = 0, ph_hit = 0, st_tailit = 0;      // (statistics) time per phase of a round
 	const bool prof = PROF && P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
 	const unsigned long long clk_start = DEEP_CLOCK();
@@ -122,6 +145,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(int, ts); LANE(uint32_t, tpos);             // exact tails: where a parked tail stands, the text position of its one row
 	LANE(uint32_t, ntl); LANE(uint32_t, ntx);      // statistics: rank steps / text finishes of this lane's exact tails
 	LANES { L(ntl) = 0; L(ntx) = 0; }
+	LANES { if (ln < 16) {      // s_bc[8 q + ..] = what a search on index q needs, out of the table the host made (SearchParams.ixtab): bucket array, primary,
+		// seq_len, L2[1..3], a spare -- words 0, 1, 12 .. 17 of the index's block there.  Entries of strand a search index 1 - a (bwtgap.c:149)
+		const uint32_t w = (uint32_t)ln & 7u;
+		s_bc[ln] = S.ixtab[(uint32_t)(ln >> 3) * NABWA_IXTAB_STRIDE + (w < 2u ? w : w + 10u)];
+	} }
+	WAVE_SYNC();
 
 	LANE(uint32_t, tu);       // scratch for broadcasts
 	LANE(DeepLane, e);
@@ -249,36 +278,26 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// ---------------------------------------------------------------- the chains
 				while (WBALLOT(L(act)) != 0ull) {
 					if (PROF) { ++st_steps; st_lanesteps += (unsigned)__popcll((unsigned long long)WBALLOT(L(act))); }
-					if (PROF) {      // how many of the lanes that will expand stand on ONE row (what a text step would serve)
-						const uint64_t ex_ = WBALLOT(L(act) && L(e).i > 0), on_ = WBALLOT(L(act) && L(e).i > 0 && L(e).k == L(e).l);
-						st_expand += (unsigned)__popcll((unsigned long long)ex_); st_onerow += (unsigned)__popcll((unsigned long long)on_);
-						if (on_ && on_ != ex_) ++st_mixed; else if (on_) ++st_allone;
-					}
 					LANES { if (L(act)) {
 						DeepLane &E = L(e);
 						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
 						if (L(rel) > L(peak)) L(peak) = L(rel);
 						L(rel) -= 1;
 						const int m = max_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
-						bool go_on = m >= 0;
-						if (go_on && E.i > 0 && m < (int)(DEEP_BB(E.a, E.i - 1) & 127u)) go_on = false;      // bwtgap.c:156
-						if (!go_on) L(act) = false;
+						// the fates of a popped entry, decided side by side (bwtgap.c:141-164): pruned (m < 0, or below the bound of the prefix
+						// still to match, :156) / a hit (nothing left to match) / an exact tail (nothing may differ any more: bwt_match_exact_alt,
+						// bwt.c:237-252 -- parked here and walked after the loop together with the other chains' tails: a tail is a run of
+						// dependent loads, and inside this loop every other lane of the wave would wait for each of them) / an expansion
+						const uint32_t bprev = DEEP_BB(E.a, E.i > 0 ? E.i - 1 : 0) & 127u;
+						const bool go_on = m >= 0 && !(E.i > 0 && m < (int)bprev);
+						const bool hit = go_on && E.i == 0;
+						const bool tail = go_on && !hit && m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape);
+						if (hit) L(flag) = DF_HIT; else if (tail) L(flag) = DF_TAIL;
+						if (!go_on || hit || tail) L(act) = false;
 						else {
-							const bool q1 = E.a == 0;                                         // the index searched: bwts[1 - a] (bwtgap.c:149)
-							DevBwt B;
-							B.bk = q1 ? S.bwt[1].bk : S.bwt[0].bk; B.primary = q1 ? S.bwt[1].primary : S.bwt[0].primary;
-							B.seq_len = q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len;
-							B.L2[0] = 0; B.L2[1] = q1 ? S.bwt[1].L2[1] : S.bwt[0].L2[1]; B.L2[2] = q1 ? S.bwt[1].L2[2] : S.bwt[0].L2[2]; B.L2[3] = q1 ? S.bwt[1].L2[3] : S.bwt[0].L2[3];
-							bool hit = false;
-							if (E.i == 0) hit = true;
-							else if (m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape)) {
-								// nothing may differ any more: the chain ends in an exact tail (bwt_match_exact_alt, bwt.c:237-252).  It is
-								// parked here and walked after the loop together with the other chains' tails: a tail is a run of
-								// dependent loads, and inside this loop every other lane of the wave would wait for each of them
-								L(flag) = DF_TAIL; L(act) = false;
-							}
-							if (hit) { L(flag) = DF_HIT; L(act) = false; }
-							else if (L(act)) {
+							DevBwt B;                                                       // the index searched: bwts[1 - a] (bwtgap.c:149)
+							deep_index_of(s_bc, E.a, B);
+							{
 								// ---- expansion (bwtgap.c:201-260)
 								const int i = E.i - 1;
 								Occ4 ck, cl;
@@ -286,19 +305,20 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, true);
 								const uint32_t occ = E.l - E.k + 1u;
 								bool allow_diff = true, allow_M = true;
-								if (i > 0) {
-									const uint32_t B1 = DEEP_BB(E.a, i - 1), B0 = DEEP_BB(E.a, i);
+								{	// the bounds of the prefix still to match and of the seed (bwtgap.c:205-215), read with clamped positions and applied by
+									// predicates: no branch, nothing to merge afterwards
+									const bool in = i > 0;
+									const uint32_t B1 = DEEP_BB(E.a, in ? i - 1 : 0), B0 = DEEP_BB(E.a, i);
 									const int b1 = (int)(B1 & 127u), b0 = (int)(B0 & 127u);
-									if (b1 > m - 1) allow_diff = false;
-									else if (b1 == m - 1 && b0 == m - 1 && (B0 & 128u)) allow_M = false;
+									const bool no_d = in && b1 > m - 1, no_m = in && b1 == m - 1 && b0 == m - 1 && (B0 & 128u) != 0u;
 									const int ii = i - (len - S.seed_len);
-									if (seeded && ii > 0) {
-										const uint32_t S1 = DEEP_SB(E.a, ii - 1), S0 = DEEP_SB(E.a, ii);
-										const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
-										const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
-										if (s1 > m_seed - 1) allow_diff = false;
-										else if (s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u)) allow_M = false;
-									}
+									const bool sd = seeded && in && ii > 0;
+									const uint32_t S1 = DEEP_SB(E.a, sd ? ii - 1 : 0), S0 = DEEP_SB(E.a, sd ? ii : 0);
+									const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
+									const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
+									const bool no_ds = sd && s1 > m_seed - 1, no_ms = sd && s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u) != 0u;
+									allow_diff = !(no_d || no_ds);
+									allow_M = !((!no_d && no_m) || (!no_ds && no_ms));
 								}
 								// ---- the children (bwtgap.c:206-259).  Deletions, mismatches and the match over symbol x all have the interval
 								// of "x in front of the suffixes": four intervals serve every child of this expansion.  The chain does not
@@ -372,9 +392,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						bool fail = false, hit = false;
 						if (L(ts) == 0 || L(ts) == 4) {
 							DevBwt B;
-							B.bk = q1 ? S.bwt[1].bk : S.bwt[0].bk; B.primary = q1 ? S.bwt[1].primary : S.bwt[0].primary;
-							B.seq_len = q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len;
-							B.L2[0] = 0; B.L2[1] = q1 ? S.bwt[1].L2[1] : S.bwt[0].L2[1]; B.L2[2] = q1 ? S.bwt[1].L2[2] : S.bwt[0].L2[2]; B.L2[3] = q1 ? S.bwt[1].L2[3] : S.bwt[0].L2[3];
+							deep_index_of(s_bc, E.a, B);
 							const uint32_t c = DEEP_RD(E.a, E.i - 1);
 							if (c > 3u) fail = true;
 							else {
@@ -615,7 +633,6 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
 			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit); atomicAdd(P.stats + 22, st_lanesteps);
-			atomicAdd(P.stats + 23, st_expand); atomicAdd(P.stats + 24, st_onerow); atomicAdd(P.stats + 25, st_mixed); atomicAdd(P.stats + 26, st_allone);
 			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}

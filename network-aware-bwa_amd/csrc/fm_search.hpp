@@ -48,4 +48,32 @@ struct SearchParams {
 	uint8_t *rd_cls;                          // kernel W -> partition: per strand the restarts of its width pass, clipped to 4
 	const unsigned int *n_sync;               // work items from *n_sync on are class-0 reads: their waves run in lockstep (see fm_search_kernel, partition_kernel)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches
+	const uint32_t *ixtab;                    // NABWA_IXTAB_WORDS words (device): per index what a lane picks by the strand of its entry -- see below
 };
+
+/* The per-index constants a lane of kernel D selects by its entry's strand, as a table the kernel copies into LDS (fm_deep_body.hpp): as
+ * selects over the kernel's arguments they were a dozen scalar registers live across the chain loop -- spilled, and read back lane by lane
+ * (v_readlane) at every use.  (The same for kernel S -- all its index pointers through such a table -- took its spilled scalars from 126 to 73
+ * and made it 6 % SLOWER: an LDS round trip in front of every load.  Measured in round 3, not kept.)  Per index NABWA_IXTAB_STRIDE words: */
+#define NABWA_IXTAB_STRIDE 24
+#define NABWA_IXTAB_WORDS  48
+#define IX_BK 0                  /* pointers: two words each, low word first */
+#define IX_KMER 2
+#define IX_KMER_LO 4
+#define IX_TEXT 6
+#define IX_ISA 8
+#define IX_SA_FULL 10
+#define IX_PRIMARY 12
+#define IX_SEQ_LEN 13
+#define IX_L2 13                 /* IX_L2 + c for c = 1..3 */
+static inline void nabwa_ixtab_fill(uint32_t *tab, const DevBwt *bwt /* [2] */)
+{
+	for (int q = 0; q < 2; ++q) {
+		uint32_t *o = tab + NABWA_IXTAB_STRIDE * q;
+		const uint64_t p[6] = { (uint64_t)(uintptr_t)bwt[q].bk, (uint64_t)(uintptr_t)bwt[q].kmer, (uint64_t)(uintptr_t)bwt[q].kmer_lo,
+								(uint64_t)(uintptr_t)bwt[q].text, (uint64_t)(uintptr_t)bwt[q].isa, (uint64_t)(uintptr_t)bwt[q].sa_full };
+		for (int f = 0; f < 6; ++f) { o[2 * f] = (uint32_t)p[f]; o[2 * f + 1] = (uint32_t)(p[f] >> 32); }
+		o[IX_PRIMARY] = bwt[q].primary; o[IX_SEQ_LEN] = bwt[q].seq_len; o[IX_L2 + 1] = bwt[q].L2[1]; o[IX_L2 + 2] = bwt[q].L2[2]; o[IX_L2 + 3] = bwt[q].L2[3];
+		for (int f = 17; f < NABWA_IXTAB_STRIDE; ++f) o[f] = 0;
+	}
+}

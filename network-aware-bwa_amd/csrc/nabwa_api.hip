@@ -442,6 +442,7 @@ struct nabwa_batch {
 	unsigned long long *d_sum;
 	// kernel D (deep searches): page pool, per-wave page lists and staging, counters; allocated on demand, kept for the next run
 	uint4 *d_pages; uint32_t *d_page_prev, *d_deep_own; uint4 *d_deep_stage; unsigned long long *d_deep_ctr;
+	uint32_t *d_ixtab;
 	size_t deep_pages, deep_own_words, deep_stage_ent;
 	hipEvent_t evd0, evd1; float last_ms_deep; int deep_ran, deep_only;
 	int deep_cfg; uint32_t deep_K, deep_lds_rd, deep_rd_pl; size_t deep_n_pages; uint64_t deep_cap_pages; long deep_waves_max;
@@ -469,7 +470,7 @@ extern "C" void nabwa_batch_destroy(nabwa_batch_t *b)
 	(void)hipSetDevice(b->ix->device);
 	void *ptrs[] = { b->d_pack, b->d_cls, b->d_perm, b->d_ncls, b->d_key, b->d_wdata, b->d_nN, b->d_seq, b->d_rseq, b->d_md, b->d_mg, b->d_poff, b->d_len, b->d_scratch, b->d_naln, b->d_maxent, b->d_wide_idx,
 					 b->d_status, b->d_aln, b->d_counter, b->d_novf, b->d_ovf_ids, b->d_scratch2, b->d_naln2, b->d_maxent2,
-					 b->d_status2, b->d_aln2, b->d_sum, b->d_pages, b->d_page_prev, b->d_deep_own, b->d_deep_stage, b->d_deep_ctr };
+					 b->d_status2, b->d_aln2, b->d_sum, b->d_pages, b->d_page_prev, b->d_deep_own, b->d_deep_stage, b->d_deep_ctr, b->d_ixtab };
 	if (b->stream) (void)hipStreamSynchronize(b->stream);      /* the buffers go back to the pool, not to the driver: nothing may still use them */
 	for (void *p : ptrs) if (p) (void)pool_free(b->ix, p);
 	for (int t = 0; t < b->n_grown; ++t) (void)pool_free(b->ix, b->grown[t]);
@@ -625,6 +626,13 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	SearchParams &P = b->P;
 	memset(&P, 0, sizeof(P));
 	P.bwt[0] = ix->bwt[0]; P.bwt[1] = ix->bwt[1];
+	{	/* the per-index constants the search kernels pick per lane, as a table for their LDS (fm_search.hpp) */
+		uint32_t tab[NABWA_IXTAB_WORDS];
+		nabwa_ixtab_fill(tab, ix->bwt);
+		BCHK(pool_malloc(b->ix, (void**)&b->d_ixtab, sizeof tab));
+		BCHK(hipMemcpy(b->d_ixtab, tab, sizeof tab, hipMemcpyHostToDevice));
+		P.ixtab = b->d_ixtab;
+	}
 	P.seq = b->d_seq; P.rseq = b->d_rseq; P.poff = b->d_poff; P.rd_len = b->d_len; P.rd_maxdiff = b->d_md; P.rd_maxgapo = b->d_mg; P.rd_key = b->d_key; P.rd_pack = b->d_pack; P.pack_stride = b->pack_stride;
 	P.text_mode = env_int("NABWA_TEXT_KERNELS", 7);      /* bit 0: text mode in the width kernel, bit 1: in the search kernel, bit 2: key form in the search kernel */
 	if (ix->bwt[0].kmer_T != ix->bwt[1].kmer_T) P.bwt[0].kmer_T = P.bwt[1].kmer_T = 0;
@@ -913,7 +921,6 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
 				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f; active lanes per chain step %.1f\n",
 						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
-				fprintf(stderr, "[nabwa] kernel D chain steps: %llu lane-steps that reach the expansion test, %llu of them on one-row intervals; wave-steps with only such lanes %llu, with both kinds %llu\n", st[23], st[24], st[26], st[25]);
 			}
 			if (pass == 0 && dump_path) {
 				std::vector<uint32_t> rounds(dump_ids.size());

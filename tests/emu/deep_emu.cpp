@@ -137,6 +137,9 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	memset(&P, 0, sizeof(P));
 	SearchParams &S = P.S;
 	S.bwt[0] = X[0].B; S.bwt[1] = X[1].B;
+	uint32_t ixtab[NABWA_IXTAB_WORDS];
+	nabwa_ixtab_fill(ixtab, S.bwt);
+	S.ixtab = ixtab;
 	// reads, padded to 16-byte starts as pad_reads_kernel lays them out
 	std::vector<int64_t> poff(n + 1, 0);
 	for (int i = 0; i < n; ++i) poff[i + 1] = poff[i] + (off[i + 1] - off[i] + 15) / 16 * 16;
