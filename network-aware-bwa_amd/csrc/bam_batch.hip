@@ -696,11 +696,14 @@ extern "C" int nabwa_bam_batch_search(nabwa_bam_batch_t *b)
 	rc = nabwa_batch_run(sb);
 	if (rc == NABWA_OK) rc = nabwa_batch_sync(sb, 0);
 	if (rc == NABWA_OK) {
-		rc = nabwa_batch_fetch(sb, b->n_aln.data(), 0, 0, &n_rows, b->max_ent.data());
-		if (rc == NABWA_ECAP || rc == NABWA_OK) {
-			b->rows.resize(n_rows ? (size_t)n_rows : 1);
-			rc = n_rows ? nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data()) : NABWA_OK;
+		/* one fetch where the rows fit a guess (most reads bring one row), a second one where they do not */
+		b->rows.resize((size_t)n + (size_t)n / 4 + 1024);
+		rc = nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), (int64_t)b->rows.size(), &n_rows, b->max_ent.data());
+		if (rc == NABWA_ECAP && n_rows > (int64_t)b->rows.size()) {
+			b->rows.resize((size_t)n_rows);
+			rc = nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data());
 		}
+		if (rc == NABWA_OK) b->rows.resize(n_rows ? (size_t)n_rows : 1);
 	}
 	nabwa_batch_destroy(sb);
 	if (rc == NABWA_OK) b->searched = true;

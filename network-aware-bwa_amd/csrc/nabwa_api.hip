@@ -579,7 +579,11 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	nabwa_batch *b = new nabwa_batch();
 	memset(b, 0, sizeof(*b));
 	b->ix = ix; b->opt = *opt; b->n = n; b->deep_only = deep_only ? 1 : 0;
-	BCHK(hipStreamCreate(&b->stream));
+	/* a stream that does not synchronise with the legacy default stream: the finishing chains of another batch (bwt_sa batches, the
+	 * alignment kernels: default stream, synchronous copies) run from another thread while this batch's search kernels do; everything in
+	 * this file orders its own work on b->stream explicitly.  NABWA_STREAM_BLOCKING=1: the old kind, for comparison. */
+	if (env_int("NABWA_STREAM_BLOCKING", 0)) BCHK(hipStreamCreate(&b->stream));
+	else BCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
 	BCHK(hipEventCreate(&b->ev0));
 	BCHK(hipEventCreate(&b->ev1));
 	BCHK(hipEventCreate(&b->evw));
