@@ -13,9 +13,11 @@ def test_counter_summaries_hold_the_kernels_bench_quotes():
     spec.loader.exec_module(bench)
     for k in ("NABWA_KMER_T", "NABWA_TEXT_MODE", "NABWA_TRIP_BUDGET"):
         assert k not in os.environ
-    s = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-    assert {"S", "W", "D"} <= set(s)
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_adna.json")))
-    assert "D" in d
-    assert bench.pmc_traffic() and bench.pmc_traffic() > 1e11          # kernel S on the headline workload: ~172 GB per launch
-    assert bench.pmc_traffic(True) and bench.pmc_traffic(True) > 1e11  # kernel D on the ancient-DNA workload
+    s = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    assert {"S", "W", "D"} <= set(s) and s["units"] == 10_000_000
+    assert bench.pmc_traffic("headline", 10_000_000) > 1e11                 # kernel S on the headline workload: ~172 GB per launch
+    for kind, units in (("adna", 6_250_000), ("pe", 1_000_000), ("repeats", 10_000_000)):      # kernel D at the sizes of the driver's line
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % kind)))
+        assert "D" in d and d["units"] == units
+        assert bench.pmc_traffic(kind, units) > 1e11, kind
+        assert bench.pmc_traffic(kind, units + 1) is None                   # a pass taken at another launch size says nothing
