@@ -96,10 +96,27 @@ DEEP_FN uint32_t deep_sel4(const uint32_t (&a)[4], uint32_t c) { return c == 0u 
 // the constants of the index an entry of strand a is searched on, from the wave's LDS table
 DEEP_FN void deep_index_of(const uint32_t *s_bc, uint32_t a, DevBwt &B)
 {
-	const uint32_t *const c = s_bc + (a ? 0u : 8u);
+	const uint32_t *const c = s_bc + (a ? 0u : 12u);
 	const uint4 lo = *(const uint4*)c, hi = *(const uint4*)(c + 4);
 	B.bk = (const uint4*)(uintptr_t)((uint64_t)lo.y << 32 | lo.x); B.primary = lo.z; B.seq_len = lo.w;
 	B.L2[0] = 0; B.L2[1] = hi.x; B.L2[2] = hi.y; B.L2[3] = hi.z;
+}
+
+// the interval table (all levels back to back, DEEP_LVO) of the index an entry of strand a is searched on
+DEEP_FN const uint2 *deep_table_of(const uint32_t *s_bc, uint32_t a)
+{
+	const uint2 p = *(const uint2*)(s_bc + (a ? 8u : 20u));
+	return (const uint2*)(uintptr_t)((uint64_t)p.y << 32 | p.x);
+}
+DEEP_FN uint2 deep_ld_global8(const uint2 *p)
+{
+#ifdef NABWA_EMU
+	return *p;
+#else
+	typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+	const u32x2_ v = *(const u32x2_ __attribute__((address_space(1)))*)(uintptr_t)p;
+	return make_uint2(v.x, v.y);
+#endif
 }
 
 // One wave: takes reads from the work counter until it runs out.  lds: 2 * NS + DEEP_NEWP words of this wave.
@@ -137,6 +154,11 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
 	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
 	unsigned long long st_lanesteps = 0;
+	// (statistics build) per lane: expansions of entries in key form / their tail jumps and hits / records filed / children stored / entries pruned at the pop /
+	// expansions / rank queries on two buckets / expansions that may push no difference (allow_diff false): in key form, on one row, on several rows
+	LANE(uint32_t, pk_key); LANE(uint32_t, pk_ktl); LANE(uint32_t, pk_rec); LANE(uint32_t, pk_chl); LANE(uint32_t, pk_prn); LANE(uint32_t, pk_exp); LANE(uint32_t, pk_two);
+	LANE(uint32_t, pk_fk); LANE(uint32_t, pk_f1); LANE(uint32_t, pk_fw);
+	LANES { L(pk_key) = L(pk_ktl) = L(pk_rec) = L(pk_chl) = L(pk_prn) = L(pk_exp) = L(pk_two) = L(pk_fk) = L(pk_f1) = L(pk_fw) = 0u; }
 	unsigned long long ph_pop = 0, ph_chain = 0, ph_tail = 0, ph_commit = 0, ph_hit = 0, st_tailit = 0;      // (statistics) time per phase of a round
 	const bool prof = PROF && P.stats != 0;      // the longest single read of this wave: time, rounds; time in reads altogether
 	const unsigned long long clk_start = DEEP_CLOCK();
@@ -145,10 +167,11 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(int, ts); LANE(uint32_t, tpos);             // exact tails: where a parked tail stands, the text position of its one row
 	LANE(uint32_t, ntl); LANE(uint32_t, ntx);      // statistics: rank steps / text finishes of this lane's exact tails
 	LANES { L(ntl) = 0; L(ntx) = 0; }
-	LANES { if (ln < 16) {      // s_bc[8 q + ..] = what a search on index q needs, out of the table the host made (SearchParams.ixtab): bucket array, primary,
-		// seq_len, L2[1..3], a spare -- words 0, 1, 12 .. 17 of the index's block there.  Entries of strand a search index 1 - a (bwtgap.c:149)
-		const uint32_t w = (uint32_t)ln & 7u;
-		s_bc[ln] = S.ixtab[(uint32_t)(ln >> 3) * NABWA_IXTAB_STRIDE + (w < 2u ? w : w + 10u)];
+	LANES { if (ln < 24) {      // s_bc[12 q + ..] = what a search on index q needs, out of the table the host made (SearchParams.ixtab): bucket array, primary,
+		// seq_len, L2[1..3], a spare -- words 0, 1, 12 .. 17 of the index's block there --, the interval table (words 4, 5), two spares.
+		// Entries of strand a search index 1 - a (bwtgap.c:149)
+		const uint32_t q = (uint32_t)ln >= 12u ? 1u : 0u, w = (uint32_t)ln - 12u * q;
+		s_bc[ln] = S.ixtab[q * NABWA_IXTAB_STRIDE + (w < 2u ? w : (w < 8u ? w + 10u : (w < 10u ? IX_KMER_LO + w - 8u : 17u)))];
 	} }
 	WAVE_SYNC();
 
@@ -158,18 +181,24 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	LANE(int, flag);
 	LANE(uint32_t, cc0); LANE(uint32_t, cc1); LANE(uint32_t, cc2);   // children staged (through records), per (canonical) class
 	LANE(uint32_t, nrec);     // records this lane's chain has filed in this round
+	LANE(bool, norun);        // this lane's entry takes its forced levels step by step (its row is the empty suffix's)
 	LANE(int, rel);           // live entries relative to the count before this lane's first pop
 	LANE(int, peak);          // the largest value `rel` had right before a pop
 	LANE(uint32_t, d); LANE(uint32_t, off);
 	LANE(int, nst);
 	LANE(uint32_t, tch);      // bucket touches of the reference algorithm in this lane's chain (instrumented runs only)
 	const bool counting = PROF && S.touch_counter != 0;      // (the touch-counting run uses the statistics instantiation: one per-lane counter less to carry)
+	const uint32_t KT = counting ? 0u : P.key_T;             // key-form entries (fm_deep.hpp) while their strings are shorter than this; the counted touches are those of rows
 
 	// the read's own data: from LDS, or (reads too long for it) from where kernel W / the batch put them
 #define DEEP_BB(a_, p_) (lds_mode ? (uint32_t)s_bb[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)] : (uint32_t)(rec + S.woff_bid)[(uint32_t)(a_) * S.WLB + (uint32_t)(p_)])
 #define DEEP_SB(a_, p_) (lds_mode ? (uint32_t)s_sb[(uint32_t)(a_) * S.SLB + (uint32_t)(p_)] : (uint32_t)(rec + S.woff_sbid)[(uint32_t)(a_) * S.SLB + (uint32_t)(p_)])
 #define DEEP_RD(a_, p_) (lds_mode ? (uint32_t)s_sq[(uint32_t)(a_) * PL + (uint32_t)(p_)] : (uint32_t)((a_) ? S.rseq : S.seq)[sq_off + (size_t)(p_)])
 #define DEEP_RD16(a_, p_) (lds_mode ? *(const uint4*)(s_sq + (uint32_t)(a_) * PL + (uint32_t)(p_)) : *(const uint4*)(((a_) ? S.rseq : S.seq) + sq_off + (size_t)(p_)))
+
+	// an expansion at read position p_ that may push no difference (bwtgap.c:205-215: allow_diff = 0), for an entry with m_ differences left (ms_ in the seed)
+#define DEEP_FORCED(a_, p_, m_, ms_) ((p_) > 0 && ((int)(DEEP_BB(a_, (p_) - 1) & 127u) > (m_) - 1 || \
+		(seeded && (p_) - (len - S.seed_len) > 0 && (int)(DEEP_SB(a_, (p_) - (len - S.seed_len) - 1) & 127u) > (ms_) - 1)))
 
 	// n_new pages into s_newp[]: from this wave's free ones first, then from the pool; ok_ = false when the pool is dry
 #define DEEP_ALLOC(n_new_, ok_) do { \
@@ -232,8 +261,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 			else {
 				const uint32_t p0 = WUNI(s_newp[0]);
 				ONE_LANE {
-					P.pages[(size_t)p0 * DEEP_PAGE + 0] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 0, 0u);
-					P.pages[(size_t)p0 * DEEP_PAGE + 1] = deep_pack(0u, S.bwt[0].seq_len, len, 0, 0, 0, 0, DST_M, 1, 0u);
+					const uint32_t root_l = KT ? DEEP_KEYL : S.bwt[0].seq_len;      // the empty string: every row, or key form of length 0
+					P.pages[(size_t)p0 * DEEP_PAGE + 0] = deep_pack(0u, root_l, len, 0, 0, 0, 0, DST_M, 0, 0u);
+					P.pages[(size_t)p0 * DEEP_PAGE + 1] = deep_pack(0u, root_l, len, 0, 0, 0, 0, DST_M, 1, 0u);
 					P.page_prev[p0] = DEEP_NIL; s_cnt[0] = 2; s_top[0] = p0;
 				}
 				WAVE_SYNC();
@@ -265,7 +295,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				uint32_t prev_pg = DEEP_NIL;
 				if (((cs - W) >> DEEP_PAGE_SH) != topq) prev_pg = WUNI(P.page_prev[top_pg]);
 				LANES {
-					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(nrec) = 0; L(rel) = 0; L(peak) = 0;
+					L(act) = (uint32_t)ln < W; L(flag) = DF_NONE; L(tch) = 0; L(cc0) = L(cc1) = L(cc2) = 0; L(nrec) = 0; L(norun) = false; L(rel) = 0; L(peak) = 0;
 					if (L(act)) {
 						const uint32_t p = cs - 1u - (uint32_t)ln;
 						const uint32_t pg = (p >> DEEP_PAGE_SH) == topq ? top_pg : prev_pg;
@@ -275,7 +305,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				if (PROF) { ++st_rounds; st_run += W; if (careful) ++st_careful; }
 
 				unsigned long long pc1 = 0; if (prof) { LANES { L(tu) = L(e).k; } (void)WUNI(WBCAST(tu, 0)); pc1 = DEEP_CLOCK(); ph_pop += pc1 - pc0; }
-				// ---------------------------------------------------------------- the chains
+				// ---------------------------------------------------------------- the chains (and, when forced levels were walked on the text for
+				// some of them, the chains again: those lanes come back with their entries at the end of the walk)
+				unsigned long long pc2 = 0;
+				for (;;) {
 				while (WBALLOT(L(act)) != 0ull) {
 					if (PROF) { ++st_steps; st_lanesteps += (unsigned)__popcll((unsigned long long)WBALLOT(L(act))); }
 					LANES { if (L(act)) {
@@ -293,17 +326,21 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						const bool hit = go_on && E.i == 0;
 						const bool tail = go_on && !hit && m == 0 && (E.state == DST_M || gape_mode || E.ge == S.max_gape);
 						if (hit) L(flag) = DF_HIT; else if (tail) L(flag) = DF_TAIL;
+						if (PROF && !go_on) L(pk_prn) += 1u;
 						if (!go_on || hit || tail) L(act) = false;
 						else {
-							DevBwt B;                                                       // the index searched: bwts[1 - a] (bwtgap.c:149)
-							deep_index_of(s_bc, E.a, B);
 							{
 								// ---- expansion (bwtgap.c:201-260)
 								const int i = E.i - 1;
-								Occ4 ck, cl;
-								deep_occ4_pair(B, E.k - 1u, E.l, ck, cl);
-								if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, true);
-								const uint32_t occ = E.l - E.k + 1u;
+								const bool kf = E.l >= DEEP_KEYL;                                // key form: the four extensions come out of the table
+								const uint32_t kt = E.l & 0xffu;
+								uint32_t occ;
+								uint32_t nk0, nl0, nk1, nl1, nk2, nl2, nk3, nl3;
+								if (PROF) L(pk_exp) += 1u;
+#ifndef NABWA_EMU
+								if (PROF && P.stats && P.hist) { const uint32_t dd = (uint32_t)(len - i - 1) < 31u ? (uint32_t)(len - i - 1) : 31u; atomicAdd(P.stats + 32 + (kf ? 64u : (E.k == E.l ? 32u : 0u)) + dd, 1ull); }
+#endif
+								const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
 								bool allow_diff = true, allow_M = true;
 								{	// the bounds of the prefix still to match and of the seed (bwtgap.c:205-215), read with clamped positions and applied by
 									// predicates: no branch, nothing to merge afterwards
@@ -315,66 +352,124 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 									const bool sd = seeded && in && ii > 0;
 									const uint32_t S1 = DEEP_SB(E.a, sd ? ii - 1 : 0), S0 = DEEP_SB(E.a, sd ? ii : 0);
 									const int s1 = (int)(S1 & 127u), s0 = (int)(S0 & 127u);
-									const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
 									const bool no_ds = sd && s1 > m_seed - 1, no_ms = sd && s1 == m_seed - 1 && s0 == m_seed - 1 && (S0 & 128u) != 0u;
 									allow_diff = !(no_d || no_ds);
 									allow_M = !((!no_d && no_m) || (!no_ds && no_ms));
 								}
-								// ---- the children (bwtgap.c:206-259).  Deletions, mismatches and the match over symbol x all have the interval
-								// of "x in front of the suffixes": four intervals serve every child of this expansion.  The chain does not
-								// build the children: it files ONE 64-byte record -- the four intervals, the parent, which groups it pushes
-								// and where in their classes' sequences they go -- and the commit, where all 64 lanes work whatever the
-								// chains' lengths were, turns records into entries.  The counts are all the chain itself needs.
-								const uint32_t nk0 = B.L2[0] + ck.c[0] + 1u, nl0 = B.L2[0] + cl.c[0], nk1 = B.L2[1] + ck.c[1] + 1u, nl1 = B.L2[1] + cl.c[1];
-								const uint32_t nk2 = B.L2[2] + ck.c[2] + 1u, nl2 = B.L2[2] + cl.c[2], nk3 = B.L2[3] + ck.c[3] + 1u, nl3 = B.L2[3] + cl.c[3];
-								const uint32_t vm = (nk0 <= nl0 ? 1u : 0u) | (nk1 <= nl1 ? 2u : 0u) | (nk2 <= nl2 ? 4u : 0u) | (nk3 <= nl3 ? 8u : 0u);
-								const uint32_t nv = (uint32_t)__popc(vm);
-								int tmp = E.go + E.ge;
-								if (loggap) { const uint32_t v = (uint32_t)(E.ge + E.go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
-								uint32_t grp = 0, n_gap = 0, gcls = DCL_GO;      // DRG_* bits; children of the gap group; its class
-								if (allow_diff && i >= S.indel_end_skip + tmp && len - i >= S.indel_end_skip + tmp) {
-									if (E.state == DST_M) { if (E.go < MG) { grp = DRG_OPEN; n_gap = 1u + nv; } }                                 // the insertion, then the deletions
-									else if (E.state == DST_I) { if (E.ge < S.max_gape) { grp = DRG_EXT_I; n_gap = 1u; gcls = DCL_GE; } }
-									else if (E.ge < S.max_gape && (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
+								// FORCED LEVELS.  Where no difference may be pushed (allow_diff = 0) an expansion pushes the matching child and nothing else
+								// (bwtgap.c:252-258), and that child is the next pop: a stretch of such levels is an exact walk along the read, without a
+								// record and with the live-entry count where it was.  It dies where the string stops occurring, where a symbol is an N, or
+								// where the child is pruned at its pop (bwtgap.c:156) -- all without a trace -- and it ends in front of the first level that
+								// may push a difference, at the read's end (a hit), where nothing may differ any more (an exact tail), or where the table ends.
+								// An entry in key form takes the whole stretch with ONE load: the interval of its string plus the stretch's symbols.  An entry
+								// on ONE row takes it from the text (parked like an exact tail: DF_RUN, walked in the loop behind this one, then back here).
+								bool walked = false;
+								if (!allow_diff && kf) {
+									walked = true;
+									if (PROF) L(pk_fk) += 1u;
+									uint32_t key = E.k, t = kt; int p = i; bool die = false;
+									for (;;) {
+										const uint32_t c = DEEP_RD(E.a, p);
+										if (c > 3u) { die = true; break; }
+										key = key << 2 | c; ++t;
+										if (p == 0) break;
+										if (m < (int)(DEEP_BB(E.a, p - 1) & 127u)) { die = true; break; }
+										if (m == 0 || t >= KT || !DEEP_FORCED(E.a, p - 1, m, m_seed)) break;
+										--p;
+									}
+									if (!die) {
+										const uint2 r = deep_ld_global8(deep_table_of(s_bc, E.a) + ((size_t)DEEP_LVO(t) + key));
+										if (r.x > r.y) die = true;
+										else {
+											L(rel) += 1; E.i = p; E.ldp = 0; E.state = DST_M;
+											if (t < KT) { E.k = key; E.l = DEEP_KEYL | t; } else { E.k = r.x; E.l = r.y; }
+										}
+									}
+									if (die) L(act) = false;
+								} else if (!allow_diff && text_ok && E.k == E.l && !L(norun)) {
+									walked = true; L(flag) = DF_RUN; L(act) = false;
+									if (PROF) L(pk_f1) += 1u;
 								}
-								const uint32_t c = DEEP_RD(E.a, i);
-								uint32_t mmv = 0;                                   // symbols with a mismatch child
-								bool match = false;
-								if (allow_diff && allow_M) { mmv = c > 3u ? vm : vm & ~(1u << c); match = c <= 3u && (vm >> c & 1u); }
-								else if (c < 4u) match = (vm >> c & 1u) != 0u;
-								const uint32_t n_mm = (uint32_t)__popc(mmv);
-								L(rel) += (int)(n_gap + n_mm);
-								// a class that can never be popped (after the first hit the loop ends at the first pop above best_score + s_mm,
-								// bwtgap.c:144) is counted, not stored
-								const bool keep_gap = gcls == DCL_GO ? keep1 : keep2;
-								if (!keep_gap) { grp = 0; n_gap = 0; }
-								if (!keep0) mmv = 0;
-								const uint32_t n_mm_st = keep0 ? n_mm : 0u;
-								if (n_gap + n_mm_st) {
-									const uint32_t gcn = gcls == DCL_GO ? can1 : can2;
-									const uint32_t at_gap = gcn == 0u ? L(cc0) : (gcn == 1u ? L(cc1) : L(cc2));
-									if (gcn == 0u) L(cc0) += n_gap; else if (gcn == 1u) L(cc1) += n_gap; else L(cc2) += n_gap;
-									const uint32_t at_mm = L(cc0);
-									L(cc0) += n_mm_st;
-									uint4 *const rp = stage + ((size_t)ln * K + L(nrec)) * 4u;
-									rp[0] = make_uint4(nk0, nk1, nk2, nk3);
-									rp[1] = make_uint4(nl0, nl1, nl2, nl3);
-									rp[2] = make_uint4(E.k, E.l, (uint32_t)i | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
-													   (uint32_t)E.mm | (uint32_t)E.go << 8 | (uint32_t)E.ge << 16 | (uint32_t)E.a << 26 | (c & 7u) << 27);
-									rp[3] = make_uint4(at_gap, at_mm, 0u, 0u);
-									L(nrec) += 1u;
+								if (!walked) {
+									if (kf) {
+										if (PROF) L(pk_key) += 1u;
+										const uint2 *const tab = deep_table_of(s_bc, E.a);
+										const uint4 *const ch = (const uint4*)(tab + ((size_t)DEEP_LVO(kt + 1u) + (size_t)E.k * 4u));
+										const uint4 c01 = deep_ld_global16(ch), c23 = deep_ld_global16(ch + 1);
+										nk0 = c01.x; nl0 = c01.y; nk1 = c01.z; nl1 = c01.w; nk2 = c23.x; nl2 = c23.y; nk3 = c23.z; nl3 = c23.w;
+										occ = 0xffffffffu;
+										// the one place an expansion asks how many rows its entry has (bwtgap.c:232: the extension of a deletion, once the gaps alone use up max_diff)
+										if (E.state == DST_D && E.ge + E.go >= max_diff && kt) { const uint2 own = deep_ld_global8(tab + ((size_t)DEEP_LVO(kt) + E.k)); occ = own.y - own.x + 1u; }
+									} else {
+										DevBwt B;                                                       // the index searched: bwts[1 - a] (bwtgap.c:149)
+										deep_index_of(s_bc, E.a, B);
+										Occ4 ck, cl;
+										deep_occ4_pair(B, E.k - 1u, E.l, ck, cl);
+										if (counting) L(tch) += ref_touches(B, E.k - 1u, E.l, true);
+										if (PROF && (E.k - 1u - (E.k - 1u >= B.primary ? 1u : 0u)) / NABWA_INTV != (E.l - (E.l >= B.primary ? 1u : 0u)) / NABWA_INTV) L(pk_two) += 1u;
+										occ = E.l - E.k + 1u;
+										// ---- the children (bwtgap.c:206-259).  Deletions, mismatches and the match over symbol x all have the interval
+										// of "x in front of the suffixes": four intervals serve every child of this expansion.
+										nk0 = B.L2[0] + ck.c[0] + 1u; nl0 = B.L2[0] + cl.c[0]; nk1 = B.L2[1] + ck.c[1] + 1u; nl1 = B.L2[1] + cl.c[1];
+										nk2 = B.L2[2] + ck.c[2] + 1u; nl2 = B.L2[2] + cl.c[2]; nk3 = B.L2[3] + ck.c[3] + 1u; nl3 = B.L2[3] + cl.c[3];
+									}
+									if (PROF && !allow_diff) { if (kf) L(pk_fk) += 1u; else if (E.k == E.l) L(pk_f1) += 1u; else L(pk_fw) += 1u; }
+									// The chain does not build the children: it files ONE 64-byte record -- the four intervals, the parent, which groups it
+									// pushes and where in their classes' sequences they go -- and the commit, where all 64 lanes work whatever the
+									// chains' lengths were, turns records into entries.  The counts are all the chain itself needs.
+									const uint32_t vm = (nk0 <= nl0 ? 1u : 0u) | (nk1 <= nl1 ? 2u : 0u) | (nk2 <= nl2 ? 4u : 0u) | (nk3 <= nl3 ? 8u : 0u);
+									const uint32_t nv = (uint32_t)__popc(vm);
+									int tmp = E.go + E.ge;
+									if (loggap) { const uint32_t v = (uint32_t)(E.ge + E.go); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
+									uint32_t grp = 0, n_gap = 0, gcls = DCL_GO;      // DRG_* bits; children of the gap group; its class
+									if (allow_diff && i >= S.indel_end_skip + tmp && len - i >= S.indel_end_skip + tmp) {
+										if (E.state == DST_M) { if (E.go < MG) { grp = DRG_OPEN; n_gap = 1u + nv; } }                                 // the insertion, then the deletions
+										else if (E.state == DST_I) { if (E.ge < S.max_gape) { grp = DRG_EXT_I; n_gap = 1u; gcls = DCL_GE; } }
+										else if (E.ge < S.max_gape && (E.ge + E.go < max_diff || occ < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
+									}
+									const uint32_t c = DEEP_RD(E.a, i);
+									uint32_t mmv = 0;                                   // symbols with a mismatch child
+									bool match = false;
+									if (allow_diff && allow_M) { mmv = c > 3u ? vm : vm & ~(1u << c); match = c <= 3u && (vm >> c & 1u); }
+									else if (c < 4u) match = (vm >> c & 1u) != 0u;
+									const uint32_t n_mm = (uint32_t)__popc(mmv);
+									L(rel) += (int)(n_gap + n_mm);
+									// a class that can never be popped (after the first hit the loop ends at the first pop above best_score + s_mm,
+									// bwtgap.c:144) is counted, not stored
+									const bool keep_gap = gcls == DCL_GO ? keep1 : keep2;
+									if (!keep_gap) { grp = 0; n_gap = 0; }
+									if (!keep0) mmv = 0;
+									const uint32_t n_mm_st = keep0 ? n_mm : 0u;
+									if (n_gap + n_mm_st) {
+										const uint32_t gcn = gcls == DCL_GO ? can1 : can2;
+										const uint32_t at_gap = gcn == 0u ? L(cc0) : (gcn == 1u ? L(cc1) : L(cc2));
+										if (gcn == 0u) L(cc0) += n_gap; else if (gcn == 1u) L(cc1) += n_gap; else L(cc2) += n_gap;
+										const uint32_t at_mm = L(cc0);
+										L(cc0) += n_mm_st;
+										uint4 *const rp = stage + ((size_t)ln * K + L(nrec)) * 4u;
+										rp[0] = make_uint4(nk0, nk1, nk2, nk3);
+										rp[1] = make_uint4(nl0, nl1, nl2, nl3);
+										rp[2] = make_uint4(E.k, E.l, (uint32_t)i | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
+														   (uint32_t)E.mm | (uint32_t)E.go << 8 | (uint32_t)E.ge << 16 | (uint32_t)E.a << 26 | (c & 7u) << 27);
+										rp[3] = make_uint4(at_gap, at_mm, 0u, 0u);
+										L(nrec) += 1u;
+										if (PROF) { L(pk_rec) += 1u; L(pk_chl) += n_gap + n_mm_st; }
+									}
+									const uint32_t mk_ = c == 0u ? nk0 : (c == 1u ? nk1 : (c == 2u ? nk2 : nk3)), ml_ = c == 0u ? nl0 : (c == 1u ? nl1 : (c == 2u ? nl2 : nl3));
+									// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
+									if (match) {
+										L(rel) += 1; E.i = i; E.ldp = 0; E.state = DST_M;
+										if (kf && kt + 1u < KT) { E.k = E.k << 2 | c; E.l = DEEP_KEYL | (kt + 1u); } else { E.k = mk_; E.l = ml_; }
+									}
+									else L(act) = false;
 								}
-								const uint32_t mk_ = c == 0u ? nk0 : (c == 1u ? nk1 : (c == 2u ? nk2 : nk3)), ml_ = c == 0u ? nl0 : (c == 1u ? nl1 : (c == 2u ? nl2 : nl3));
-								// the matching child: same score, pushed last -> it is the reference's next pop: the chain goes on with it
-								if (match) { L(rel) += 1; E.k = mk_; E.l = ml_; E.i = i; E.ldp = 0; E.state = DST_M; }
-								else L(act) = false;
 								if (L(act) && (careful || L(nrec) >= K)) { L(flag) = DF_CONT; L(act) = false; }      // no room for another record: the chain goes on in the next round
 							}
 						}
 					} }
 					// a chain that ended in a hit or ran out of staging room: the lanes above it will be dropped
 					const uint64_t sm = WBALLOT(L(flag) == DF_HIT || L(flag) == DF_CONT);
-					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) { L(act) = false; if (L(flag) == DF_TAIL) L(flag) = DF_NONE; } } }
+					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) { L(act) = false; if (L(flag) == DF_TAIL || L(flag) == DF_RUN) L(flag) = DF_NONE; } } }
 				}
 
 				// ---------------------------------------------------------------- the parked exact tails, all together: every turn
@@ -382,8 +477,13 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// has several rows; once ONE row is left (text mode, nabwa_dev.hpp) its suffix's text position, then the comparison
 				// of the i symbols still to match with the text right in front of it (str[j] against text[pos - i + j], 16 per
 				// word pair, both packed low bits first), then the row of the extended suffix from the inverse suffix array
-				unsigned long long pc2 = 0; if (prof) { pc2 = DEEP_CLOCK(); ph_chain += pc2 - pc1; }
-				LANES { L(ts) = L(flag) == DF_TAIL ? ((text_ok && L(e).k == L(e).l) ? 1 : 0) : -1; }
+				if (prof) { pc2 = DEEP_CLOCK(); ph_chain += pc2 - pc1; }
+				// (an entry in key form first takes its rows from the table: a tail jumps as far down as the table goes -- min(T - t, i) symbols
+				// for one load --, a hit takes the rows of its own string)
+				LANES {
+					const bool kf = L(e).l >= DEEP_KEYL;
+					L(ts) = L(flag) == DF_TAIL ? (kf ? 5 : ((text_ok && L(e).k == L(e).l) ? 1 : 0)) : (L(flag) == DF_HIT && kf ? 6 : (L(flag) == DF_RUN ? 7 : -1));
+				}
 				while (WBALLOT(L(ts) >= 0) != 0ull) {
 					if (PROF) ++st_tailit;
 					LANES { if (L(ts) >= 0) {
@@ -428,13 +528,65 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							}
 							if (PROF) L(ntx) += 1;
 							if (ok) L(ts) = 3; else fail = true;
-						} else {
+						} else if (L(ts) == 3) {
 							E.k = E.l = (q1 ? S.bwt[1].isa : S.bwt[0].isa)[L(tpos) - (uint32_t)E.i];
 							hit = true;
+						} else if (L(ts) == 7) {
+							// ---- forced levels of an entry on ONE row (DF_RUN): the text position of its suffix, ...
+							const uint32_t pos = (q1 ? S.bwt[1].sa_full : S.bwt[0].sa_full)[E.k];
+							if (pos == 0xffffffffu) { L(rel) += 1; L(act) = true; L(norun) = true; L(flag) = DF_NONE; L(ts) = -1; }      // (the empty suffix: this entry takes its levels by rank queries; its pop is undone)
+							else { L(tpos) = pos; L(ts) = 8; }
+						} else if (L(ts) == 8) {
+							// ... the levels, up to 32 per turn: level after level what the chain step would do with an expansion that pushes its matching
+							// child alone and with that child's pop -- the symbol in front of the suffix is the text's, ...
+							const uint32_t *const txt = q1 ? S.bwt[1].text : S.bwt[0].text;
+							const int m = max_diff - E.mm - E.go - (gape_mode ? E.ge : 0), m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
+							const uint32_t tp = L(tpos), lo = tp >= 32u ? tp - 32u : 0u, w0 = lo >> 4, sh = (lo & 15u) << 1;
+							const uint32_t t0 = txt[w0], t1 = txt[w0 + 1u], t2 = txt[w0 + 2u];
+							const uint64_t a64 = (uint64_t)t1 << 32 | t0;
+							const uint64_t win = sh ? (a64 >> sh | (uint64_t)t2 << (64u - sh)) : a64;      // text[lo + x] = (win >> 2 x) & 3, x < 32
+							const uint32_t avail = tp - lo;
+							int p = (int)E.i - 1; uint32_t d = 0; bool stop = false;
+							for (;;) {
+								if (d >= avail) { if (lo == 0u) fail = true; break; }      // the window is used up (or the text begins here: nothing in front of it)
+								const uint32_t c = DEEP_RD(E.a, p), x = (uint32_t)(win >> ((tp - 1u - d - lo) << 1)) & 3u;
+								if (c != x) { fail = true; break; }                       // (an N is 4: never equal)
+								++d;
+								if (p == 0) { stop = true; break; }
+								if (m < (int)(DEEP_BB(E.a, p - 1) & 127u)) { fail = true; break; }
+								if (m == 0 || !DEEP_FORCED(E.a, p - 1, m, m_seed)) { stop = true; break; }
+								--p;
+							}
+							if (!fail) { L(tpos) = tp - d; E.i = E.i - d; if (stop) L(ts) = 9; }
+						} else if (L(ts) == 9) {
+							// ... and the row of the suffix the walk ended on: the chain goes on with it
+							E.k = E.l = (q1 ? S.bwt[1].isa : S.bwt[0].isa)[L(tpos)];
+							E.ldp = 0; E.state = DST_M;
+							L(rel) += 1; L(ts) = -1;
+							if (careful) L(flag) = DF_CONT; else { L(flag) = DF_NONE; L(act) = true; }
+						} else {
+							const uint2 *const tab = deep_table_of(s_bc, E.a);
+							const uint32_t kt = E.l & 0xffu;
+							uint32_t key = E.k, j = 0;
+							if (PROF) L(pk_ktl) += 1u;
+							if (L(ts) == 5) {
+								j = KT - kt < (uint32_t)E.i ? KT - kt : (uint32_t)E.i;
+								for (uint32_t u = 0; u < j; ++u) { const uint32_t c = DEEP_RD(E.a, E.i - 1 - (int)u); if (c > 3u) fail = true; key = key << 2 | (c & 3u); }
+							}
+							if (!fail) {
+								const uint2 r = kt + j ? deep_ld_global8(tab + ((size_t)DEEP_LVO(kt + j) + key)) : make_uint2(0u, q1 ? S.bwt[1].seq_len : S.bwt[0].seq_len);
+								E.k = r.x; E.l = r.y; E.i -= j;
+								if (r.x > r.y) fail = true;
+								else if (E.i == 0) hit = true;
+								else L(ts) = (text_ok && r.x == r.y) ? 1 : 0;
+							}
 						}
 						if (fail) { L(flag) = DF_NONE; L(ts) = -1; }
 						else if (hit) { L(flag) = DF_HIT; L(ts) = -1; }
 					} }
+				}
+				if (WBALLOT(L(act)) == 0ull) break;
+				if (prof) { pc1 = DEEP_CLOCK(); ph_tail += pc1 - pc2; }
 				}
 
 				unsigned long long pc3 = 0; if (prof) { pc3 = DEEP_CLOCK(); ph_tail += pc3 - pc2; }
@@ -514,7 +666,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						const uint32_t ri = r2.z & 0xffffu, vm = r2.z >> 16 & 15u, grp = r2.z >> 20 & 15u, mmv = r2.z >> 24 & 15u, gcn = r2.z >> 28 & 3u;
 						const int pmm = (int)(r2.w & 0xffu), pgo = (int)(r2.w >> 8 & 0xffu), pge = (int)(r2.w >> 16 & 0xffu), pa = (int)(r2.w >> 26 & 1u);
 						const uint32_t c = r2.w >> 27 & 7u;
-						if (grp) {                                     // the gap group: [the insertion,] [the deletions over the symbols that occur]
+						// the children of a parent in key form stay in it while the table has a level below theirs (a deletion or a mismatch over x: the
+						// parent's string and x); the insertion child has its parent's string
+						const uint32_t kt1 = (r2.y & 0xffu) + 1u;
+						const bool kfc = r2.y >= DEEP_KEYL && kt1 < KT;
+						const uint32_t ckey = r2.x << 2, clen = DEEP_KEYL | kt1;
+						if (grp) {                                    // the gap group: [the insertion,] [the deletions over the symbols that occur]
 							const uint32_t gT = gcn == 0u ? cT0 : (gcn == 1u ? cT1 : cT2), gO = gcn == 0u ? ot0 : (gcn == 1u ? ot1 : ot2);
 							const uint32_t gQ = gcn == 0u ? qn0 : (gcn == 1u ? qn1 : qn2), gN = gcn == 0u ? 0u : (gcn == 1u ? nb1 : nb2);
 							uint32_t at = s_off[64u + 64u * gcn + j] + r3.x;
@@ -523,7 +680,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							if (grp != DRG_EXT_I) {
 #pragma unroll
 								for (int x = 0; x < 4; ++x)
-									if (vm >> x & 1u) { DEEP_PUT(gT, gO, gQ, gN, at, deep_pack(nkv[x], nlv[x], (int)ri + 1, (int)ri + 1, pmm, cgo, cge, DST_D, pa, 0u)); ++at; }
+									if (vm >> x & 1u) { DEEP_PUT(gT, gO, gQ, gN, at, deep_pack(kfc ? ckey | (uint32_t)x : nkv[x], kfc ? clen : nlv[x], (int)ri + 1, (int)ri + 1, pmm, cgo, cge, DST_D, pa, 0u)); ++at; }
 							}
 						}
 						if (mmv) {                                     // the mismatches, in the reference's order: (c + 1) & 3, (c + 2) & 3, ...
@@ -531,7 +688,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #pragma unroll
 							for (uint32_t t = 1; t <= 4u; ++t) {
 								const uint32_t x = (c + t) & 3u;
-								if (mmv >> x & 1u) { DEEP_PUT(cT0, ot0, qn0, 0u, at, deep_pack(deep_sel4(nkv, x), deep_sel4(nlv, x), (int)ri, (int)ri, pmm + 1, pgo, pge, DST_M, pa, 0u)); ++at; }
+								if (mmv >> x & 1u) { DEEP_PUT(cT0, ot0, qn0, 0u, at, deep_pack(kfc ? ckey | x : deep_sel4(nkv, x), kfc ? clen : deep_sel4(nlv, x), (int)ri, (int)ri, pmm + 1, pgo, pge, DST_M, pa, 0u)); ++at; }
 							}
 						}
 					} }
@@ -625,14 +782,28 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 		uint32_t t6 = 0, t7 = 0;
 		LANES { L(d) = L(ntl); } WEXSCAN_U32(L(off), L(d), t6);
 		LANES { L(d) = L(ntx); } WEXSCAN_U32(L(off), L(d), t7);
+		uint32_t s_key = 0, s_ktl = 0, s_rec = 0, s_chl = 0, s_prn = 0, s_exp = 0, s_two = 0, s_fk = 0, s_f1 = 0, s_fw = 0;
+		LANES { L(d) = L(pk_key); } WEXSCAN_U32(L(off), L(d), s_key);
+		LANES { L(d) = L(pk_ktl); } WEXSCAN_U32(L(off), L(d), s_ktl);
+		LANES { L(d) = L(pk_rec); } WEXSCAN_U32(L(off), L(d), s_rec);
+		LANES { L(d) = L(pk_chl); } WEXSCAN_U32(L(off), L(d), s_chl);
+		LANES { L(d) = L(pk_prn); } WEXSCAN_U32(L(off), L(d), s_prn);
+		LANES { L(d) = L(pk_exp); } WEXSCAN_U32(L(off), L(d), s_exp);
+		LANES { L(d) = L(pk_two); } WEXSCAN_U32(L(off), L(d), s_two);
+		LANES { L(d) = L(pk_fk); } WEXSCAN_U32(L(off), L(d), s_fk);
+		LANES { L(d) = L(pk_f1); } WEXSCAN_U32(L(off), L(d), s_f1);
+		LANES { L(d) = L(pk_fw); } WEXSCAN_U32(L(off), L(d), s_fw);
 		ONE_LANE {
 #ifdef NABWA_EMU
+			P.stats[10] += s_key; P.stats[11] += s_ktl; P.stats[12] += s_fk; P.stats[13] += s_f1;
 			P.stats[0] += st_rounds; P.stats[1] += st_run; P.stats[2] += st_commit; P.stats[3] += st_steps; P.stats[4] += st_careful; P.stats[5] += st_pool; P.stats[6] += t6; P.stats[7] += t7;
 #else
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);
 			atomicAdd(P.stats + 3, st_steps); atomicAdd(P.stats + 4, st_careful); atomicAdd(P.stats + 5, st_pool);
 			atomicAdd(P.stats + 6, (unsigned long long)t6); atomicAdd(P.stats + 7, (unsigned long long)t7);
-			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit); atomicAdd(P.stats + 22, st_lanesteps);
+			atomicAdd(P.stats + 16, ph_pop); atomicAdd(P.stats + 17, ph_chain); atomicAdd(P.stats + 18, ph_tail); atomicAdd(P.stats + 19, ph_commit); atomicAdd(P.stats + 20, ph_hit); atomicAdd(P.stats + 21, st_tailit); atomicAdd(P.stats + 22, st_lanesteps); atomicAdd(P.stats + 23, (unsigned long long)s_key); atomicAdd(P.stats + 24, (unsigned long long)s_ktl);
+			atomicAdd(P.stats + 25, (unsigned long long)s_rec); atomicAdd(P.stats + 26, (unsigned long long)s_chl); atomicAdd(P.stats + 27, (unsigned long long)s_prn); atomicAdd(P.stats + 28, (unsigned long long)s_exp); atomicAdd(P.stats + 29, (unsigned long long)s_two);
+			atomicAdd(P.stats + 30, (unsigned long long)s_fk); atomicAdd(P.stats + 31, (unsigned long long)s_f1); atomicAdd(P.stats + 9, (unsigned long long)s_fw);
 			atomicMax(P.stats + 10, st_maxclk); atomicMax(P.stats + 11, st_maxrounds); atomicAdd(P.stats + 12, st_sumclk); atomicMax(P.stats + 13, DEEP_CLOCK() - clk_start);
 #endif
 		}

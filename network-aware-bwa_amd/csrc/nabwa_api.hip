@@ -865,7 +865,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			b->d_deep_stage = 0; b->deep_stage_ent = 0;
 			HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_stage, stage_ent * 16)); b->deep_stage_ent = stage_ent;
 		}
-		if (!b->d_deep_ctr) HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_ctr, 256));
+		if (!b->d_deep_ctr) HIPCHK(pool_malloc(b->ix, (void**)&b->d_deep_ctr, 1024));
 		DeepParams D;
 		memset(&D, 0, sizeof(D));
 		D.S = b->P;
@@ -875,10 +875,19 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		D.page_bump = (unsigned int*)(b->d_deep_ctr + 8);
 		D.own = b->d_deep_own; D.stage = b->d_deep_stage; D.stage_k = K; D.NS = NS; D.lds_rd = lds_rd; D.rd_pl = rd_pl;
 		D.careful_all = env_int("NABWA_DEEP_CAREFUL", 0); D.max_lanes = env_int("NABWA_DEEP_LANES", 64);
+		/* key-form entries (fm_deep.hpp): both indexes carry interval tables of one depth, and no row number reaches the form's marker;
+		 * NABWA_DEEP_KEYFORM=0 keeps every entry as rows (A/B runs, and what the touch-counting run does anyway) */
+		{
+			const DevBwt &B0 = b->P.bwt[0], &B1 = b->P.bwt[1];
+			const bool ok = B0.kmer_T > 0 && B0.kmer_T == B1.kmer_T && B0.kmer_LW == B0.kmer_T && B1.kmer_LW == B1.kmer_T && B0.kmer_lo && B1.kmer_lo &&
+							B0.seq_len < DEEP_KEYL - 1u && B1.seq_len < DEEP_KEYL - 1u && (b->P.text_mode & 4) && env_int("NABWA_DEEP_KEYFORM", 1);
+			D.key_T = ok ? B0.kmer_T : 0u;
+		}
 		if (D.max_lanes < 1) D.max_lanes = 1;
 		if (D.max_lanes > 64) D.max_lanes = 64;
 
 		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
+		D.hist = getenv("NABWA_DEEP_HIST") ? 1 : 0;
 		/* NABWA_DEEP_DUMP=<file> (investigations of the work order): per search of the first launch its read, length, max_diff, the width
 		 * passes' restart classes, what kernel S saw of it (trips, hits) and the rounds kernel D needed -- int32 x 8 per search */
 		const char *dump_path = getenv("NABWA_DEEP_DUMP");
@@ -908,7 +917,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			D.S.n = (int)todo; D.own_cap = (uint32_t)own_cap;
 			rebuild_widths(D.S, todo);
 			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 256, b->stream));
+			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 1024, b->stream));
 			D.S.work_counter = b->d_counter;
 			if (pass == 0) HIPCHK(hipEventRecord(b->evd0, b->stream));
 			nabwa_launch_fm_deep(&D, (int)waves, b->stream);
@@ -919,12 +928,19 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			int r = recollect(NABWA_ST_POOL, &n_pool);
 			if (r != NABWA_OK) return r;
 			if (timing) {
-				unsigned long long st[32];
-				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 256, hipMemcpyDeviceToHost));
+				unsigned long long st[128];
+				HIPCHK(hipMemcpy(st, b->d_deep_ctr, 1024, hipMemcpyDeviceToHost));
 				fprintf(stderr, "[nabwa] kernel D%s: %u reads on %ld waves (%zu pages of 4 KB, %u handed out), %u left for the guaranteed pass, %.3f s; rounds %llu, chains run %llu / committed %llu, wave-steps %llu, careful rounds %llu, exact tails: %llu rank steps, %llu finished by text; longest read %.3f s / %llu rounds, all reads %.1f wave-s, longest wave %.3f s\n",
 						pass ? " (guaranteed pass)" : "", todo, waves, n_pages, (unsigned int)(st[8] & 0xffffffffu), n_pool, now() - tt0, st[0], st[1], st[2], st[3], st[4], st[6], st[7], st[10] * 1e-8, st[11], st[12] * 1e-8, st[13] * 1e-8);
 				fprintf(stderr, "[nabwa] kernel D phases (wave-s): pop %.1f, chains %.1f, exact tails %.1f (%llu turns), commit %.1f, hit bookkeeping %.1f; active lanes per chain step %.1f\n",
 						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
+				fprintf(stderr, "[nabwa] kernel D lane-steps %llu: pruned at the pop %llu, expansions %llu (in key form %llu, on two buckets %llu), records %llu, children stored %llu; key-form tails / hits %llu; expansions without a difference allowed: %llu in key form, %llu on one row, %llu on several\n",
+						st[22], st[27], st[28], st[23], st[29], st[25], st[26], st[24], st[30], st[31], st[9]);
+				if (getenv("NABWA_DEEP_HIST")) for (int h = 0; h < 3; ++h) {
+					fprintf(stderr, "[nabwa] kernel D expansions by depth (read symbols consumed), %s:", h == 0 ? "rows, several" : (h == 1 ? "rows, one" : "key form"));
+					for (int d = 0; d < 32; ++d) fprintf(stderr, " %llu", st[32 + 32 * h + d]);
+					fprintf(stderr, "\n");
+				}
 			}
 			if (pass == 0 && dump_path) {
 				std::vector<uint32_t> rounds(dump_ids.size());
@@ -988,7 +1004,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			G.S.n = (int)n_hit; G.own_cap = (uint32_t)cap_pages;
 			rebuild_widths(G.S, n_hit);
 			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
-			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 256, b->stream));
+			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 1024, b->stream));
 			G.S.work_counter = b->d_counter;
 			nabwa_launch_fm_deep(&G, (int)waves, b->stream);
 			nabwa_launch_scatter_grown((int)n_hit, b->d_ovf_ids, n3, m3, s3, b->d_naln, b->d_maxent, b->d_status, b->d_wide_idx, (const uint4*)base, cap3, b->d_grown_tab, b->grown_used, b->stream);

@@ -20,7 +20,7 @@ uint32_t ref_base(const uint32_t *w, uint32_t j)          // base j of the refer
 	return p[(j & 127u) >> 4] >> ((~j & 15u) << 1) & 3u;
 }
 
-struct EmuBwt { std::vector<uint4> bk; std::vector<uint32_t> sa, sa_full, isa, text; DevBwt B; };
+struct EmuBwt { std::vector<uint4> bk; std::vector<uint32_t> sa, sa_full, isa, text; std::vector<uint2> kmer; DevBwt B; };
 
 void build(EmuBwt &X, const uint32_t *words)
 {
@@ -45,6 +45,32 @@ void build(EmuBwt &X, const uint32_t *words)
 		for (int g = 0; g < 3; ++g) o[1 + g] = make_uint4((uint32_t)lo[g], (uint32_t)(lo[g] >> 32), (uint32_t)hi[g], (uint32_t)(hi[g] >> 32));
 	}
 	X.B.bk = X.bk.data(); X.B.n_buckets = nb;
+}
+
+// the interval table of an index, levels 1 .. T back to back, as kmer_level_kernel (fm_index.hip) builds it: the children of every string
+// of t - 1 symbols by one backward step, {1, 0} for a string that does not occur
+void build_table(EmuBwt &X, int T)
+{
+	DevBwt &B = X.B;
+	size_t n = 0;
+	for (int t = 1; t <= T; ++t) n += (size_t)1 << (2 * t);
+	X.kmer.assign(n, make_uint2(1u, 0u));
+	size_t prev = 0, cur = 0;
+	for (int t = 1; t <= T; ++t) {
+		const size_t n_par = (size_t)1 << (2 * (t - 1));
+		for (size_t idx = 0; idx < n_par; ++idx) {
+			const uint2 par = t == 1 ? make_uint2(0u, B.seq_len) : X.kmer[prev + idx];
+			if (par.x > par.y) continue;
+			Occ4 ck, cl;
+			nabwa_occ4_pair(B, par.x - 1u, par.y, ck, cl);
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t k = B.L2[c] + ck.c[c] + 1u, l = B.L2[c] + cl.c[c];
+				if (k <= l) X.kmer[cur + 4 * idx + c] = make_uint2(k, l);
+			}
+		}
+		prev = cur; cur += (size_t)1 << (2 * t);
+	}
+	B.kmer_lo = X.kmer.data(); B.kmer = X.kmer.data() + prev; B.kmer_T = B.kmer_LW = (uint32_t)T;
 }
 
 // the text-mode companions of an index -- SA value of every row, its inverse, the text 2 bits per base -- from the BWT and the
@@ -121,8 +147,10 @@ uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, max_entries; float fnr; int max_diff, max_gapo, max_gape, max_seed_diff, seed_len, n_threads, max_top2, trim_qual; };
 
 // knobs: [8] 1 = the read's own data in (emulated) LDS;  [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap,
-// [7] text mode (needs sa0 / sa1: the .sa / .rsa file contents; touches are then not the reference's)
-// stats: 10 words -- 8 as in DeepParams, [8] the reference's bucket touches in the width passes, [9] in bwt_match_gap.  Returns 0.
+// [7] text mode (needs sa0 / sa1: the .sa / .rsa file contents; touches are then not the reference's), [9] depth of the interval tables for key-form entries (0: none; the
+// touch counter is then off, as in the product)
+// stats: 16 words -- 8 as in DeepParams, [8] the reference's bucket touches in the width passes, [9] in bwt_match_gap, [10] expansions in key form, [11] their tail jumps / hits,
+// [12] forced walks through the table, [13] forced walks on the text.  Returns 0.
 extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const uint32_t *sa0, const uint32_t *sa1, const emu_opt *opt, int n, const int64_t *off,
 							   const uint8_t *seq, const uint8_t *rseq, int per_read, const int *knobs,
 							   int32_t *n_aln, uint32_t *rows /* n x aln_cap x 4 */, int32_t *max_ent, uint8_t *status,
@@ -131,6 +159,7 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	EmuBwt X[2];
 	build(X[0], bwt0); build(X[1], bwt1);
 	if (knobs[7] && sa0 && sa1) { build_text(X[0], sa0); build_text(X[1], sa1); }
+	if (knobs[9] > 0) { build_table(X[0], knobs[9]); build_table(X[1], knobs[9]); }
 	int max_len = 0;
 	for (int i = 0; i < n; ++i) if (off[i + 1] - off[i] > max_len) max_len = (int)(off[i + 1] - off[i]);
 	DeepParams P;
@@ -187,7 +216,8 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	S.n_aln = n_aln; S.max_ent = max_ent; S.status = status; S.aln = (uint4*)rows; S.aln_cap = aln_cap;
 	unsigned int counter = 0, bump = 0;
 	S.work_counter = &counter;
-	S.touch_counter = &st;
+	S.touch_counter = knobs[9] > 0 ? 0 : &st;
+	P.key_T = knobs[9] > 0 ? (uint32_t)knobs[9] : 0u;
 	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)(knobs[2] < 1 ? 1 : (knobs[2] > (int)DEEP_STAGE_MAX ? (int)DEEP_STAGE_MAX : knobs[2]));
 	P.max_lanes = knobs[0]; P.careful_all = knobs[1]; P.NS = NS; P.stats = stats;
 	const int per_wave = knobs[5];

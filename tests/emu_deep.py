@@ -37,15 +37,15 @@ def toy_words():
 
 
 def run(lib, words, opt, seq, rseq, off, per_read=0, max_lanes=64, careful=0, stage_k=32, n_pages=1 << 14, own_cap=1 << 14,
-        per_wave=0, aln_cap=1024, text=0, lds=1):
+        per_wave=0, aln_cap=1024, text=0, lds=1, table=0):
     """-> (rows per read, max_entries, status, stats)"""
     n = len(off) - 1
-    knobs = np.array([max_lanes, careful, stage_k, n_pages, own_cap, per_wave, aln_cap, text, lds], np.int32)
+    knobs = np.array([max_lanes, careful, stage_k, n_pages, own_cap, per_wave, aln_cap, text, lds, table], np.int32)
     n_aln = np.zeros(max(n, 1), np.int32)
     maxe = np.zeros(max(n, 1), np.int32)
     status = np.zeros(max(n, 1), np.uint8)
     rows = np.zeros((max(n, 1), aln_cap), T.ALN_DT)
-    stats = np.zeros(12, np.uint64)
+    stats = np.zeros(16, np.uint64)
     rc = lib.emu_deep_search(T.ptr(words[0]), T.ptr(words[1]), T.ptr(words[2]), T.ptr(words[3]), C.byref(opt), n, T.ptr(off), T.ptr(seq), T.ptr(rseq), per_read,
                              T.ptr(knobs), T.ptr(n_aln), T.ptr(rows), T.ptr(maxe), T.ptr(status), T.ptr(stats))
     assert rc == 0

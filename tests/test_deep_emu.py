@@ -63,6 +63,14 @@ def test_golden_sai(emu, words, orc, name):
     got, maxe, st, stats = E.run(emu, words, opt, seq, rseq, off, text=1)
     check(got, maxe, st, gold, wmaxe, "%s, text mode" % name)
     assert stats[7] > 0
+    assert stats[13] > 0, "no forced levels were walked on the text"
+    # key form: entries whose strings are shorter than the interval table is deep carry the string, not its rows (fm_deep.hpp); a shallow
+    # table moves the change to rows close to the roots, a deep one to where intervals are a few rows wide
+    for table, kn in ((2, dict()), (5, dict(max_lanes=7)), (9, dict(text=1))):
+        got, maxe, st, stats = E.run(emu, words, opt, seq, rseq, off, table=table, **kn)
+        check(got, maxe, st, gold, wmaxe, "%s, table of depth %d" % (name, table))
+        assert stats[10] > 0 and (stats[11] > 0 or table < 5), "no entry in key form was expanded / finished: %s" % stats[10:12]
+        assert stats[12] > 0 and (stats[13] > 0 or not kn.get("text")), "no forced levels were walked through the table / on the text: %s" % stats[12:14]
 
 
 def noisy_reads(seed, n, lens, err):
@@ -78,7 +86,9 @@ def deep_opt():
 
 
 @pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=1), dict(stage_k=3, max_lanes=64),
-                                   dict(stage_k=48, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1)])
+                                   dict(stage_k=48, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1),
+                                   dict(table=1), dict(table=4, careful=1), dict(table=7, stage_k=1), dict(table=8, text=1, per_wave=25), dict(table=10, lds=0, text=1),
+                                   dict(table=6, per_read=1, max_lanes=3)])
 def test_noisy_reads_vs_oracle(emu, words, orc, knobs):
     reads = noisy_reads(11, 150, (50, 63, 76, 100), 0.04)
     seq, rseq, off, _ = T.encode_reads(reads)
@@ -125,13 +135,38 @@ def test_pool_runs_dry_and_hit_rows_run_out(emu, words, orc):
         assert got[i].tobytes() == want[i].tobytes()
 
 
+def test_reads_shorter_than_the_table(emu, words, orc):
+    """a hit, an exact tail and the cut-off inside the table's depth: the rows come from the level of the entry's own string"""
+    from test_gpu_parity import toy_genome
+    rng = np.random.default_rng(15)
+    g = toy_genome()
+    reads = []
+    for i in range(300):
+        L = int(rng.integers(3, 14))
+        p = int(rng.integers(0, len(g) - L))
+        sq = list(g[p:p + L])
+        for _ in range(int(rng.integers(0, 3))):
+            sq[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+        reads.append(("s%d" % i, "".join(sq), "I" * L))
+    seq, rseq, off, _ = T.encode_reads(reads)
+    for opt in (T.default_opt(), deep_opt()):
+        opt.max_diff, opt.fnr, opt.seed_len = 2, -1.0, 5
+        for mode_bits in (0, 0x10):                      # the default, and -N: every hit within max_diff
+            opt.mode = (opt.mode & ~0x10) | mode_bits
+            want, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off)
+            for table in (0, 3, 8, 11):
+                got, maxe, st, _ = E.run(emu, words, opt, seq, rseq, off, table=table, text=1 if table == 8 else 0, aln_cap=4096)
+                check(got, maxe, st, want, wmaxe, "short reads, table %d" % table)
+
+
 def test_empty_and_all_n_reads(emu, words, orc):
     reads = [("e", "", ""), ("n", "N" * 60, "I" * 60), ("a", "ACGT" * 15, "I" * 60), ("n2", "ACGTN" * 12, "I" * 60)]
     seq, rseq, off, _ = T.encode_reads(reads)
     opt = T.default_opt()
     want, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off)
-    got, maxe, st, _ = E.run(emu, words, opt, seq, rseq, off)
-    check(got, maxe, st, want, wmaxe, "edge reads")
+    for table in (0, 6):
+        got, maxe, st, _ = E.run(emu, words, opt, seq, rseq, off, table=table)
+        check(got, maxe, st, want, wmaxe, "edge reads")
 
 
 def test_under_address_sanitizer():
@@ -141,7 +176,7 @@ def test_under_address_sanitizer():
     code = ("import sys; sys.path.insert(0, %r); import numpy as np, nabwa_testlib as T, emu_deep as E, test_deep_emu as D\n"
             "lib = E.load(asan=True); words = E.toy_words(); o = T.load_oracle(); ox = T.OracleIndex(o)\n"
             "reads = D.noisy_reads(14, 40, (50, 76, 100), 0.04); seq, rseq, off, _ = T.encode_reads(reads)\n"
-            "for kn in (dict(), dict(stage_k=2), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=48)):\n"
+            "for kn in (dict(), dict(stage_k=2), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=48), dict(table=7), dict(table=9, text=1, stage_k=2)):\n"
             "    opt = D.deep_opt(); want, wm = T.oracle_cal_sa_reg_gap(o, ox.h, opt, seq, rseq, off)\n"
             "    got, maxe, st, _ = E.run(lib, words, opt, seq, rseq, off, **kn)\n"
             "    assert all(st[i] == 3 or got[i].tobytes() == want[i].tobytes() for i in range(len(reads)))\n"

@@ -29,10 +29,13 @@ def orc():
     return lib, T.OracleIndex(lib)
 
 
+@pytest.mark.parametrize("keyform", ["1", "0"])
 @pytest.mark.parametrize("name", SAI_SETS)
-def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name):
-    """a first-pass arena of 16 entries sends nearly every read on to kernel D: rows = the reference's .sai, max_entries = the oracle's"""
+def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name, keyform):
+    """a first-pass arena of 16 entries sends nearly every read on to kernel D: rows = the reference's .sai, max_entries = the oracle's;
+    with entries in key form while the interval table reaches (the default) and as rows throughout"""
     monkeypatch.setenv("NABWA_CAP1", "16")
+    monkeypatch.setenv("NABWA_DEEP_KEYFORM", keyform)
     opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
     reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "nonstop" else "reads_se.fq"))
     seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
@@ -46,6 +49,52 @@ def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name):
     bad = [reads[i][0] for i in range(len(reads)) if got[i].tobytes() != gold[i].tobytes()]
     assert not bad, "kernel D differs from the reference .sai for %d reads, e.g. %s" % (len(bad), bad[:5])
     assert np.array_equal(maxe, wmaxe)
+
+
+@pytest.mark.parametrize("depth", ["3", "6"])
+def test_key_form_with_shallow_tables(orc, monkeypatch, depth):
+    """interval tables of 3 and 6 levels: the entries of kernel D change from key form to rows that close to the roots; and reads shorter
+    than the table is deep, whose hits and exact tails take their rows from the level of their own string"""
+    monkeypatch.setenv("NABWA_KMER_T", depth)
+    monkeypatch.setenv("NABWA_CAP1", "16")
+    ix = nabwa.Index.load(T.TOY, 0, True)
+    try:
+        for name in ("adna", "default", "nonstop", "e3"):
+            opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
+            reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "nonstop" else "reads_se.fq"))
+            seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
+            _, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, n_threads=8)
+            b = nabwa.Batch(ix, to_gap_opt(opt), seq, rseq, off, False)
+            b.run(); b.sync()
+            got, maxe = b.fetch()
+            b.close()
+            bad = [reads[i][0] for i in range(len(reads)) if got[i].tobytes() != gold[i].tobytes()]
+            assert not bad and np.array_equal(maxe, wmaxe), (name, bad[:5])
+        rng = np.random.default_rng(15)
+        g = toy_genome()
+        reads = []
+        for i in range(2000):
+            L = int(rng.integers(3, 14))
+            p = int(rng.integers(0, len(g) - L))
+            sq = list(g[p:p + L])
+            for _ in range(int(rng.integers(0, 3))):
+                sq[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+            reads.append(("s%d" % i, "".join(sq), "I" * L))
+        seq, rseq, off, _ = T.encode_reads(reads)
+        opt = deep_opt()
+        opt.max_diff, opt.fnr, opt.seed_len = 2, -1.0, 5
+        monkeypatch.setenv("NABWA_CAP1", "4")
+        monkeypatch.setenv("NABWA_ALNCAP2", "8192")
+        want, wmaxe = T.oracle_cal_sa_reg_gap(orc[0], orc[1].h, opt, seq, rseq, off, n_threads=8)
+        b = nabwa.Batch(ix, to_gap_opt(opt), seq, rseq, off, False)
+        b.run()
+        assert b.sync() > 500
+        got, maxe = b.fetch()
+        b.close()
+        bad = [i for i in range(len(reads)) if got[i].tobytes() != want[i].tobytes()]
+        assert not bad and np.array_equal(maxe, wmaxe), bad[:5]
+    finally:
+        ix.close()
 
 
 def deep_opt():
