@@ -14,28 +14,28 @@
 
 extern __shared__ __attribute__((aligned(16))) uint32_t s_deep[];
 
-template <bool PROF, bool LDSM>
+template <bool PROF, bool LDSM, bool COOP>
 // The statistics instantiation (phase clocks, touch counts: never timed) gets the whole register file: at 128 registers it spilled some 70 of
 // them -- among them the registers that hold spilled SCALAR values lane by lane -- and round 3 saw that build fault on the GPU
 // (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, a pointer read back wrong) while the same source passes in the CPU emulation and in the build
 // without statistics.  With two waves per SIMD nothing of it is spilled to memory.
 __global__ __launch_bounds__(64, PROF ? 2 : NABWA_DEEP_WAVES) void fm_deep_kernel(const DeepParams P)
 {
-	deep_wave_body<PROF, LDSM>(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
+	deep_wave_body<PROF, LDSM, COOP>(P, s_deep, blockIdx.x, (int)(threadIdx.x & 63u));
 }
 
 extern "C" void nabwa_launch_fm_deep(const DeepParams *P, int n_waves, hipStream_t s)
 {
 	const size_t lds = (size_t)DEEP_LDS_WORDS(P->NS, P->lds_rd) * 4u;
-	const bool prof = P->stats || P->S.touch_counter, ldsm = P->lds_rd != 0u;
-	if (prof && ldsm) hipLaunchKernelGGL((fm_deep_kernel<true, true>), dim3(n_waves), dim3(64), lds, s, *P);
-	else if (prof) hipLaunchKernelGGL((fm_deep_kernel<true, false>), dim3(n_waves), dim3(64), lds, s, *P);
-	else if (ldsm) hipLaunchKernelGGL((fm_deep_kernel<false, true>), dim3(n_waves), dim3(64), lds, s, *P);
-	else hipLaunchKernelGGL((fm_deep_kernel<false, false>), dim3(n_waves), dim3(64), lds, s, *P);
+	const bool prof = P->stats || P->S.touch_counter, ldsm = P->lds_rd != 0u, coop = P->coop_lanes != 0u;
+#define DEEP_GO(a_, b_, c_) hipLaunchKernelGGL((fm_deep_kernel<a_, b_, c_>), dim3(n_waves), dim3(64), lds, s, *P)
+	if (prof) { if (ldsm) { if (coop) DEEP_GO(true, true, true); else DEEP_GO(true, true, false); } else { if (coop) DEEP_GO(true, false, true); else DEEP_GO(true, false, false); } }
+	else { if (ldsm) { if (coop) DEEP_GO(false, true, true); else DEEP_GO(false, true, false); } else { if (coop) DEEP_GO(false, false, true); else DEEP_GO(false, false, false); } }
+#undef DEEP_GO
 }
 
 extern "C" int nabwa_deep_occupancy(int ns, int lds_rd)
 {
 	int nb = 0;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lds_rd ? fm_deep_kernel<false, true> : fm_deep_kernel<false, false>, 64, (size_t)DEEP_LDS_WORDS((unsigned)ns, (unsigned)lds_rd) * 4u) == hipSuccess ? nb : 0;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lds_rd ? fm_deep_kernel<false, true, true> : fm_deep_kernel<false, false, true>, 64, (size_t)DEEP_LDS_WORDS((unsigned)ns, (unsigned)lds_rd) * 4u) == hipSuccess ? nb : 0;
 }

@@ -18,6 +18,7 @@
 #define DF_CONT 2
 #define DF_TAIL 3      /* the chain ends in an exact tail that is still to be walked */
 #define DF_RUN  4      /* the chain stands in front of forced levels (no difference may be pushed) on ONE row: walked on the text, then the chain goes on */
+#define DF_COOP 5      /* ... on ONE row in front of levels that may push differences: the wave takes the chain's next levels together (one level per lane) */
 #define DCL_MM 0u      /* child classes = the three scores a chain at score s pushes to: s + s_mm, s + s_gapo, s + s_gape */
 #define DCL_GO 1u
 #define DCL_GE 2u
@@ -47,6 +48,7 @@ struct DeepParams {
 	uint32_t lds_rd, rd_pl;          // bytes of LDS for the read's own data (2 WLB + 2 SLB + 2 rd_pl; 0: it stays in global memory), stride of a strand's bases there
 	                                 // LDS per wave: DEEP_LDS_WORDS(NS, lds_rd) words
 	uint32_t key_T;                  // depth of the interval tables the searches may use for key-form entries (0: rows only -- no tables, or the touch-counting run)
+	uint32_t coop_lanes;             // a chain on one row is taken over by the whole wave (64 levels at a time) when no more than this many chains of the round are still running (0: never)
 	int hist;                        // statistics build: also the expansions by depth and form (stats[32 ..])
 	int careful_all, max_lanes;      // test knobs: every round one pop; lanes a round may use (production: 0, 64)
 	uint32_t *rounds_out;            // or null (statistics build): per work item the rounds its search took

@@ -125,7 +125,8 @@ DEEP_FN uint2 deep_ld_global8(const uint2 *p)
 // LDSM: the read's own data (bound bytes, seed bound bytes, bases) sit in the wave's LDS -- every read that fits (NABWA_DEEP_LDS_MAX); the other
 // instantiation reads them where kernel W / the batch put them.  A template flag, not a runtime one: the chain step consults these
 // bytes six times, and both ways of getting at them were in its code.
-template <bool PROF, bool LDSM>
+// COOP: with the wave-wide expansion of one-row chains (DF_COOP) -- for batches of reads long enough to have such chains (the host decides)
+template <bool PROF, bool LDSM, bool COOP>
 DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #ifndef NABWA_EMU
 							, const int ln
@@ -153,7 +154,8 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 	const bool gape_mode = S.mode & 0x01, nonstop = S.mode & 0x10, loggap = S.mode & 0x04;
 	unsigned long long st_rounds = 0, st_run = 0, st_commit = 0, st_steps = 0, st_careful = 0, st_pool = 0;
 	unsigned long long st_maxclk = 0, st_maxrounds = 0, st_sumclk = 0;
-	unsigned long long st_lanesteps = 0;
+	uint32_t coop_n = 0, coop_lv = 0, coop_skip = 0;      // the wave's one-row chains so far: taken over, their levels; steps since that stopped paying
+	unsigned long long st_lanesteps = 0, st_coop = 0, st_cooplev = 0;      // ... wave-wide expansions of one-row chains, levels they took
 	// (statistics build) per lane: expansions of entries in key form / their tail jumps and hits / records filed / children stored / entries pruned at the pop /
 	// expansions / rank queries on two buckets / expansions that may push no difference (allow_diff false): in key form, on one row, on several rows
 	LANE(uint32_t, pk_key); LANE(uint32_t, pk_ktl); LANE(uint32_t, pk_rec); LANE(uint32_t, pk_chl); LANE(uint32_t, pk_prn); LANE(uint32_t, pk_exp); LANE(uint32_t, pk_two);
@@ -196,6 +198,19 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 #define DEEP_RD(a_, p_) (lds_mode ? (uint32_t)s_sq[(uint32_t)(a_) * PL + (uint32_t)(p_)] : (uint32_t)((a_) ? S.rseq : S.seq)[sq_off + (size_t)(p_)])
 #define DEEP_RD16(a_, p_) (lds_mode ? *(const uint4*)(s_sq + (uint32_t)(a_) * PL + (uint32_t)(p_)) : *(const uint4*)(((a_) ? S.rseq : S.seq) + sq_off + (size_t)(p_)))
 
+	// the bounds of the prefix still to match and of the seed for an expansion at read position p_ (bwtgap.c:205-215): ad_ = allow_diff, am_ = allow_M
+#define DEEP_BOUNDS(a_, p_, m_, ms_, ad_, am_) do { \
+		const bool in_ = (p_) > 0; \
+		const uint32_t B1_ = DEEP_BB(a_, in_ ? (p_) - 1 : 0), B0_ = DEEP_BB(a_, p_); \
+		const int b1_ = (int)(B1_ & 127u), b0_ = (int)(B0_ & 127u); \
+		const bool no_d_ = in_ && b1_ > (m_) - 1, no_m_ = in_ && b1_ == (m_) - 1 && b0_ == (m_) - 1 && (B0_ & 128u) != 0u; \
+		const int ii_ = (p_) - (len - S.seed_len); \
+		const bool sd_ = seeded && in_ && ii_ > 0; \
+		const uint32_t S1_ = DEEP_SB(a_, sd_ ? ii_ - 1 : 0), S0_ = DEEP_SB(a_, sd_ ? ii_ : 0); \
+		const int s1_ = (int)(S1_ & 127u), s0_ = (int)(S0_ & 127u); \
+		const bool no_ds_ = sd_ && s1_ > (ms_) - 1, no_ms_ = sd_ && s1_ == (ms_) - 1 && s0_ == (ms_) - 1 && (S0_ & 128u) != 0u; \
+		ad_ = !(no_d_ || no_ds_); \
+		am_ = !((!no_d_ && no_m_) || (!no_ds_ && no_ms_)); } while (0)
 	// an expansion at read position p_ that may push no difference (bwtgap.c:205-215: allow_diff = 0), for an entry with m_ differences left (ms_ in the seed)
 #define DEEP_FORCED(a_, p_, m_, ms_) ((p_) > 0 && ((int)(DEEP_BB(a_, (p_) - 1) & 127u) > (m_) - 1 || \
 		(seeded && (p_) - (len - S.seed_len) > 0 && (int)(DEEP_SB(a_, (p_) - (len - S.seed_len) - 1) & 127u) > (ms_) - 1)))
@@ -310,7 +325,13 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				unsigned long long pc2 = 0;
 				for (;;) {
 				while (WBALLOT(L(act)) != 0ull) {
-					if (PROF) { ++st_steps; st_lanesteps += (unsigned)__popcll((unsigned long long)WBALLOT(L(act))); }
+					const uint32_t n_act = (uint32_t)__popcll((unsigned long long)WBALLOT(L(act)));
+					// few chains left in this round: the long ones -- worth the wave's while (DF_COOP, below), as long as the chains it took so far
+					// went on for 4 levels and more on average (reads of 50 bases do not: their chains end after a level or two, and the wave's
+					// time is better spent on chain steps; asked again after a while -- a batch may mix libraries)
+					if (COOP && coop_n >= 16u && coop_lv < 4u * coop_n && ++coop_skip >= 4096u) { coop_n = coop_lv = coop_skip = 0u; }
+					const bool coop_ok = COOP && n_act <= P.coop_lanes && (coop_n < 16u || coop_lv >= 4u * coop_n);
+					if (PROF) { ++st_steps; st_lanesteps += n_act; }
 					LANES { if (L(act)) {
 						DeepLane &E = L(e);
 						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
@@ -386,8 +407,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 										}
 									}
 									if (die) L(act) = false;
-								} else if (!allow_diff && text_ok && E.k == E.l && !L(norun)) {
-									walked = true; L(flag) = DF_RUN; L(act) = false;
+								} else if (text_ok && E.k == E.l && !L(norun) && (!allow_diff || coop_ok)) {
+									// (forced levels: DF_RUN, every lane walks its own stretch; levels that may push differences: DF_COOP, the wave takes
+									// the chain's next levels together, 64 at a time -- see behind the tails' loop)
+									walked = true; L(flag) = allow_diff ? DF_COOP : DF_RUN; L(act) = false;
 									if (PROF) L(pk_f1) += 1u;
 								}
 								if (!walked) {
@@ -469,7 +492,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					} }
 					// a chain that ended in a hit or ran out of staging room: the lanes above it will be dropped
 					const uint64_t sm = WBALLOT(L(flag) == DF_HIT || L(flag) == DF_CONT);
-					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) { L(act) = false; if (L(flag) == DF_TAIL || L(flag) == DF_RUN) L(flag) = DF_NONE; } } }
+					if (sm) { const int j = deep_ctz64(sm); LANES { if (ln > j) { L(act) = false; if (L(flag) == DF_TAIL || L(flag) == DF_RUN || L(flag) == DF_COOP) L(flag) = DF_NONE; } } }
 				}
 
 				// ---------------------------------------------------------------- the parked exact tails, all together: every turn
@@ -482,11 +505,11 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// for one load --, a hit takes the rows of its own string)
 				LANES {
 					const bool kf = L(e).l >= DEEP_KEYL;
-					L(ts) = L(flag) == DF_TAIL ? (kf ? 5 : ((text_ok && L(e).k == L(e).l) ? 1 : 0)) : (L(flag) == DF_HIT && kf ? 6 : (L(flag) == DF_RUN ? 7 : -1));
+					L(ts) = L(flag) == DF_TAIL ? (kf ? 5 : ((text_ok && L(e).k == L(e).l) ? 1 : 0)) : (L(flag) == DF_HIT && kf ? 6 : (L(flag) == DF_RUN || L(flag) == DF_COOP ? 7 : -1));
 				}
-				while (WBALLOT(L(ts) >= 0) != 0ull) {
+				while (WBALLOT(L(ts) >= 0 && L(ts) != 10) != 0ull) {
 					if (PROF) ++st_tailit;
-					LANES { if (L(ts) >= 0) {
+					LANES { if (L(ts) >= 0 && L(ts) != 10) {
 						DeepLane &E = L(e);
 						const bool q1 = E.a == 0;
 						bool fail = false, hit = false;
@@ -535,7 +558,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							// ---- forced levels of an entry on ONE row (DF_RUN): the text position of its suffix, ...
 							const uint32_t pos = (q1 ? S.bwt[1].sa_full : S.bwt[0].sa_full)[E.k];
 							if (pos == 0xffffffffu) { L(rel) += 1; L(act) = true; L(norun) = true; L(flag) = DF_NONE; L(ts) = -1; }      // (the empty suffix: this entry takes its levels by rank queries; its pop is undone)
-							else { L(tpos) = pos; L(ts) = 8; }
+							else { L(tpos) = pos; L(ts) = L(flag) == DF_COOP ? 10 : 8; }      // (10: waits for the wave, behind this loop)
 						} else if (L(ts) == 8) {
 							// ... the levels, up to 32 per turn: level after level what the chain step would do with an expansion that pushes its matching
 							// child alone and with that child's pop -- the symbol in front of the suffix is the text's, ...
@@ -585,7 +608,147 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						else if (hit) { L(flag) = DF_HIT; L(ts) = -1; }
 					} }
 				}
-				if (WBALLOT(L(act)) == 0ull) break;
+				// ---------------------------------------------------------------- chains on ONE row, the wave together (DF_COOP).  The chain in front
+				// of a search's first hit follows the read along one suffix of the text for a hundred levels and more, storing an insertion and a
+				// deletion at every one of them: as chain steps that is a hundred wave-steps with one lane at work.  But everything a level does is
+				// known from the text -- the one symbol in front of the suffix, hence the children that exist -- and from the read and its bounds;
+				// what runs from level to level is only "the match went on" and sums.  So the wave takes such a chain 64 levels at a time, lane d
+				// its level d: the entry there (row, position), what its pop finds (bwtgap.c:141-164), what its expansion pushes and stores; the
+				// chain reaches level d when every level before it matched on (a ballot), the live-entry count, its peak, the classes' offsets
+				// and the record slots are prefix sums over the levels reached, and the records leave together.  Then the chain's lane gets the
+				// state the chain step would have left it in: ended, a hit, an exact tail, out of record room, or 64 levels further on.
+				if (COOP) {
+					uint64_t cm = WBALLOT(L(ts) == 10);
+					if (cm) {
+						const uint64_t sm2 = WBALLOT(L(flag) == DF_HIT || L(flag) == DF_CONT);
+						int jstop = sm2 ? deep_ctz64(sm2) : 64;
+						LANE(uint32_t, v_rk); LANE(uint32_t, v_rc); LANE(uint32_t, v_inf); LANE(uint32_t, v_g); LANE(uint32_t, v_rec);
+						LANE(uint32_t, v_a0); LANE(uint32_t, v_a1); LANE(uint32_t, v_a2); LANE(uint32_t, v_ng);
+						LANE(uint32_t, x_g); LANE(uint32_t, x_f); LANE(uint32_t, x_0); LANE(uint32_t, x_1); LANE(uint32_t, x_2);
+						while (cm) {
+							const int j = deep_ctz64(cm);
+							cm &= cm - 1ull;
+							if (j > jstop) { LANES { if (ln == j) { L(flag) = DF_NONE; L(ts) = -1; } } continue; }      // a lane below it ended in a hit or is to be continued: dropped
+							if (PROF) ++st_coop;
+							// the chain: its entry (popped, past its pop's checks), its text position, its counts so far
+							LANES { L(tu) = L(e).k; } const uint32_t ck = WUNI(WBCAST(tu, j));
+							LANES { L(tu) = (uint32_t)L(e).i; } const int ci = (int)WUNI(WBCAST(tu, j));
+							LANES { L(tu) = (uint32_t)L(e).mm | (uint32_t)L(e).go << 8 | (uint32_t)L(e).ge << 16 | (uint32_t)L(e).state << 24 | (uint32_t)L(e).a << 26; }
+							const uint32_t cinfo = WUNI(WBCAST(tu, j));
+							const uint32_t ctp = WUNI(WBCAST(tpos, j));
+							const int crel = (int)WUNI(WBCAST(rel, j)), cpeak = (int)WUNI(WBCAST(peak, j));
+							const uint32_t c0 = WUNI(WBCAST(cc0, j)), c1 = WUNI(WBCAST(cc1, j)), c2 = WUNI(WBCAST(cc2, j)), cnr = WUNI(WBCAST(nrec, j));
+							const int cmm = (int)(cinfo & 0xffu), cgo = (int)(cinfo >> 8 & 0xffu), cge = (int)(cinfo >> 16 & 0xffu), cst = (int)(cinfo >> 24 & 3u);
+							const uint32_t ca = cinfo >> 26 & 1u;
+							const bool cq1 = ca == 0u;
+							const uint32_t *const isa = cq1 ? S.bwt[1].isa : S.bwt[0].isa, *const txt = cq1 ? S.bwt[1].text : S.bwt[0].text;
+							const int m = max_diff - cmm - cgo - (gape_mode ? cge : 0), m_seed = S.max_seed_diff - cmm - cgo - (gape_mode ? cge : 0);
+							int tmp = cgo + cge;
+							if (loggap) { const uint32_t v = (uint32_t)(cge + cgo); tmp = (v ? 31 - __clz((int)v) : 0) / 2 + 1; }
+							// ---- lane d: level d.  kind: 0 expanded and matched on, 1 expanded and the chain ends, 2 dropped at the pop, 3 a hit, 4 an exact tail, 5 no such level
+							LANES {
+								const uint32_t d = (uint32_t)ln;
+								uint32_t kind = 5u, rk = 0u, rc = 0u, g = 0u, a0 = 0u, a1 = 0u, a2 = 0u, ng = 0u, rcd = 0u, inf = 0u;
+								if ((int)d <= ci && d <= ctp) {
+									const int Ei = ci - (int)d;
+									const uint32_t tq = ctp - d;
+									rk = d == 0u ? ck : isa[tq];
+									const int st = d == 0u ? cst : DST_M;
+									bool go_on = true, hit = false, tail = false;
+									if (d > 0u) {
+										go_on = m >= 0 && !(Ei > 0 && m < (int)(DEEP_BB(ca, Ei - 1) & 127u));
+										hit = go_on && Ei == 0;
+										tail = go_on && !hit && m == 0;
+									}
+									if (!go_on) kind = 2u; else if (hit) kind = 3u; else if (tail) kind = 4u;
+									else {
+										const int p = Ei - 1;
+										const bool have = tq >= 1u;
+										uint32_t x = 0u;
+										if (have) { x = txt[(tq - 1u) >> 4] >> (((tq - 1u) & 15u) << 1) & 3u; rc = isa[tq - 1u]; }
+										bool allow_diff, allow_M;
+										DEEP_BOUNDS(ca, p, m, m_seed, allow_diff, allow_M);
+										const uint32_t vm = have ? 1u << x : 0u, nv = have ? 1u : 0u;
+										uint32_t grp = 0u, n_gap = 0u, gcls = DCL_GO;
+										if (allow_diff && p >= S.indel_end_skip + tmp && len - p >= S.indel_end_skip + tmp) {
+											if (st == DST_M) { if (cgo < MG) { grp = DRG_OPEN; n_gap = 1u + nv; } }
+											else if (st == DST_I) { if (cge < S.max_gape) { grp = DRG_EXT_I; n_gap = 1u; gcls = DCL_GE; } }
+											else if (cge < S.max_gape && (cge + cgo < max_diff || 1u < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
+										}
+										const uint32_t c = DEEP_RD(ca, p);
+										uint32_t mmv = 0u; bool match = false;
+										if (allow_diff && allow_M) { mmv = c > 3u ? vm : vm & ~(1u << c); match = c <= 3u && (vm >> c & 1u); }
+										else if (c < 4u) match = (vm >> c & 1u) != 0u;
+										const uint32_t n_mm = (uint32_t)__popc(mmv);
+										g = n_gap + n_mm;
+										const bool keep_gap = gcls == DCL_GO ? keep1 : keep2;
+										if (!keep_gap) { grp = 0u; n_gap = 0u; }
+										if (!keep0) mmv = 0u;
+										const uint32_t n_mm_st = keep0 ? n_mm : 0u;
+										const uint32_t gcn = gcls == DCL_GO ? can1 : can2;
+										ng = n_gap;
+										a0 = (gcn == 0u ? n_gap : 0u) + n_mm_st; a1 = gcn == 1u ? n_gap : 0u; a2 = gcn == 2u ? n_gap : 0u;
+										rcd = n_gap + n_mm_st ? 1u : 0u;
+										inf = vm | grp << 4 | mmv << 8 | gcn << 12 | (c & 7u) << 14;
+										kind = match ? 0u : 1u;
+									}
+								}
+								L(v_rk) = rk; L(v_rc) = rc; L(v_inf) = inf | kind << 17; L(v_g) = g; L(v_rec) = rcd; L(v_a0) = a0; L(v_a1) = a1; L(v_a2) = a2; L(v_ng) = ng;
+							}
+							// ---- how far the chain gets: every level before it matched on; no further than its record room (or, careful, one pop)
+							const uint64_t contm = WBALLOT((L(v_inf) >> 17 & 7u) == 0u);
+							const uint32_t z = ~contm ? (uint32_t)deep_ctz64(~contm) : 63u;
+							LANES { if ((uint32_t)ln > z) { L(v_g) = 0u; L(v_rec) = 0u; L(v_a0) = L(v_a1) = L(v_a2) = 0u; } }
+							uint32_t tot_ = 0;
+							WEXSCAN_U32(L(x_g), L(v_g), tot_); WEXSCAN_U32(L(x_f), L(v_rec), tot_);
+							WEXSCAN_U32(L(x_0), L(v_a0), tot_); WEXSCAN_U32(L(x_1), L(v_a1), tot_); WEXSCAN_U32(L(x_2), L(v_a2), tot_);
+							(void)tot_;
+							const uint64_t fullm = WBALLOT((uint32_t)ln <= z && (L(v_inf) >> 17 & 7u) == 0u && (careful || cnr + L(x_f) + L(v_rec) >= K));
+							const uint32_t le = fullm ? (uint32_t)deep_ctz64(fullm) : z;
+							const bool cut = fullm != 0ull;
+							if (PROF) st_cooplev += le + 1u;
+							++coop_n; coop_lv += le + 1u;
+							if (coop_n >= 0x40000000u) { coop_n >>= 1; coop_lv >>= 1; }
+							int64_t mxr = (int64_t)cpeak;
+							{ int64_t mx_ = 0; WMAX_I64(mx_, ((uint32_t)ln >= 1u && (uint32_t)ln <= le) ? (int64_t)crel + 1 + (int64_t)L(x_g) : (int64_t)cpeak); if (mx_ > mxr) mxr = mx_; }
+							// ---- the records of the levels reached
+							LANES {
+								if ((uint32_t)ln <= le && L(v_rec)) {
+									const uint32_t inf = L(v_inf), vm = inf & 15u, grp = inf >> 4 & 3u, mmv = inf >> 8 & 15u, gcn = inf >> 12 & 3u, c = inf >> 14 & 7u;
+									const uint32_t rc = L(v_rc), rk = L(v_rk);
+									const uint32_t at_gap = gcn == 0u ? c0 + L(x_0) : (gcn == 1u ? c1 + L(x_1) : c2 + L(x_2));
+									const uint32_t at_mm = c0 + L(x_0) + (gcn == 0u ? L(v_ng) : 0u);
+									const uint32_t p = (uint32_t)(ci - ln - 1);
+									uint4 *const rp = stage + ((size_t)j * K + cnr + L(x_f)) * 4u;
+									rp[0] = make_uint4(vm & 1u ? rc : 1u, vm & 2u ? rc : 1u, vm & 4u ? rc : 1u, vm & 8u ? rc : 1u);
+									rp[1] = make_uint4(vm & 1u ? rc : 0u, vm & 2u ? rc : 0u, vm & 4u ? rc : 0u, vm & 8u ? rc : 0u);
+									rp[2] = make_uint4(rk, rk, p | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
+													   (uint32_t)cmm | (uint32_t)cgo << 8 | (uint32_t)cge << 16 | ca << 26 | c << 27);
+									rp[3] = make_uint4(at_gap, at_mm, 0u, 0u);
+								}
+							}
+							// ---- the chain's lane: where the chain step would have left it
+							const uint32_t e_kind = WUNI(WBCAST(v_inf, le)) >> 17 & 7u, e_rk = WUNI(WBCAST(v_rk, le)), e_rc = WUNI(WBCAST(v_rc, le));
+							const uint32_t e_g = WUNI(WBCAST(v_g, le)), e_xg = WUNI(WBCAST(x_g, le)), e_nr = cnr + WUNI(WBCAST(x_f, le)) + WUNI(WBCAST(v_rec, le));
+							const uint32_t n0 = c0 + WUNI(WBCAST(x_0, le)) + WUNI(WBCAST(v_a0, le)), n1 = c1 + WUNI(WBCAST(x_1, le)) + WUNI(WBCAST(v_a1, le)), n2 = c2 + WUNI(WBCAST(x_2, le)) + WUNI(WBCAST(v_a2, le));
+							const int nrel = crel + (int)e_xg + (e_kind <= 1u ? (int)e_g : 0) + (e_kind == 0u ? 1 : 0);
+							LANES { if (ln == j) {
+								DeepLane &E = L(e);
+								L(rel) = nrel; L(peak) = (int)mxr; L(cc0) = n0; L(cc1) = n1; L(cc2) = n2; L(nrec) = e_nr; L(ts) = -1; L(flag) = DF_NONE;
+								if (e_kind == 0u) {                                       // its matching child is the next pop: out of room / careful (to be continued), or on it goes
+									E.k = E.l = e_rc; E.i = (uint32_t)(ci - (int)le - 1); E.ldp = 0; E.state = DST_M;
+									if (cut) L(flag) = DF_CONT; else L(act) = true;
+								} else if (e_kind == 3u || e_kind == 4u) {
+									E.k = E.l = e_rk; E.i = (uint32_t)(ci - (int)le); E.ldp = 0; E.state = DST_M;
+									L(flag) = e_kind == 3u ? DF_HIT : DF_TAIL;
+								}
+							} }
+							if ((e_kind == 0u && cut) || e_kind == 3u) { if (j < jstop) jstop = j; }
+							WAVE_SYNC();
+						}
+					}
+				}
+				if (WBALLOT(L(act) || L(flag) == DF_TAIL) == 0ull) break;
 				if (prof) { pc1 = DEEP_CLOCK(); ph_tail += pc1 - pc2; }
 				}
 
@@ -795,7 +958,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 		LANES { L(d) = L(pk_fw); } WEXSCAN_U32(L(off), L(d), s_fw);
 		ONE_LANE {
 #ifdef NABWA_EMU
-			P.stats[10] += s_key; P.stats[11] += s_ktl; P.stats[12] += s_fk; P.stats[13] += s_f1;
+			P.stats[10] += s_key; P.stats[11] += s_ktl; P.stats[12] += s_fk; P.stats[13] += s_f1; P.stats[14] += st_coop; P.stats[15] += st_cooplev;
 			P.stats[0] += st_rounds; P.stats[1] += st_run; P.stats[2] += st_commit; P.stats[3] += st_steps; P.stats[4] += st_careful; P.stats[5] += st_pool; P.stats[6] += t6; P.stats[7] += t7;
 #else
 			atomicAdd(P.stats + 0, st_rounds); atomicAdd(P.stats + 1, st_run); atomicAdd(P.stats + 2, st_commit);

@@ -888,6 +888,9 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 
 		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
 		D.hist = getenv("NABWA_DEEP_HIST") ? 1 : 0;
+		/* the wave-wide expansion of one-row chains pays where chains are long: reads of 100 bases and more (PE D -24 %); on reads of 50-76 bases
+		 * its chains end after a level or two, and the kernel built without it is the faster one (profiles/r03_deep_variants.txt) */
+		D.coop_lanes = (uint32_t)env_int("NABWA_DEEP_COOP", b->max_len >= 90 ? 4 : 0);
 		/* NABWA_DEEP_DUMP=<file> (investigations of the work order): per search of the first launch its read, length, max_diff, the width
 		 * passes' restart classes, what kernel S saw of it (trips, hits) and the rounds kernel D needed -- int32 x 8 per search */
 		const char *dump_path = getenv("NABWA_DEEP_DUMP");

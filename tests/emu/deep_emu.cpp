@@ -148,7 +148,7 @@ struct emu_opt { int s_mm, s_gapo, s_gape, mode, indel_end_skip, max_del_occ, ma
 
 // knobs: [8] 1 = the read's own data in (emulated) LDS;  [0] max_lanes, [1] careful_all, [2] stage_k, [3] n_pages, [4] own_cap, [5] reads per wave (0: one wave takes all), [6] aln_cap,
 // [7] text mode (needs sa0 / sa1: the .sa / .rsa file contents; touches are then not the reference's), [9] depth of the interval tables for key-form entries (0: none; the
-// touch counter is then off, as in the product)
+// touch counter is then off, as in the product), [10] coop_lanes (DeepParams)
 // stats: 16 words -- 8 as in DeepParams, [8] the reference's bucket touches in the width passes, [9] in bwt_match_gap, [10] expansions in key form, [11] their tail jumps / hits,
 // [12] forced walks through the table, [13] forced walks on the text.  Returns 0.
 extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const uint32_t *sa0, const uint32_t *sa1, const emu_opt *opt, int n, const int64_t *off,
@@ -218,6 +218,7 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	S.work_counter = &counter;
 	S.touch_counter = knobs[9] > 0 ? 0 : &st;
 	P.key_T = knobs[9] > 0 ? (uint32_t)knobs[9] : 0u;
+	P.coop_lanes = (uint32_t)knobs[10];
 	P.n_pages = (uint32_t)knobs[3]; P.own_cap = (uint32_t)knobs[4]; P.stage_k = (uint32_t)(knobs[2] < 1 ? 1 : (knobs[2] > (int)DEEP_STAGE_MAX ? (int)DEEP_STAGE_MAX : knobs[2]));
 	P.max_lanes = knobs[0]; P.careful_all = knobs[1]; P.NS = NS; P.stats = stats;
 	const int per_wave = knobs[5];
@@ -231,8 +232,8 @@ extern "C" int emu_deep_search(const uint32_t *bwt0, const uint32_t *bwt1, const
 	P.pages = pages.data(); P.page_prev = prev.data(); P.page_bump = &bump; P.own = own.data(); P.stage = stage.data();
 	for (int w = 0; w < n_waves; ++w) {
 		S.n = per_wave > 0 ? ((w + 1) * per_wave < n ? (w + 1) * per_wave : n) : n;
-		if (P.lds_rd) deep_wave_body<true, true>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
-		else deep_wave_body<true, false>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
+		if (P.lds_rd) deep_wave_body<true, true, true>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
+		else deep_wave_body<true, false, true>(P, (uint32_t*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15), (uint32_t)w);
 		counter = (unsigned int)S.n;     /* (the wave's last, failed draw took a number: on the GPU all waves draw until the reads are gone) */
 	}
 	stats[8] = wt; stats[9] = st;

@@ -37,10 +37,10 @@ def toy_words():
 
 
 def run(lib, words, opt, seq, rseq, off, per_read=0, max_lanes=64, careful=0, stage_k=32, n_pages=1 << 14, own_cap=1 << 14,
-        per_wave=0, aln_cap=1024, text=0, lds=1, table=0):
+        per_wave=0, aln_cap=1024, text=0, lds=1, table=0, coop=64):
     """-> (rows per read, max_entries, status, stats)"""
     n = len(off) - 1
-    knobs = np.array([max_lanes, careful, stage_k, n_pages, own_cap, per_wave, aln_cap, text, lds, table], np.int32)
+    knobs = np.array([max_lanes, careful, stage_k, n_pages, own_cap, per_wave, aln_cap, text, lds, table, coop], np.int32)
     n_aln = np.zeros(max(n, 1), np.int32)
     maxe = np.zeros(max(n, 1), np.int32)
     status = np.zeros(max(n, 1), np.uint8)

@@ -64,6 +64,9 @@ def test_golden_sai(emu, words, orc, name):
     check(got, maxe, st, gold, wmaxe, "%s, text mode" % name)
     assert stats[7] > 0
     assert stats[13] > 0, "no forced levels were walked on the text"
+    assert stats[14] > 0 and stats[15] >= stats[14], "no chain on one row was taken by the wave: %s" % stats[14:16]
+    got, maxe, st, stats = E.run(emu, words, opt, seq, rseq, off, text=1, coop=3, stage_k=2)
+    check(got, maxe, st, gold, wmaxe, "%s, text mode, few records per chain, the wave takes over below 4 chains" % name)
     # key form: entries whose strings are shorter than the interval table is deep carry the string, not its rows (fm_deep.hpp); a shallow
     # table moves the change to rows close to the roots, a deep one to where intervals are a few rows wide
     for table, kn in ((2, dict()), (5, dict(max_lanes=7)), (9, dict(text=1))):
@@ -88,7 +91,7 @@ def deep_opt():
 @pytest.mark.parametrize("knobs", [dict(), dict(max_lanes=1), dict(max_lanes=7), dict(careful=1), dict(stage_k=1), dict(stage_k=3, max_lanes=64),
                                    dict(stage_k=48, text=1), dict(per_wave=25), dict(per_read=1), dict(text=1, max_lanes=9), dict(lds=0), dict(lds=0, text=1),
                                    dict(table=1), dict(table=4, careful=1), dict(table=7, stage_k=1), dict(table=8, text=1, per_wave=25), dict(table=10, lds=0, text=1),
-                                   dict(table=6, per_read=1, max_lanes=3)])
+                                   dict(table=6, per_read=1, max_lanes=3), dict(text=1, coop=0), dict(text=1, coop=2, table=7), dict(text=1, coop=64, careful=1)])
 def test_noisy_reads_vs_oracle(emu, words, orc, knobs):
     reads = noisy_reads(11, 150, (50, 63, 76, 100), 0.04)
     seq, rseq, off, _ = T.encode_reads(reads)
@@ -176,7 +179,7 @@ def test_under_address_sanitizer():
     code = ("import sys; sys.path.insert(0, %r); import numpy as np, nabwa_testlib as T, emu_deep as E, test_deep_emu as D\n"
             "lib = E.load(asan=True); words = E.toy_words(); o = T.load_oracle(); ox = T.OracleIndex(o)\n"
             "reads = D.noisy_reads(14, 40, (50, 76, 100), 0.04); seq, rseq, off, _ = T.encode_reads(reads)\n"
-            "for kn in (dict(), dict(stage_k=2), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=48), dict(table=7), dict(table=9, text=1, stage_k=2)):\n"
+            "for kn in (dict(), dict(stage_k=2), dict(n_pages=8, own_cap=8), dict(per_wave=7), dict(text=1), dict(text=1, stage_k=48), dict(table=7), dict(table=9, text=1, stage_k=2), dict(text=1, coop=2)):\n"
             "    opt = D.deep_opt(); want, wm = T.oracle_cal_sa_reg_gap(o, ox.h, opt, seq, rseq, off)\n"
             "    got, maxe, st, _ = E.run(lib, words, opt, seq, rseq, off, **kn)\n"
             "    assert all(st[i] == 3 or got[i].tobytes() == want[i].tobytes() for i in range(len(reads)))\n"

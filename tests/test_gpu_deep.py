@@ -29,13 +29,16 @@ def orc():
     return lib, T.OracleIndex(lib)
 
 
-@pytest.mark.parametrize("keyform", ["1", "0"])
+@pytest.mark.parametrize("keyform,coop", [("1", None), ("0", None), ("1", "64"), ("0", "0")])
 @pytest.mark.parametrize("name", SAI_SETS)
-def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name, keyform):
+def test_every_golden_option_set_through_kernel_d(gix, orc, monkeypatch, name, keyform, coop):
     """a first-pass arena of 16 entries sends nearly every read on to kernel D: rows = the reference's .sai, max_entries = the oracle's;
-    with entries in key form while the interval table reaches (the default) and as rows throughout"""
+    with entries in key form while the interval table reaches (the default) and as rows throughout; with the wave-wide expansion of
+    one-row chains as the library picks it (on: these reads have 100 bases), for every such chain, and never"""
     monkeypatch.setenv("NABWA_CAP1", "16")
     monkeypatch.setenv("NABWA_DEEP_KEYFORM", keyform)
+    if coop is not None:
+        monkeypatch.setenv("NABWA_DEEP_COOP", coop)
     opt, gold = T.read_sai(os.path.join(T.GOLDEN, "se_%s.sai" % name))
     reads = T.read_fastq(os.path.join(T.GOLDEN, "reads_se_head.fq" if name == "nonstop" else "reads_se.fq"))
     seq, rseq, off, _ = T.encode_reads(reads, opt.trim_qual)
