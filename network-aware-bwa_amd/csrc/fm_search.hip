@@ -354,6 +354,11 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 	uint32_t item = 0; int len = 0; uint32_t mdmg = 0;   // mdmg: this read's max_diff | max_gapo << 8
 	uint32_t sq_off = 0;                                    // this read's offset in the padded base arrays
 	const int KT = (int)P.bwt[0].kmer_T;                    // 0 in the touch-counting run
+	// the hand-over budget: in a batch most of whose reads occur exactly on neither strand (the width passes counted them: *n_sync, the reads in front
+	// of the class-0 ones in the work order) the searches are bushy ones -- kernel D's kind -- and go there sooner (2 x 150 bp at 2 %: S 133 + D 90 ms
+	// at 2000 trips, S 17 + D 154 ms at 200; 100 bp at 0.2 %: 2000 is the optimum; profiles/r03_deep_variants.txt)
+	uint32_t budget = P.trip_budget;
+	if (!COUNT && P.n_sync && P.trip_budget_hard && 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)*P.n_sync) > (uint32_t)P.n) budget = P.trip_budget_hard;
 #define RID item                                            /* results and width records are indexed by read */
 #define REC (P.wdata + (size_t)RID * P.wstride)            /* this read's width record (kernel W) */
 #define MD_READ ((int)(mdmg & 0xffu))
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_MIN_WAVES) void fm_search
 				if (n_entries > P.max_entries) finish = true;                 // bwtgap.c:140
 				// a search that is still running after trip_budget trips is handed on to kernel D, which gives it a whole wave: the
 				// launch cannot end before its longest lane does, and one lane walks a long search pop by pop
-				else if (!COUNT && P.trip_budget && rd_trips > P.trip_budget) { status = NABWA_ST_OVERFLOW; finish = true; }
+				else if (!COUNT && P.trip_budget && rd_trips > budget) { status = NABWA_ST_OVERFLOW; finish = true; }
 			}
 			if (!finish) {
 				const int best_mem = mask_first();

@@ -42,6 +42,7 @@ struct SearchParams {
 	int aln_cap;
 	unsigned int *work_counter;               // [0] kernel S, [1] kernel W
 	uint32_t trip_budget;                     // kernel S: trips after which a search is handed on to kernel D (0: never)
+	uint32_t trip_budget_hard;                // ... in a batch most of whose reads have no exact occurrence on either strand (*n_sync > n / 2: the searches are kernel D's kind)
 	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
 	const uint32_t *rd_pack; int pack_stride;  // both strands of every read 2 bits per base (pad_reads_kernel); words per read
 	int w_sync;                               // kernel W: lockstep waves (all reads of the batch have one length)

@@ -656,6 +656,8 @@ extern "C" int nabwa_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt,
 	 * optimum too.  Without a seed (reads no longer than seed_len: the ancient-DNA options) the searches that do not end early are deep, and
 	 * every trip kernel S spends on them is spent again by kernel D: 6.25 M reads, 300 / 1000 / 2000 / 5000 -> 2.29 / 2.20 / 2.20 / 2.04 M reads/s */
 	P.trip_budget = (uint32_t)env_int("NABWA_TRIP_BUDGET", max_len > opt->seed_len ? 2000 : 300);
+	P.trip_budget_hard = (uint32_t)env_int("NABWA_TRIP_BUDGET_HARD", max_len > opt->seed_len ? 200 : (int)P.trip_budget);      /* (a batch of reads that mostly occur on neither strand: fm_search.hip) */
+	if (getenv("NABWA_TRIP_BUDGET") && !getenv("NABWA_TRIP_BUDGET_HARD")) P.trip_budget_hard = P.trip_budget;                       /* (a sweep of the one knob means the one budget) */
 	b->class_sort = env_int("NABWA_CLASS_SORT", 1);
 	{
 		P.w_sync = (n > 0 && min_len == max_len) ? env_int("NABWA_W_SYNC", 1) : 0;

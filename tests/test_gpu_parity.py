@@ -181,7 +181,7 @@ def test_wide_pass_is_bit_exact(gix, olib, oix, monkeypatch):
     monkeypatch.delenv("NABWA_ALNCAP1")
     b = nabwa.Batch(gix, to_gap_opt(opt), seq, rseq, off, False)
     b.run()
-    assert b.sync() < 150           # only the reads with > NABWA_CAP1 pushes, > 16 hits or more than NABWA_TRIP_BUDGET trips
+    assert b.sync() < 300           # only the reads with > NABWA_CAP1 pushes, > 16 hits or more trips than the hand-over budget (200 here: most of these reads occur exactly on neither strand)
     assert b.checksum() == cs          # device checksum is independent of which pass produced a row
     assert b.checksum()[1] == sum(len(g) for g in gold)
     b.close()
