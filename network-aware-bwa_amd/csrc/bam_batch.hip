@@ -438,14 +438,49 @@ static void res_give(void *p, size_t bytes)
 	std::lock_guard<std::mutex> lk(g_res_mu);
 	size_t tot = bytes;
 	for (auto &x : g_res_idle) tot += x.second;
-	if (tot > ((size_t)8 << 30) || g_res_idle.size() >= 4) { free(p); return; }
+	if (tot > ((size_t)8 << 30) || g_res_idle.size() >= 12) { free(p); return; }
 	g_res_idle.push_back({ p, bytes });
 }
+
+/* The parsed records of a batch: pooled memory like the other per-batch blocks, constructed and destroyed by all threads (a std::vector of
+ * a million records does both on one thread, zero fill and page faults included: 15 ms of a 60 ms create). */
+struct RecArr {
+	BamRec *p; size_t n, bytes;
+	RecArr() : p(0), n(0), bytes(0) {}
+	~RecArr() { clear(); }
+	RecArr(const RecArr&) = delete;
+	RecArr &operator=(const RecArr&) = delete;
+	bool make(size_t m)
+	{
+		clear();
+		bytes = sizeof(BamRec) * (m ? m : 1);
+		p = (BamRec*)res_take(bytes);
+		if (!p) { bytes = 0; return false; }
+		n = m;
+		BamRec *const q = p;
+		bam_parallel(m, [q](int, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) new (q + i) BamRec(); });
+		return true;
+	}
+	void clear()
+	{
+		if (p) {
+			BamRec *const q = p;
+			bam_parallel(n, [q](int, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) q[i].~BamRec(); });
+			res_give(p, bytes);
+		}
+		p = 0; n = 0; bytes = 0;
+	}
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	BamRec &operator[](size_t i) { return p[i]; }
+	const BamRec &operator[](size_t i) const { return p[i]; }
+	void swap(RecArr &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(bytes, o.bytes); }
+};
 
 struct nabwa_bam_batch {
 	nabwa_index *ix; nabwa_gap_opt_t opt; nabwa_pe_opt_t popt;
 	uint8_t *arena; size_t arena_bytes;            /* where the records' bytes live (pooled like res); declared before rec: it outlives the records */
-	std::vector<BamRec> rec;                       /* in logical-record order: singletons, and pairs as read 1, read 2 */
+	RecArr rec;                                    /* in logical-record order: singletons, and pairs as read 1, read 2 */
 	std::vector<int> kind;                         /* per logical record: 1 or 2 */
 	std::vector<int> first;                        /* per logical record: index of its first read */
 	std::vector<int> rg;                           /* per logical record: its read group, an index into rg_names */
@@ -488,14 +523,17 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 	b->ix = ix; b->opt = *opt; b->popt = *popt; b->phase = 0; b->flags = flags;
 	const bool timing = getenv("NABWA_TIMING") != 0;
 	const double tc0 = bam_now();
-	b->rec.resize(n_rec);
+	std::vector<uint32_t> flag_or;
+	if (!b->rec.make((size_t)n_rec)) { delete b; return nabwa_fail(NABWA_ENOMEM, "out of memory for the records"); }
 	{
 		for (int i = 0; i < n_rec; ++i) if (in_off[i + 1] - in_off[i] < 36 || in_off[i + 1] - in_off[i] > (int64_t)1 << 28) { delete b; return nabwa_fail(NABWA_EINVAL, "malformed BAM record"); }
 		b->arena_bytes = (size_t)(n_rec ? in_off[n_rec] - in_off[0] : 0) + (size_t)n_rec * (REC_ROOM - 36) + 64;
 		b->arena = (uint8_t*)res_take(b->arena_bytes);
 		if (!b->arena) { b->arena_bytes = 0; delete b; return nabwa_fail(NABWA_ENOMEM, "out of memory for the records"); }
 		std::vector<int> bad(bam_threads((size_t)n_rec), 0);
+		flag_or.assign(bam_threads((size_t)n_rec) * 16, 0u);          /* (a line per thread) */
 		bam_parallel((size_t)n_rec, [&](int t, size_t lo, size_t hi) {
+			uint32_t fo = 0;
 			for (size_t i = lo; i < hi; ++i)
 			{
 				/* one pass over a record while it is in the cache: parse, erase_unwanted_tags, bam_get_rg (neither depends on how the records
@@ -505,7 +543,9 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 				if (!erase_tags(r)) { bad[t] = 2; continue; }
 				const auto v = get_rg(r);
 				r.rg_p = v.first; r.rg_n = (uint32_t)v.second;
+				fo |= r.flag;
 			}
+			flag_or[(size_t)t * 16] = fo;
 		});
 		for (int x : bad) if (x) { delete b; return nabwa_fail(NABWA_EINVAL, x == 2 ? "malformed tags in a BAM record" : "malformed BAM record"); }
 	}
@@ -517,7 +557,17 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 	 * (read_bam_pair's ignore_aligned, bwaseqio.c:466-474) leaves out logical records any read of which is already mapped. */
 	{
 		const bool broken = (flags & NABWA_BAM_BROKEN_INPUT) != 0, drop = (flags & NABWA_BAM_DROP_ALIGNED) != 0, nodup = (flags & NABWA_BAM_SKIP_DUPLICATES) != 0;
-		std::vector<int> src; src.reserve(n_rec); b->kind.reserve(n_rec); b->first.reserve(n_rec); b->skip.reserve(n_rec);
+		uint32_t any_flag = 0;
+		for (size_t t = 0; t < flag_or.size(); t += 16) any_flag |= flag_or[t];
+		std::vector<int> src;
+		if (!(any_flag & F_PD) && !drop && !nodup) {
+			/* single-end records only and nothing to leave out: every record is a logical record of its own */
+			b->kind.assign((size_t)n_rec, 1); b->skip.assign((size_t)n_rec, 0); b->first.resize((size_t)n_rec);
+			int *const fp = b->first.data();
+			bam_parallel((size_t)n_rec, [fp](int, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) fp[i] = (int)i; });
+			src.resize((size_t)n_rec);      /* (only its size is looked at) */
+		} else {
+		src.reserve(n_rec); b->kind.reserve(n_rec); b->first.reserve(n_rec); b->skip.reserve(n_rec);
 		for (int i = 0; i < n_rec; ) {
 			BamRec &r0 = b->rec[i];
 			int k = 1;
@@ -547,8 +597,10 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 			}
 			i += k;
 		}
+		}
 		if ((int)src.size() != n_rec) {
-			std::vector<BamRec> kept(src.size());
+			RecArr kept;
+			if (!kept.make(src.size())) { delete b; return nabwa_fail(NABWA_ENOMEM, "out of memory for the records"); }
 			for (size_t t = 0; t < src.size(); ++t) kept[t] = std::move(b->rec[src[t]]);
 			b->rec.swap(kept);
 			n_rec = (int)src.size();
@@ -560,13 +612,18 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 		const size_t nk = b->kind.size();
 		b->rg.resize(nk);
 		std::map<std::string, int> ids;
-		const uint8_t *prev_p = 0; uint32_t prev_n = 0;
+		/* "the same read group as the logical record before" by all threads (the records' bytes are touched there); the names that change, in order, by one */
+		std::vector<uint8_t> same_rg(nk ? nk : 1, 0);
+		bam_parallel(nk, [&](int, size_t lo, size_t hi) {
+			for (size_t k = lo ? lo : 1; k < hi; ++k) {
+				const BamRec &r0 = b->rec[b->first[k]], &rp = b->rec[b->first[k - 1]];
+				same_rg[k] = r0.rg_n == rp.rg_n && !memcmp(r0.rg_p, rp.rg_p, r0.rg_n);
+			}
+		});
 		for (size_t k = 0; k < nk; ++k) {
+			if (same_rg[k]) { b->rg[k] = b->rg[k - 1]; continue; }
 			const BamRec &r0 = b->rec[b->first[k]];
 			const uint8_t *vp = r0.rg_p; const uint32_t vn = r0.rg_n;
-			const bool same = k && vn == prev_n && !memcmp(vp, prev_p, vn);
-			prev_p = vp; prev_n = vn;
-			if (same) { b->rg[k] = b->rg[k - 1]; continue; }
 			auto ins = ids.emplace(std::string((const char*)vp, vn), (int)b->rg_names.size());
 			if (ins.second) b->rg_names.push_back(ins.first->first);
 			b->rg[k] = ins.first->second;
