@@ -500,8 +500,9 @@ struct nabwa_bam_batch {
 };
 
 static const uint8_t nt16_nt4[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };      /* bam_nt16_nt4_table (bwaseqio.c:10) */
-/* the same for the two bases of a byte at once: low byte = the code of the high nibble (the earlier base), high byte = that of the low nibble */
-static const struct Nt16Pair { uint16_t v[256]; Nt16Pair() { for (int x = 0; x < 256; ++x) v[x] = (uint16_t)(nt16_nt4[x >> 4] | nt16_nt4[x & 15] << 8); } uint16_t operator[](uint8_t x) const { return v[x]; } } nt16_pair;
+/* the two bases of a byte at once, as they lie in a REVERSED read (the later base first), plain and complemented: one 16-bit store per strand for two bases */
+static const struct Nt16Rev { uint16_t s[256], r[256]; Nt16Rev() { for (int x = 0; x < 256; ++x) { const uint8_t a = nt16_nt4[x >> 4], b = nt16_nt4[x & 15];
+	s[x] = (uint16_t)(b | a << 8); r[x] = (uint16_t)((b < 4 ? 3 - b : b) | (a < 4 ? 3 - a : a) << 8); } } } nt16_rev;
 
 extern "C" int nabwa_bam_batch_create(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, const nabwa_pe_opt_t *popt, int n_rec,
 									  const uint8_t *in, const int64_t *in_off, nabwa_bam_batch_t **out)
@@ -671,11 +672,10 @@ extern "C" int nabwa_bam_batch_create_ex(nabwa_index_t *ix, const nabwa_gap_opt_
 					/* s[j] = code of base len-1-j; a byte of the record holds bases 2m (high nibble) and 2m+1: both codes from one table look-up,
 					 * written back to front */
 					int k = 0;
-					for (; k + 1 < len; k += 2) {
-						const uint16_t two = nt16_pair[sq[k >> 1]];          /* low byte: base k, high byte: base k+1 */
-						const uint8_t v0 = (uint8_t)two, v1 = (uint8_t)(two >> 8);
-						s[len - 1 - k] = v0; s[len - 2 - k] = v1;
-						r[len - 1 - k] = v0 < 4 ? 3 - v0 : v0; r[len - 2 - k] = v1 < 4 ? 3 - v1 : v1;
+					for (; k + 1 < len; k += 2) {          /* bases k, k + 1 go to places len-1-k, len-2-k: the two bytes at len-2-k, the later base first */
+						const uint8_t x = sq[k >> 1];
+						memcpy(s + (len - 2 - k), &nt16_rev.s[x], 2);
+						memcpy(r + (len - 2 - k), &nt16_rev.r[x], 2);
 					}
 					if (k < len) { const uint8_t v = nt16_nt4[sq[k >> 1] >> 4]; s[len - 1 - k] = v; r[len - 1 - k] = v < 4 ? 3 - v : v; }
 				} else for (int j = 0; j < len; ++j) {

@@ -553,6 +553,10 @@ int nabwa_se_refine_strided(nabwa_index_t *ix, int n, const int64_t *off, const 
 	auto phase4 = [&](int lo, int hi) {
 		std::vector<uint8_t> fwd;
 		for (int i = lo; i < hi; ++i) {
+			/* what a record needs lies far apart -- its head and its MD field in a 3 KB record, its window in 775 MB of packed reference --, and
+			 * every piece was a cache miss in turn: the record 16 ahead and the window of the record 8 ahead are asked for now */
+			if (i + 16 < hi) { const nabwa_se_t *const f = rec_at(out_base, stride, i + 16); __builtin_prefetch(f); __builtin_prefetch(f->md, 1); __builtin_prefetch(&f->flag, 1); }
+			if (i + 8 < hi) { const nabwa_se_t *const f = rec_at(out_base, stride, i + 8); if (f->type) { const uint8_t *const w = R->pac.data() + (f->pos >> 2); __builtin_prefetch(w); __builtin_prefetch(w + 32); } }
 			nabwa_se_t &s = *rec_at(out_base, stride, i);
 			if (s.type == 0) { s.flag = 4; continue; }
 			if (!md_and_trim(R, s, seq + off[i], rseq + off[i], fwd)) md_over = 1;
