@@ -978,6 +978,10 @@ extern "C" int nabwa_bam_batch_pass2(nabwa_bam_batch_t *b, const nabwa_isize_tab
 	const double tq1 = bam_now();
 	bam_parallel(b->kind.size(), [&](int, size_t lo, size_t hi) {
 		for (size_t k = lo; k < hi; ++k) {
+			/* (a record's pieces lie far apart -- its parsed head, the end of its bytes in the arena where the tags go, the head and the MD field of
+			 * its 3 KB working record: asked for ahead, the ones behind a pointer once that pointer is at hand) */
+			if (k + 16 < hi) { const int f = b->first[k + 16]; __builtin_prefetch(&b->rec[f], 1); __builtin_prefetch(&b->res[f].se); __builtin_prefetch(b->res[f].se.md); __builtin_prefetch(&b->res[f].se.flag); }
+			if (k + 8 < hi) { const BamRec &fr = b->rec[b->first[k + 8]]; __builtin_prefetch(fr.data.p + fr.data.n, 1); __builtin_prefetch(fr.data.p + fr.l_qname, 1); }
 			const int i = b->first[k];
 			if (b->skip[k]) continue;
 			const bool dbg = (b->flags & NABWA_BAM_DEBUG) != 0;
@@ -1002,21 +1006,35 @@ extern "C" int nabwa_bam_batch_output(const nabwa_bam_batch_t *b, uint8_t *out, 
 {
 	if (!b || !n_bytes) return nabwa_fail(NABWA_EINVAL, "null argument");
 	const size_t n = b->rec.size();
-	std::vector<int> pick; pick.reserve(n);
-	for (size_t k = 0; k < b->kind.size(); ++k) {
-		const int i = b->first[k];
-		bool keep = true;
-		if ((b->flags & NABWA_BAM_ONLY_ALIGNED) && b->phase == 2) for (int e = 0; e < b->kind[k]; ++e) if (b->rec[i + e].flag & F_SU) keep = false;      /* (before pass 2 the flag is the input's) */
-		if (keep) for (int e = 0; e < b->kind[k]; ++e) pick.push_back(i + e);
+	std::vector<int> pick;
+	if ((b->flags & NABWA_BAM_ONLY_ALIGNED) && b->phase == 2) {
+		pick.reserve(n);
+		for (size_t k = 0; k < b->kind.size(); ++k) {
+			const int i = b->first[k];
+			bool keep = true;
+			for (int e = 0; e < b->kind[k]; ++e) if (b->rec[i + e].flag & F_SU) keep = false;      /* (before pass 2 the flag is the input's) */
+			if (keep) for (int e = 0; e < b->kind[k]; ++e) pick.push_back(i + e);
+		}
+	} else {       /* every record, in the order they lie in (logical records are consecutive) */
+		pick.resize(n);
+		int *const pp = pick.data();
+		bam_parallel(n, [pp](int, size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) pp[t] = (int)t; });
 	}
 	const size_t m = pick.size();
 	std::vector<int64_t> at(n + 1, 0);
-	for (size_t t = 0; t < m; ++t) at[t + 1] = at[t] + 36 + (int64_t)b->rec[pick[t]].data.size();
+	bam_parallel(m, [&](int, size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) at[t + 1] = 36 + (int64_t)b->rec[pick[t]].data.size(); });      /* the sizes by all threads ... */
+	for (size_t t = 0; t < m; ++t) at[t + 1] += at[t];                                                                                                     /* ... their sums by one */
 	for (size_t t = m; t < n; ++t) at[t + 1] = at[m];
 	if (out_off) memcpy(out_off, at.data(), sizeof(int64_t) * (n + 1));
 	*n_bytes = at[m];
 	if (!out || cap < at[m]) return nabwa_fail(NABWA_ECAP, "output buffer too small");
-	bam_parallel(m, [&](int, size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) write_rec(b->rec[pick[t]], out + at[t]); });
+	bam_parallel(m, [&](int, size_t lo, size_t hi) {
+		for (size_t t = lo; t < hi; ++t) {
+			if (t + 8 < hi) { const BamRec &fr = b->rec[pick[t + 8]]; __builtin_prefetch(fr.data.p); __builtin_prefetch(fr.data.p + 64); __builtin_prefetch(fr.data.p + 128); __builtin_prefetch(fr.data.p + 192); }
+			if (t + 16 < hi) __builtin_prefetch(&b->rec[pick[t + 16]]);
+			write_rec(b->rec[pick[t]], out + at[t]);
+		}
+	});
 	return NABWA_OK;
 }
 

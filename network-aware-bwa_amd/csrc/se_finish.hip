@@ -462,6 +462,7 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 			Q.which.reserve((hi - lo) + (hi - lo) / 4); Q.rows.reserve((hi - lo) + (hi - lo) / 4); Q.look_rec.reserve((hi - lo) + (hi - lo) / 4); Q.look_multi.reserve((hi - lo) + (hi - lo) / 4);
 			uint64_t st = slice_state[(size_t)t]; size_t a0 = slice_a0[(size_t)t];
 			for (size_t i = lo; i < hi; ++i) {
+				if (i + 8 < hi) { nabwa_se_t *const f = &out_at(i + 8); __builtin_prefetch(f, 1); __builtin_prefetch(&f->nm, 1); __builtin_prefetch(&f->n_multi, 1); __builtin_prefetch(&f->flag, 1); }      /* (the fields written below, in a 3 KB record) */
 				nabwa_se_t &s = out_at(i);
 				memset(&s, 0, offsetof(nabwa_se_t, cigar));          /* the scalar head; arrays are only valid up to their counts */
 				s.n_cigar = 0; s.nm = 0; s.md[0] = 0; s.n_multi = 0; s.flag = 0; s.seqid = 0; s.nn = 0; s.rpos = 0; s.xt = 0;
@@ -509,11 +510,12 @@ static int se_posn_impl(nabwa_index_t *ix, const nabwa_gap_opt_t *opt, int n, co
 	});
 	/* bwa_approx_mapQ (bwase.c:113-122); max_diff of a read follows from its length: one table instead of a Poisson sum per read */
 	int longest = 0;
-	for (int i = 0; i < n; ++i) if (out_at(i).len > longest) longest = out_at(i).len;
+	for (int i = 0; i < n; ++i) if ((int)(off[i + 1] - off[i]) > longest) longest = (int)(off[i + 1] - off[i]);      /* (= the records' len, without touching a million records on one thread) */
 	std::vector<int> md_of(longest + 1, opt->max_diff);
 	if (opt->fnr > 0.0f) for (int L = 0; L <= longest; ++L) md_of[L] = nabwa_cal_maxdiff(L, 0.02, opt->fnr);
 	in_threads(nt, (size_t)n, [&](size_t lo, size_t hi) {
 		for (size_t i = lo; i < hi; ++i) {
+			if (i + 8 < hi) __builtin_prefetch(&out_at(i + 8), 1);
 			nabwa_se_t &s = out_at(i);
 			if (s.type == 0) continue;
 			const int q = approx_mapq(s, md_of[s.len]);
