@@ -289,17 +289,31 @@ static std::pair<const uint8_t*, size_t> get_rg(const BamRec &r)       /* a view
 static inline int nib4(uint8_t v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }   /* complement of a 4-bit base code = its bits reversed */
 
 /* revcom_bam1 (bam2bam.c:335-362): flip the strand flag, reverse-complement SEQ, reverse QUAL */
+/* both nibbles of a byte complemented (nib4), in place and swapped */
+static const struct NibComp { uint8_t same[256], swap[256]; NibComp() { for (int x = 0; x < 256; ++x) { const int hi = nib4((uint8_t)(x >> 4)), lo = nib4((uint8_t)(x & 15));
+	same[x] = (uint8_t)(hi << 4 | lo); swap[x] = (uint8_t)(lo << 4 | hi); } } } nib_comp;
+
 static void revcom_rec(BamRec &r)
 {
 	r.flag ^= F_SR;
 	const int L = r.l_qseq;
 	uint8_t *s = r.data.data() + r.off_seq(), *q = r.data.data() + r.off_qual();
-	uint8_t small[512]; std::vector<uint8_t> big;
-	uint8_t *codes = small;
-	if (L > (int)sizeof(small)) { big.resize(L); codes = big.data(); }
-	for (int i = 0; i < L; ++i) codes[i] = (uint8_t)(s[i >> 1] >> ((~i & 1) << 2) & 15);
-	memset(s, 0, ((size_t)L + 1) / 2);
-	for (int i = 0; i < L; ++i) s[i >> 1] |= (uint8_t)(nib4(codes[L - 1 - i]) << ((~i & 1) << 2));
+	/* byte by byte: with an even number of bases the bytes change places and their nibbles with them; with an odd number every byte of the
+	 * result is put together from two neighbours (base L-1 sits alone in the top of the last byte, and the new last byte ends in a zero nibble) */
+	const int nb = (L + 1) / 2;
+	if (!(L & 1)) {
+		int a = 0, b = nb - 1;
+		for (; a < b; ++a, --b) { const uint8_t x = nib_comp.swap[s[a]], y = nib_comp.swap[s[b]]; s[a] = y; s[b] = x; }
+		if (a == b) s[a] = nib_comp.swap[s[a]];
+	} else if (nb) {
+		uint8_t small[256]; std::vector<uint8_t> big;
+		uint8_t *c = small;
+		if (nb > (int)sizeof(small)) { big.resize((size_t)nb); c = big.data(); }
+		for (int j = 0; j < nb; ++j) c[j] = nib_comp.same[s[j]];
+		const int m = nb - 1;
+		for (int j = 0; j < m; ++j) s[j] = (uint8_t)((c[m - j] & 0xF0) | (c[m - j - 1] & 0x0F));
+		s[m] = (uint8_t)(c[0] & 0xF0);
+	}
 	for (int a = 0, b = L - 1; a < b; ++a, --b) { const uint8_t t = q[a]; q[a] = q[b]; q[b] = t; }
 }
 
@@ -401,11 +415,26 @@ static void write_rec(const BamRec &r, uint8_t *o)
 
 /* ------------------------------------------------------------------ the batch */
 
-struct RawBytes {          /* bytes without the zero fill of std::vector (100 MB per million reads, written once by many threads) */
-	uint8_t *p; size_t n;
-	RawBytes() : p(0), n(0) {}
-	~RawBytes() { free(p); }
-	bool alloc(size_t m) { free(p); p = (uint8_t*)malloc(m ? m : 1); n = m; return p != 0; }
+
+static void *res_take(size_t bytes);
+static void res_give(void *p, size_t bytes);
+struct RawBytes {          /* bytes without the zero fill of std::vector (100 MB per million reads, written once by many threads); large blocks come from
+                            * and go back to the pool of per-batch blocks below: no page faults, no unmapping from batch to batch */
+	uint8_t *p; size_t n, cap; bool pooled;
+	RawBytes() : p(0), n(0), cap(0), pooled(false) {}
+	~RawBytes() { drop(); }
+	RawBytes(const RawBytes&) = delete;
+	RawBytes &operator=(const RawBytes&) = delete;
+	void drop() { if (p) { if (pooled) res_give(p, cap); else free(p); } p = 0; n = cap = 0; pooled = false; }
+	bool alloc(size_t m)
+	{
+		drop();
+		cap = m ? m : 1; pooled = cap >= ((size_t)1 << 20);
+		p = (uint8_t*)(pooled ? res_take(cap) : malloc(cap));
+		n = m;
+		if (!p) { cap = 0; pooled = false; }
+		return p != 0;
+	}
 	uint8_t *data() { return p; }
 	const uint8_t *data() const { return p; }
 	const uint8_t *begin() const { return p; }
