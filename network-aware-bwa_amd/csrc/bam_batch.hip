@@ -506,6 +506,17 @@ struct RecArr {
 	void swap(RecArr &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(bytes, o.bytes); }
 };
 
+/* hit rows as they come back from the device: no zero fill on one thread in front of the copy (a std::vector's resize), pooled like the rest.
+ * Growing it loses what it held (every caller fills it whole afterwards); shrinking keeps it. */
+struct RowArr {
+	RawBytes raw; size_t n;
+	RowArr() : n(0) {}
+	bool resize(size_t m) { if (m * sizeof(nabwa_aln1_t) > raw.cap) { if (!raw.alloc(m * sizeof(nabwa_aln1_t))) { n = 0; return false; } } n = m; return true; }
+	size_t size() const { return n; }
+	nabwa_aln1_t *data() { return (nabwa_aln1_t*)raw.p; }
+	const nabwa_aln1_t *data() const { return (const nabwa_aln1_t*)raw.p; }
+};
+
 struct nabwa_bam_batch {
 	nabwa_index *ix; nabwa_gap_opt_t opt; nabwa_pe_opt_t popt;
 	uint8_t *arena; size_t arena_bytes;            /* where the records' bytes live (pooled like res); declared before rec: it outlives the records */
@@ -517,7 +528,7 @@ struct nabwa_bam_batch {
 	std::vector<uint8_t> skip;                     /* per logical record: a flagged duplicate that passes through untouched (--skip-duplicates; unique(), bam2bam.c:595-606) */
 	uint32_t flags;                                /* NABWA_BAM_* */
 	std::vector<int64_t> off; RawBytes seq, rseq; std::vector<int32_t> full_len;     /* the encoded reads, one per BAM record */
-	std::vector<int32_t> n_aln, max_ent; std::vector<nabwa_aln1_t> rows; std::vector<int64_t> row0;
+	std::vector<int32_t> n_aln, max_ent; RowArr rows; std::vector<int64_t> row0;
 	nabwa_pe_t *res;                               /* per read: the chain's record (singletons use .se only); raw memory: only what a phase fills is valid */
 	int phase;                                     /* 0 created, 1 positioned, 2 finished */
 	bool searched;                                 /* nabwa_bam_batch_search ran */
@@ -783,13 +794,13 @@ extern "C" int nabwa_bam_batch_search(nabwa_bam_batch_t *b)
 	if (rc == NABWA_OK) rc = nabwa_batch_sync(sb, 0);
 	if (rc == NABWA_OK) {
 		/* one fetch where the rows fit a guess (most reads bring one row), a second one where they do not */
-		b->rows.resize((size_t)n + (size_t)n / 4 + 1024);
+		if (!b->rows.resize((size_t)n + (size_t)n / 4 + 1024)) { nabwa_batch_destroy(sb); return nabwa_fail(NABWA_ENOMEM, "out of memory for the hit rows"); }
 		rc = nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), (int64_t)b->rows.size(), &n_rows, b->max_ent.data());
 		if (rc == NABWA_ECAP && n_rows > (int64_t)b->rows.size()) {
-			b->rows.resize((size_t)n_rows);
+			if (!b->rows.resize((size_t)n_rows)) { nabwa_batch_destroy(sb); return nabwa_fail(NABWA_ENOMEM, "out of memory for the hit rows"); }
 			rc = nabwa_batch_fetch(sb, b->n_aln.data(), b->rows.data(), n_rows, &n_rows, b->max_ent.data());
 		}
-		if (rc == NABWA_OK) b->rows.resize(n_rows ? (size_t)n_rows : 1);
+		if (rc == NABWA_OK) (void)b->rows.resize(n_rows ? (size_t)n_rows : 1);
 	}
 	nabwa_batch_destroy(sb);
 	if (rc == NABWA_OK) b->searched = true;
@@ -886,7 +897,7 @@ extern "C" int nabwa_bam_batch_restore(nabwa_bam_batch_t *b, const nabwa_wire_re
 		if ((int64_t)w.len != b->off[i + 1] - b->off[i]) { char m[160]; snprintf(m, sizeof m, "record %d: positioned with a length of %d, the batch has %lld (other trimming options?)", i, w.len, (long long)(b->off[i + 1] - b->off[i])); return nabwa_fail(NABWA_EINVAL, "%s", m); }
 		b->n_aln[i] = w.n_aln; b->max_ent[i] = w.max_entries; b->row0[i + 1] = b->row0[i] + w.n_aln;
 	}
-	b->rows.resize(b->row0[n] ? (size_t)b->row0[n] : 1);
+	if (!b->rows.resize(b->row0[n] ? (size_t)b->row0[n] : 1)) return nabwa_fail(NABWA_ENOMEM, "out of memory for the hit rows");
 	res_give(b->res, b->res_bytes);
 	b->res_bytes = sizeof(nabwa_pe_t) * (size_t)(n ? n : 1);
 	b->res = (nabwa_pe_t*)res_take(b->res_bytes);
