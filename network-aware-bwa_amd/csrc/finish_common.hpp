@@ -291,7 +291,15 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 		for (size_t t = lo_t; t < hi_t; ++t) {
 			const RefineJob &J = jobs[t];
 			uint8_t *rb = rbuf.data() + ro[t], *qb = qbuf.data() + qo[t];
-			for (int k = 0; k < J.win_n; ++k) rb[k] = (uint8_t)pac_at(R, J.win_lo + k);
+			if (t + 8 < hi_t) { const RefineJob &F = jobs[t + 8]; const uint8_t *const w = R->pac.data() + (F.win_lo >> 2); __builtin_prefetch(w); __builtin_prefetch(w + 48); __builtin_prefetch((F.strand ? rseq : seq) + off[F.rec]); }
+			{	/* the window out of the packed reference: four bases per byte of it through a table */
+				static const struct Pac4 { uint32_t v[256]; Pac4() { for (int x = 0; x < 256; ++x) v[x] = (uint32_t)(x >> 6 & 3) | (uint32_t)(x >> 4 & 3) << 8 | (uint32_t)(x >> 2 & 3) << 16 | (uint32_t)(x & 3) << 24; } } pac4;
+				int k = 0; int64_t g = J.win_lo;
+				for (; k < J.win_n && (g & 3); ++k, ++g) rb[k] = (uint8_t)pac_at(R, g);
+				const uint8_t *pb = R->pac.data() + (g >> 2);
+				for (; k + 4 <= J.win_n; k += 4, g += 4, ++pb) memcpy(rb + k, &pac4.v[*pb], 4);
+				for (; k < J.win_n; ++k, ++g) rb[k] = (uint8_t)pac_at(R, g);
+			}
 			/* query in alignment orientation: reverse strand = rseq, forward = the read itself (seq is stored reversed) */
 			const uint8_t *src = (J.strand ? rseq : seq) + off[J.rec];
 			if (J.strand) memcpy(qb, src, (size_t)J.len);

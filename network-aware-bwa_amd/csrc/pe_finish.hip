@@ -434,6 +434,10 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	auto phaseE = [&](int lo, int hi) {
 		std::vector<uint8_t> fwd;
 		for (int pr = lo; pr < hi; ++pr) {
+			/* (the pieces of a record lie far apart -- head, MD field and tail of a 3 KB record, its window in the packed reference: asked for ahead,
+			 * as in se_finish.hip) */
+			if (pr + 8 < hi) for (int j = 0; j < 2; ++j) { const nabwa_pe_t *const f = &PE(out, pr + 8, j); __builtin_prefetch(f, 1); __builtin_prefetch(f->se.md, 1); __builtin_prefetch(&f->se.flag, 1); __builtin_prefetch(&f->extra_flag, 1); }
+			if (pr + 4 < hi) for (int j = 0; j < 2; ++j) { const nabwa_se_t &f = PE(out, pr + 4, j).se; if (f.type) { const uint8_t *const w = R->pac.data() + (f.pos >> 2); __builtin_prefetch(w); __builtin_prefetch(w + 32); } }
 			for (int j = 0; j < 2; ++j) {
 				nabwa_se_t &s = PE(out, pr, j).se;
 				if (s.type != 0 && !md_and_trim(R, s, seq + off[2 * pr + j], rseq + off[2 * pr + j], fwd)) md_over = 1;
