@@ -284,8 +284,11 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 		ro[t + 1] = ro[t] + J.win_n; qo[t + 1] = qo[t] + J.len;
 	}
 	/* (no zero fill: every byte that is read is written first -- 100 MB of it for 181 k jobs with the CIGAR rows below) */
-	std::unique_ptr<uint8_t[]> rbuf_p(new uint8_t[(size_t)ro[nj] + 1]), qbuf_p(new uint8_t[(size_t)qo[nj] + 1]);
-	struct { uint8_t *p; uint8_t *data() const { return p; } } rbuf{ rbuf_p.get() }, qbuf{ qbuf_p.get() };
+	/* (and no fresh memory either: the three big blocks of a call -- windows, reads, CIGAR rows, 100 MB for 181 k jobs -- stay with the calling thread
+	 * for its next batch; mapping, faulting in and unmapping them anew every call cost as much as cutting the windows) */
+	struct Scratch { std::unique_ptr<uint8_t[]> p; size_t cap = 0; uint8_t *get(size_t m) { if (m > cap) { p.reset(); p.reset(new uint8_t[m + m / 4]); cap = m + m / 4; } return p.get(); } };
+	static thread_local Scratch scr_r, scr_q, scr_c;
+	struct { uint8_t *p; uint8_t *data() const { return p; } } rbuf{ scr_r.get((size_t)ro[nj] + 1) }, qbuf{ scr_q.get((size_t)qo[nj] + 1) };
 	rbuf.p[ro[nj]] = 0; qbuf.p[qo[nj]] = 0;
 	fin_parallel(ntj, nj, [&](int, size_t lo_t, size_t hi_t) {
 		for (size_t t = lo_t; t < hi_t; ++t) {
@@ -309,7 +312,7 @@ static inline int refine_batch(nabwa_index_t *ix, void *base, size_t stride, int
 	const double tr1 = fin_now();
 	const int MAXC = NABWA_MAX_CIGAR;
 	std::vector<int32_t> sc(nj), nc(nj);
-	std::unique_ptr<uint32_t[]> c32(new uint32_t[nj * (size_t)MAXC]);      /* row t: its first nc[t] words are valid */
+	struct { uint32_t *p; uint32_t *get() const { return p; } uint32_t &operator[](size_t i) const { return p[i]; } } c32{ (uint32_t*)scr_c.get(nj * (size_t)MAXC * 4) };      /* row t: its first nc[t] words are valid */
 	int r = nabwa_global_align(ix->device, (int)nj, ro.data(), rbuf.data(), qo.data(), qbuf.data(), 26, 9, 5, maq, 50,
 							   sc.data(), nc.data(), c32.get(), MAXC);                       /* aln_param_bwa, stdaln.c:227 */
 	if (r != NABWA_OK) return r;
