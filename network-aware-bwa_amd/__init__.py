@@ -516,17 +516,25 @@ class Batch:
         bounds = np.concatenate([[0], np.cumsum(n_aln)])
         return [buf[bounds[i]:bounds[i + 1]] for i in range(self.n)], maxe[:self.n]
 
-    def fetch_flat(self):
-        """-> (n_aln per read, all rows back to back, max_entries per read)"""
-        n_aln = np.zeros(max(self.n, 1), np.int32)
-        maxe = np.zeros(max(self.n, 1), np.int32)
+    def fetch_flat(self, keep=None):
+        """-> (n_aln per read, all rows back to back, max_entries per read).  keep: a dict the caller holds from batch to batch -- the three
+        arrays live in it and are used again (a streaming caller's buffers: no fresh pages per batch, one fetch where the rows fit)"""
+        if keep is not None and "n_aln" in keep and len(keep["n_aln"]) >= max(self.n, 1):
+            n_aln, maxe, buf = keep["n_aln"], keep["maxe"], keep["rows"]
+        else:
+            n_aln = np.zeros(max(self.n, 1), np.int32)
+            maxe = np.zeros(max(self.n, 1), np.int32)
+            buf = None
         rows = C.c_int64()
-        rc = lib().nabwa_batch_fetch(self._h, _ptr(n_aln), None, 0, C.byref(rows), _ptr(maxe))
+        rc = lib().nabwa_batch_fetch(self._h, _ptr(n_aln), _ptr(buf) if buf is not None else None, len(buf) if buf is not None else 0, C.byref(rows), _ptr(maxe))
         if rc not in (OK, ECAP):
             _chk(rc)
-        buf = np.zeros(max(rows.value, 1), ALN_DT)
-        if rows.value:
-            _chk(lib().nabwa_batch_fetch(self._h, _ptr(n_aln), _ptr(buf), rows.value, C.byref(rows), _ptr(maxe)))
+        if rc == ECAP or buf is None:
+            buf = np.zeros(max(rows.value + rows.value // 8, 1), ALN_DT)
+            if rows.value:
+                _chk(lib().nabwa_batch_fetch(self._h, _ptr(n_aln), _ptr(buf), len(buf), C.byref(rows), _ptr(maxe)))
+        if keep is not None:
+            keep["n_aln"], keep["maxe"], keep["rows"] = n_aln, maxe, buf
         return n_aln[:self.n], buf[:rows.value], maxe[:self.n]
 
     def close(self):
