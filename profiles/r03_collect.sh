@@ -25,6 +25,15 @@ pmc() {   # name, counter groups..., then -- bench args
     NABWA_BENCH_QUICK=1 timeout -k 10 600 rocprofv3 --pmc $g -d "$d" -o run --output-format csv -- python3 bench.py --extras off --no-cpu --no-e2e --steps 1 --warmup 0 "$@" > "$d.json" 2> "$d.err" || echo "group '$g' of $name failed (see $d.err)"
   done
   python3 profiles/summarize_pmc.py $O/pmc_$name > $O/pmc_$name.json
+  # the launch size the pass was taken at and its dominant kernel: bench.py quotes a pass only for the same size (tests/test_profiles.py)
+  python3 - "$O/pmc_$name.json" "$name" <<'PY'
+import json, sys
+p, name = sys.argv[1], sys.argv[2]
+d = json.load(open(p))
+d["units"], d["dominant"] = {"headline": (10_000_000, "S"), "adna": (6_250_000, "D"), "pe": (1_000_000, "D"), "repeats": (10_000_000, "D")}[name]
+d["what"] = "rocprofv3 --pmc passes (profiles/r03_collect.sh pmc) of bench.py --extras off at the size of the driver line; per-launch means of the first-pass launches"
+json.dump(d, open(p, "w"), indent=1)
+PY
   echo "pmc $name:"; cat $O/pmc_$name.json
 }
 if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
