@@ -153,7 +153,8 @@ __global__ __launch_bounds__(NABWA_SEARCH_BLOCK, NABWA_W_WAVES) void fm_width_ke
 					len = P.rd_len[rid];
 					sq_off = (uint32_t)o;
 					nN = 0; stag = -1;
-					if (len > 0) {
+					if (P.w_skip_clean && P.n_aln[rid] == 0) { /* its record is as the first run of this kernel left it */ }
+					else if (len > 0) {
 						run = true; phase = 0; wi = 0; n = len; sbase = 0; tmode = false;
 						if (KT) { wkey = P.rd_key[6 * (size_t)rid + 2 + x]; tok = wkey != 0xffffffffu; }
 						tbase = 0;

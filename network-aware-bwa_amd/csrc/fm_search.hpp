@@ -46,6 +46,7 @@ struct SearchParams {
 	int sync_refill;                          // experiment knob (NABWA_SYNC_REFILL): every wave refills only when all its lanes are idle
 	const uint32_t *rd_pack; int pack_stride;  // both strands of every read 2 bits per base (pad_reads_kernel); words per read
 	int w_sync;                               // kernel W: lockstep waves (all reads of the batch have one length)
+	int w_skip_clean;                         // kernel W run again over the reads kernel S handed on: a search that found no hit has not edited its record (gap_shadow, bwtgap.c:81-91) -- n_aln[read] == 0: nothing to rebuild
 	uint8_t *rd_cls;                          // kernel W -> partition: per strand the restarts of its width pass, clipped to 4
 	const unsigned int *n_sync;               // work items from *n_sync on are class-0 reads: their waves run in lockstep (see fm_search_kernel, partition_kernel)
 	unsigned long long *touch_counter;        // non-null: also count the reference algorithm's bucket touches

@@ -755,8 +755,11 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 	unsigned int cur = novf;
 	b->deep_ran = 0; b->last_ms_deep = 0.f;
 	// the kernel-W records of the listed reads again: a search edits them in place (gap_shadow)
-	auto rebuild_widths = [&](const SearchParams &Q, unsigned int cnt) {
+	auto rebuild_widths = [&](const SearchParams &Q, unsigned int cnt, bool after_first_pass) {
 		SearchParams QW = Q; QW.touch_counter = 0; QW.rd_cls = 0; QW.n_sync = 0; QW.w_sync = 0;
+		/* only a search that found a hit has edited its record; after kernel D has had a read (the guaranteed pass, the searches with longer
+		 * hit lists) its record is rebuilt whatever it found */
+		QW.w_skip_clean = after_first_pass && env_int("NABWA_W_SKIP_CLEAN", 1) ? 1 : 0;
 		QW.n_aln = b->d_naln; QW.max_ent = b->d_maxent; QW.status = b->d_status; QW.aln = b->d_aln; QW.aln_cap = b->P.aln_cap;
 		long bw2 = (2 * (long)cnt + NABWA_SEARCH_BLOCK - 1) / NABWA_SEARCH_BLOCK;     /* one lane per strand */
 		if (bw2 > b->n_blocks_w) bw2 = b->n_blocks_w;
@@ -785,7 +788,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			b->scratch2_bytes = need;
 		}
 		Q.scratch = b->d_scratch2; Q.ids = b->d_ovf_ids; Q.n = (int)cur; Q.n_sync = 0; Q.w_sync = 0;
-		rebuild_widths(Q, cur);
+		rebuild_widths(Q, cur, false);
 		HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 		nabwa_launch_fm_search(&Q, (int)blocks, b->stream);
 		HIPCHK(hipGetLastError());
@@ -920,7 +923,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			}
 			if (waves > (long)todo) waves = (long)todo;
 			D.S.n = (int)todo; D.own_cap = (uint32_t)own_cap;
-			rebuild_widths(D.S, todo);
+			rebuild_widths(D.S, todo, pass == 0);
 			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 1024, b->stream));
 			D.S.work_counter = b->d_counter;
@@ -1007,7 +1010,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 			if (waves > n_waves) waves = n_waves;
 			if (waves > (long)n_hit) waves = (long)n_hit;
 			G.S.n = (int)n_hit; G.own_cap = (uint32_t)cap_pages;
-			rebuild_widths(G.S, n_hit);
+			rebuild_widths(G.S, n_hit, false);
 			HIPCHK(hipMemsetAsync(b->d_counter, 0, 16, b->stream));
 			HIPCHK(hipMemsetAsync(b->d_deep_ctr, 0, 1024, b->stream));
 			G.S.work_counter = b->d_counter;
