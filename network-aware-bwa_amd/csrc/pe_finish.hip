@@ -140,6 +140,7 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 	std::vector<uint32_t> prow((size_t)(n_pairs ? n_pairs : 1), 0);
 	fin_parallel(fin_threads((size_t)n_pairs), (size_t)n_pairs, [&](int, size_t p_lo, size_t p_hi) {
 		for (size_t pr = p_lo; pr < p_hi; ++pr) {
+			if (pr + 8 < p_hi) { __builtin_prefetch(&PE(out, (int)pr + 8, 0)); __builtin_prefetch(&PE(out, (int)pr + 8, 1)); }      /* (3 KB records: the next ones asked for ahead) */
 			uint32_t rows_here = 0;
 			if (pair_is_enumerated(PE(out, pr, 0).se, PE(out, pr, 1).se, aln + a_off[2 * pr], n_aln[2 * pr], aln + a_off[2 * pr + 1], n_aln[2 * pr + 1], popt->max_occ, &rows_here))
 				prow[pr] = rows_here;
@@ -204,6 +205,7 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 		fin_parallel(fin_threads(pairs.size()), pairs.size(), [&](int, size_t t_lo, size_t t_hi) {      /* pairs are independent of each other */
 		std::vector<uint64_t> hits;
 		for (size_t t = t_lo; t < t_hi; ++t) {
+			if (t + 8 < t_hi) { const int f = pairs[t + 8]; __builtin_prefetch(&PE(out, f, 0), 1); __builtin_prefetch(&PE(out, f, 1), 1); }
 			const int pr = pairs[t];
 			hits.clear();
 			size_t u = pair_lo[t];
@@ -247,6 +249,7 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 		std::vector<uint8_t> &which = M.which; std::vector<uint32_t> &rows = M.rows; std::vector<int> &look_rec = M.look_rec, &look_multi = M.look_multi;
 		for (int pr = (int)p_lo; pr < (int)p_hi; ++pr)
 			for (int j = 0; j < 2; ++j) {
+				if (j == 0 && pr + 8 < (int)p_hi) for (int e = 0; e < 2; ++e) { const nabwa_pe_t *const f = &PE(out, pr + 8, e); __builtin_prefetch(f, 1); __builtin_prefetch(&f->se.n_multi, 1); __builtin_prefetch(&f->extra_flag); }
 				nabwa_pe_t &r = PE(out, pr, j); nabwa_se_t &s = r.se;
 				s.n_multi = 0;
 				if (s.type == 0) continue;
@@ -286,6 +289,7 @@ extern "C" int nabwa_pe_finish_cached(nabwa_index_t *ix, const nabwa_gap_opt_t *
 			std::vector<uint64_t> tot0((size_t)ntc, 0), tot1((size_t)ntc, 0);
 			fin_parallel(ntc, (size_t)n_pairs, [&](int slice, size_t p_lo, size_t p_hi) {
 				for (int pr = (int)p_lo; pr < (int)p_hi; ++pr) {
+					if (pr + 8 < (int)p_hi) for (int e = 0; e < 2; ++e) { const nabwa_pe_t *const f = &PE(out, pr + 8, e); __builtin_prefetch(f); __builtin_prefetch(&f->extra_flag); }
 					const nabwa_pe_t &r0 = PE(out, pr, 0), &r1 = PE(out, pr, 1);
 					if (!((r0.se.mapQ >= SW_MIN_MAPQ || r1.se.mapQ >= SW_MIN_MAPQ) && (r0.extra_flag & F_PP) == 0)) continue;
 					const int single = (r0.se.type == 0 || r1.se.type == 0) ? 1 : 0;
