@@ -466,6 +466,85 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
     dt, ob, oo, nb = once(ob, oo)           # what a streaming caller sees from then on
     barrier(ctx)
     elapsed = max_over_ranks(ctx, time.time() - t0)
+
+    def streamed(n_batches):
+        """the same batch n_batches times through the four calls as a stream: create | pass 1 | pass 2 | output + destroy, a thread each (ctypes
+        releases the interpreter lock), batches in order through every stage -- pass 1 on the one drand48 stream in input order, as nabwa_bam2bam
+        runs it; for single-end records pass 2 needs nothing of later batches, so it may run beside the next batch's pass 1.  While a batch's
+        search runs on the GPU the host threads work on its neighbours."""
+        import queue
+        import threading
+        q1, q2, q3 = queue.Queue(2), queue.Queue(2), queue.Queue(2)
+        tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
+        st = C.c_uint64(nabwa.srand48_state(11))
+        outs = [(np.zeros(len(ob), np.uint8), np.zeros(n_e + 1, np.int64)) for _ in range(2)]
+        for o in outs:
+            o[0][:] = 1                     # (touched: a streaming caller's buffers are)
+        err = []
+
+        def s_create():
+            for _ in range(n_batches):
+                h = P()
+                if Lb.nabwa_bam_batch_create(ix._h, C.byref(opt), C.byref(po), n_e, T.ptr(buf), T.ptr(boff), C.byref(h)) != 0:
+                    err.append(Lb.nabwa_last_error())
+                    h = None
+                q1.put(h)
+                if h is None:
+                    return
+            q1.put(None)
+
+        def s_pass1():
+            while True:
+                h = q1.get()
+                st.value = nabwa.srand48_state(11)          # (every batch of the stream is the same batch: the same draws, the same bytes -- checked below)
+                if h is not None and Lb.nabwa_bam_batch_pass1(h, C.byref(st), tab) != 0:
+                    err.append(Lb.nabwa_last_error())
+                q2.put(h)
+                if h is None:
+                    return
+
+        def s_pass2():
+            while True:
+                h = q2.get()
+                if h is not None:
+                    tot, mp = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+                    if Lb.nabwa_bam_batch_pass2(h, tab, tot, mp) != 0:
+                        err.append(Lb.nabwa_last_error())
+                q3.put(h)
+                if h is None:
+                    return
+
+        def s_out():
+            k = 0
+            while True:
+                h = q3.get()
+                if h is None:
+                    return
+                o_b, o_o = outs[k & 1]
+                nbk = C.c_int64()
+                if Lb.nabwa_bam_batch_output(h, T.ptr(o_b), len(o_b), T.ptr(o_o), C.byref(nbk)) != 0:
+                    err.append(Lb.nabwa_last_error())
+                Lb.nabwa_bam_batch_destroy(h)
+                k += 1
+
+        th = [threading.Thread(target=f) for f in (s_create, s_pass1, s_pass2, s_out)]
+        t_s = time.time()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        t_s = time.time() - t_s
+        Lb.nabwa_isize_table_destroy(tab)
+        assert not err, err[:2]
+        return t_s, outs
+
+    n_stream = int(os.environ.get("NABWA_BENCH_E2E_BATCHES", "8"))
+    streamed(2)                                 # (the pool of per-batch blocks grows to what four batches in flight need)
+    barrier(ctx)
+    t_stream, outs = streamed(n_stream)
+    barrier(ctx)
+    t_stream = max_over_ranks(ctx, t_stream)
+    stream_same = bool(np.array_equal(outs[(n_stream - 1) & 1][0][:nb.value], ob[:nb.value]))      # the last batch of the stream = the one-batch run's bytes
     if ctx.rank != 0:
         return None
     exact, n_chk, cpu = None, 0, None
@@ -525,6 +604,9 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
                 cpu = None
     return {"what": "unaligned BAM records in host memory -> aligned BAM records in host memory (nabwa_bam_batch_*: the whole of bam2bam's two passes for single-end records, without BGZF)",
             "reads": n_e, "n_gpus": ctx.world, "reads_per_s": round(n_e * ctx.world / elapsed, 1), "first_batch_reads_per_s": round(n_e / dt_first.sum(), 1), "bam_bytes_out": int(nb.value),
+            "streamed_reads_per_s": round(n_e * n_stream * ctx.world / t_stream, 1),
+            "streamed": "%d batches of %d records through create | pass 1 | pass 2 | output + destroy as a four-thread pipeline over the same calls (what nabwa_bam2bam does around them, "
+                        "without BGZF); reads_per_s is ONE batch through the four calls one after the other; the stream's last batch has the one-batch run's bytes: %s" % (n_stream, n_e, stream_same),
             "stage_ms": {"parse + erase tags + bam1_to_seq": round(dt[0] * 1e3, 1), "pass 1: search (upload, kernels W / S / D, rows back) + posn_singleton": round(dt[1] * 1e3, 1),
                          "pass 2: bwa_refine_gapped + MD/NM + bwa_update_bam1": round(dt[2] * 1e3, 1), "records out": round(dt[3] * 1e3, 1)},
             "bit_exact_vs_reference_sample": exact, "sample_reads": n_chk,
