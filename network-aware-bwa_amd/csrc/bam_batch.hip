@@ -442,7 +442,7 @@ struct RawBytes {          /* bytes without the zero fill of std::vector (100 MB
 
 /* The per-read records of a batch (3 KB each: they end in fixed CIGAR / MD / multi-hit arrays) are never filled whole, but fresh
  * memory costs a page fault per record (0.4 s per million).  A streaming caller makes one batch after the other: the buffer of a
- * destroyed batch is kept (up to 8 GB) and handed to the next one. */
+ * destroyed batch is kept (up to 16 GB) and handed to the next one. */
 static std::mutex g_res_mu;
 static std::vector<std::pair<void*, size_t>> g_res_idle;
 static void *res_take(size_t bytes)
@@ -467,7 +467,7 @@ static void res_give(void *p, size_t bytes)
 	std::lock_guard<std::mutex> lk(g_res_mu);
 	size_t tot = bytes;
 	for (auto &x : g_res_idle) tot += x.second;
-	if (tot > ((size_t)8 << 30) || g_res_idle.size() >= 12) { free(p); return; }
+	if (tot > ((size_t)16 << 30) || g_res_idle.size() >= 24) { free(p); return; }      /* (a pipeline holds four batches: two 3 GB record blocks and a dozen smaller ones come and go) */
 	g_res_idle.push_back({ p, bytes });
 }
 
