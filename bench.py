@@ -430,6 +430,7 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
     Lb.nabwa_isize_table_create.argtypes = [C.c_double, C.c_int64]
     Lb.nabwa_bam_batch_create.argtypes = [P, P, P, C.c_int, P, P, P]
     Lb.nabwa_bam_batch_pass1.argtypes = [P, P, P]
+    Lb.nabwa_bam_batch_search.argtypes = [P]
     Lb.nabwa_bam_batch_pass2.argtypes = [P, P, P, P]
     Lb.nabwa_bam_batch_output.argtypes = [P, P, C.c_int64, P, P]
     Lb.nabwa_bam_batch_destroy.argtypes = [P]
@@ -468,13 +469,13 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
     elapsed = max_over_ranks(ctx, time.time() - t0)
 
     def streamed(n_batches):
-        """the same batch n_batches times through the four calls as a stream: create | pass 1 | pass 2 | output + destroy, a thread each (ctypes
+        """the same batch n_batches times through the calls as a stream: create | search | pass 1 | pass 2 | output + destroy, a thread each (ctypes
         releases the interpreter lock), batches in order through every stage -- pass 1 on the one drand48 stream in input order, as nabwa_bam2bam
         runs it; for single-end records pass 2 needs nothing of later batches, so it may run beside the next batch's pass 1.  While a batch's
         search runs on the GPU the host threads work on its neighbours."""
         import queue
         import threading
-        q1, q2, q3 = queue.Queue(2), queue.Queue(2), queue.Queue(2)
+        q0, q1, q2, q3 = queue.Queue(1), queue.Queue(1), queue.Queue(1), queue.Queue(1)      # (one batch waiting between two stages: what is in flight stays within the pool of per-batch blocks)
         tab = P(Lb.nabwa_isize_table_create(po.ap_prior, n))
         st = C.c_uint64(nabwa.srand48_state(11))
         outs = [(np.zeros(len(ob), np.uint8), np.zeros(n_e + 1, np.int64)) for _ in range(2)]
@@ -488,10 +489,19 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
                 if Lb.nabwa_bam_batch_create(ix._h, C.byref(opt), C.byref(po), n_e, T.ptr(buf), T.ptr(boff), C.byref(h)) != 0:
                     err.append(Lb.nabwa_last_error())
                     h = None
+                q0.put(h)
+                if h is None:
+                    return
+            q0.put(None)
+
+        def s_search():                     # the GPU's part of pass 1 (nabwa_bam_batch_search: upload, kernels W / S / D, rows back), as nabwa_bam2bam's search threads run it
+            while True:
+                h = q0.get()
+                if h is not None and Lb.nabwa_bam_batch_search(h) != 0:
+                    err.append(Lb.nabwa_last_error())
                 q1.put(h)
                 if h is None:
                     return
-            q1.put(None)
 
         def s_pass1():
             while True:
@@ -527,7 +537,7 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
                 Lb.nabwa_bam_batch_destroy(h)
                 k += 1
 
-        th = [threading.Thread(target=f) for f in (s_create, s_pass1, s_pass2, s_out)]
+        th = [threading.Thread(target=f) for f in (s_create, s_search, s_pass1, s_pass2, s_out)]
         t_s = time.time()
         for x in th:
             x.start()
@@ -605,7 +615,7 @@ def e2e_leg(ctx, G, opt, seq, rseq, off, L):
     return {"what": "unaligned BAM records in host memory -> aligned BAM records in host memory (nabwa_bam_batch_*: the whole of bam2bam's two passes for single-end records, without BGZF)",
             "reads": n_e, "n_gpus": ctx.world, "reads_per_s": round(n_e * ctx.world / elapsed, 1), "first_batch_reads_per_s": round(n_e / dt_first.sum(), 1), "bam_bytes_out": int(nb.value),
             "streamed_reads_per_s": round(n_e * n_stream * ctx.world / t_stream, 1),
-            "streamed": "%d batches of %d records through create | pass 1 | pass 2 | output + destroy as a four-thread pipeline over the same calls (what nabwa_bam2bam does around them, "
+            "streamed": "%d batches of %d records through create | search | pass 1 | pass 2 | output + destroy as a five-thread pipeline over the same calls (what nabwa_bam2bam does around them, "
                         "without BGZF); reads_per_s is ONE batch through the four calls one after the other; the stream's last batch has the one-batch run's bytes: %s" % (n_stream, n_e, stream_same),
             "stage_ms": {"parse + erase tags + bam1_to_seq": round(dt[0] * 1e3, 1), "pass 1: search (upload, kernels W / S / D, rows back) + posn_singleton": round(dt[1] * 1e3, 1),
                          "pass 2: bwa_refine_gapped + MD/NM + bwa_update_bam1": round(dt[2] * 1e3, 1), "records out": round(dt[3] * 1e3, 1)},
