@@ -671,6 +671,57 @@ def pe_workload(ctx, G, N, steps, warmup, cpu_seconds):
         kms.append(km)
     barrier(ctx)
     elapsed = max_over_ranks(ctx, time.time() - t1)
+    # the same steps as a stream: the next batch's search runs on the GPU (nabwa_batch_run returns at once) while the host finishes this one -- two
+    # batch objects over the same resident reads, taken in turn; the results of every step are the sequential step's
+    streamed = None
+    if not quick_env() or os.environ.get("NABWA_BENCH_STREAM"):
+        batch2 = nabwa.Batch(ix, opt, seq, rseq, off, per_read=True)
+        rec_buf2 = (nabwa.PeRec * (2 * N))()
+        pair = [(batch, rec_buf, {}), (batch2, rec_buf2, {})]
+
+        import queue
+        import threading
+        n_st = max(steps, 4)
+        qs, qf = queue.Queue(1), queue.Queue(2)
+        for k in range(2):
+            qf.put(k)
+
+        def searcher():                                # run + sync + fetch of batch k & 1, one after the other: the GPU's share of a step
+            for k in range(n_st + 1):
+                slot = qf.get()
+                bk, rb, kp = pair[slot]
+                bk.run()
+                bk.sync()
+                na, rw, _ = bk.fetch_flat(kp)
+                qs.put((slot, na, rw))
+
+        def finish():                                  # the host's share, while the searcher is at the next batch
+            slot, na, rw = qs.get()
+            rb = pair[slot][1]
+            rc_, _ = ix.pe_posn_flat(opt, off, full, na, rw, nabwa.srand48_state(11), out=rb)
+            hh = np.zeros(100000, np.uint16)
+            nabwa.isize_add_pairs(rc_, N, hh)
+            _, ii_ = nabwa.isize_infer(hh, po.ap_prior, n)
+            ix.pe_finish_flat(opt, po, ii_, seq, rseq, off, na, rw, rc_)
+            qf.put(slot)
+            return rc_
+
+        th = threading.Thread(target=searcher)
+        th.start()
+        finish()                                       # (warm-up: the second batch's buffers)
+        barrier(ctx)
+        ts = time.time()
+        for k in range(n_st):
+            rc_last = finish()
+        barrier(ctx)
+        ts = max_over_ranks(ctx, time.time() - ts)
+        th.join()
+        same = bool(np.array_equal(np.frombuffer(rc_last, np.uint8).reshape(2 * N, -1)[:, :64], np.frombuffer(recs, np.uint8).reshape(2 * N, -1)[:, :64]))
+        streamed = {"pairs_per_s": round(N * world * n_st / ts, 1), "ms_per_step": round(ts / n_st * 1e3, 1), "steps": n_st,
+                    "what": "the same step with the next batch's search on the GPU while the host positions and finishes this one (two batch objects over the resident reads); "
+                            "the heads of the finished records equal the sequential step's: %s" % same}
+        batch2.close()
+        del rec_buf2
     if rank != 0:
         batch.close()
         return None
@@ -708,7 +759,7 @@ def pe_workload(ctx, G, N, steps, warmup, cpu_seconds):
                                    "finish_pair (pairing, mate rescue, refinement, MD)": round(float(sp[4]), 1)},
                       "isize": [ii.avg, ii.std, ii.low, ii.high, ii.high_bayesian], "mate_rescued": int(sw[1][0]), "rescue_attempts": int(sw[0][0]),
                       "mapped_ends": int((tp != 0).sum()), "second_pass_reads": n2, "hits": n_rows, "checksum": "%016x" % checksum,
-                      "bit_exact_vs_cpu_sample": exact, "instrumented_run_same_rows": instrumented_same},
+                      "bit_exact_vs_cpu_sample": exact, "instrumented_run_same_rows": instrumented_same, "streamed": streamed},
            "roofline": roofline, "cpu_baseline": cpu}
     batch.close()
     del rec_buf
