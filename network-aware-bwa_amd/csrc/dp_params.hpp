@@ -12,6 +12,7 @@ struct DpParams {
 	int matrix[25];
 	int W;                 // max_l1 + 1
 	int H;                 // max_l2 + 1
+	int wb;                // cells a row's band can hold at most, + 1: min(W, 2 band + max |l1 - l2| + 1) -- the width of a task's direction rows in the wave-per-task form (0: not known, that form is not used)
 	int32_t *rows;         // per wave: [6][W][64]
 	uint8_t *tb;           // per wave: [H][W][64], byte = Mt | It<<2 | Dt<<4
 	uint8_t *path;         // per wave: [W+H][64]

@@ -80,10 +80,12 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 	for (int c0 = 0; c0 < n; c0 += CHUNK) {
 		const double tg0 = now();
 		const int m = std::min(CHUNK, n - c0);
-		int W = 1, H = 1;
+		int W = 1, H = 1; int64_t maxdiff = 0;
 		for (int i = c0; i < c0 + m; ++i) {
-			W = std::max<int64_t>(W, ref_off[i + 1] - ref_off[i] + 1);
-			H = std::max<int64_t>(H, qry_off[i + 1] - qry_off[i] + 1);
+			const int64_t a1 = ref_off[i + 1] - ref_off[i], a2 = qry_off[i + 1] - qry_off[i];
+			W = std::max<int64_t>(W, a1 + 1);
+			H = std::max<int64_t>(H, a2 + 1);
+			maxdiff = std::max<int64_t>(maxdiff, a1 > a2 ? a1 - a2 : a2 - a1);
 		}
 		std::vector<int64_t> ro(m + 1), qo(m + 1);
 		for (int i = 0; i <= m; ++i) { ro[i] = ref_off[c0 + i] - ref_off[c0]; qo[i] = qry_off[c0 + i] - qry_off[c0]; }
@@ -106,6 +108,7 @@ extern "C" int nabwa_global_align(int device, int n, const int64_t *ref_off, con
 		P.gap_open = gap_open; P.gap_ext = gap_ext; P.gap_end = gap_end; P.band = band;
 		memcpy(P.matrix, matrix25, sizeof(P.matrix));
 		P.W = W; P.H = H; P.max_cigar = max_cigar;
+		P.wb = (int)std::min<int64_t>(W, 2 * (int64_t)band + maxdiff + 1);
 		const double tg2 = now();
 		nabwa_launch_dp_global(&P, 0);
 		SCHK(hipGetLastError());
