@@ -21,9 +21,12 @@ SM = [np.array([11, -19, -19, -19, -13, -19, 11, -19, -19, -13, -19, -19, 11, -1
                 -3, -3, -3, 1, -2, -2, -2, -2, -2, -2], np.int32)]
 
 
-@pytest.mark.parametrize("small", ["4096", "0"])
-def test_global_align_golden(monkeypatch, small):
-    monkeypatch.setenv("NABWA_DP_SMALL", small)       # both forms of the kernel: rows in LDS for a handful of tasks, in HBM for many
+@pytest.mark.parametrize("wave,small", [("1", "4096"), ("0", "4096"), ("0", "0")])
+def test_global_align_golden(monkeypatch, wave, small):
+    # every form of the kernel: one wavefront per task (rows and directions in LDS: what runs unless a task is too large for it), and one pair
+    # per lane with the rows in LDS for a handful of tasks / in HBM for many
+    monkeypatch.setenv("NABWA_DP_WAVE", wave)
+    monkeypatch.setenv("NABWA_DP_SMALL", small)
     vec = np.load(os.path.join(T.GOLDEN, "vectors.npz"))
     n = int(vec["dp_n"])
     for pid in range(len(vec["dp_params"])):
@@ -43,8 +46,10 @@ def test_global_align_golden(monkeypatch, small):
             nabwa.lib().nabwa_dp_scratch_release(0)
 
 
-def test_global_align_random_vs_oracle():
-    """fresh random pairs incl. length-1 and very unequal lengths, several parameter blocks"""
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_global_align_random_vs_oracle(monkeypatch, wave):
+    """fresh random pairs incl. length-1 and very unequal lengths, several parameter blocks; one wavefront per task, and one pair per lane"""
+    monkeypatch.setenv("NABWA_DP_WAVE", wave)
     olib = T.load_oracle()
     rng = np.random.default_rng(5)
     refs, qrys = [], []
