@@ -318,6 +318,11 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					}
 				}
 				if (PROF) { ++st_rounds; st_run += W; if (careful) ++st_careful; }
+#ifndef NABWA_EMU
+				// (statistics build, NABWA_DEEP_HIST=2: rounds and wave-steps by the round's width -- 1, 2, 3-4, 5-8, ... 33-64 entries)
+				const uint32_t wbin = W <= 1u ? 0u : 32u - (uint32_t)__clz((int)(W - 1u));
+				if (PROF && P.stats && P.hist == 2) { ONE_LANE { atomicAdd(P.stats + 32 + wbin, 1ull); } }
+#endif
 
 				unsigned long long pc1 = 0; if (prof) { LANES { L(tu) = L(e).k; } (void)WUNI(WBCAST(tu, 0)); pc1 = DEEP_CLOCK(); ph_pop += pc1 - pc0; }
 				// ---------------------------------------------------------------- the chains (and, when forced levels were walked on the text for
@@ -332,6 +337,9 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					if (COOP && coop_n >= 16u && coop_lv < 4u * coop_n && ++coop_skip >= 4096u) { coop_n = coop_lv = coop_skip = 0u; }
 					const bool coop_ok = COOP && n_act <= P.coop_lanes && (coop_n < 16u || coop_lv >= 4u * coop_n);
 					if (PROF) { ++st_steps; st_lanesteps += n_act; }
+#ifndef NABWA_EMU
+					if (PROF && P.stats && P.hist == 2) { ONE_LANE { atomicAdd(P.stats + 64 + wbin, 1ull); } }
+#endif
 					LANES { if (L(act)) {
 						DeepLane &E = L(e);
 						// ---- what the reference does with a popped entry (bwtgap.c:141-164)
@@ -359,7 +367,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								uint32_t nk0, nl0, nk1, nl1, nk2, nl2, nk3, nl3;
 								if (PROF) L(pk_exp) += 1u;
 #ifndef NABWA_EMU
-								if (PROF && P.stats && P.hist) { const uint32_t dd = (uint32_t)(len - i - 1) < 31u ? (uint32_t)(len - i - 1) : 31u; atomicAdd(P.stats + 32 + (kf ? 64u : (E.k == E.l ? 32u : 0u)) + dd, 1ull); }
+								if (PROF && P.stats && P.hist == 1) { const uint32_t dd = (uint32_t)(len - i - 1) < 31u ? (uint32_t)(len - i - 1) : 31u; atomicAdd(P.stats + 32 + (kf ? 64u : (E.k == E.l ? 32u : 0u)) + dd, 1ull); }
 #endif
 								const int m_seed = S.max_seed_diff - E.mm - E.go - (gape_mode ? E.ge : 0);
 								bool allow_diff = true, allow_M = true;
@@ -407,6 +415,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 										}
 									}
 									if (die) L(act) = false;
+								} else if (kf && coop_ok) {
+									// (a chain in key form that may push differences, few chains left: the wave takes its levels down to the table's depth together -- the
+									// two chains of a search's first round are such: a dozen steps with two lanes at work, a quarter of the PE workload's wave-steps)
+									walked = true; L(flag) = DF_COOP; L(act) = false;
 								} else if (text_ok && E.k == E.l && !L(norun) && (!allow_diff || coop_ok)) {
 									// (forced levels: DF_RUN, every lane walks its own stretch; levels that may push differences: DF_COOP, the wave takes
 									// the chain's next levels together, 64 at a time -- see behind the tails' loop)
@@ -505,7 +517,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 				// for one load --, a hit takes the rows of its own string)
 				LANES {
 					const bool kf = L(e).l >= DEEP_KEYL;
-					L(ts) = L(flag) == DF_TAIL ? (kf ? 5 : ((text_ok && L(e).k == L(e).l) ? 1 : 0)) : (L(flag) == DF_HIT && kf ? 6 : (L(flag) == DF_RUN || L(flag) == DF_COOP ? 7 : -1));
+					L(ts) = L(flag) == DF_TAIL ? (kf ? 5 : ((text_ok && L(e).k == L(e).l) ? 1 : 0)) : (L(flag) == DF_HIT && kf ? 6 : (L(flag) == DF_COOP && kf ? 10 : (L(flag) == DF_RUN || L(flag) == DF_COOP ? 7 : -1)));
 				}
 				while (WBALLOT(L(ts) >= 0 && L(ts) != 10) != 0ull) {
 					if (PROF) ++st_tailit;
@@ -622,7 +634,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 					if (cm) {
 						const uint64_t sm2 = WBALLOT(L(flag) == DF_HIT || L(flag) == DF_CONT);
 						int jstop = sm2 ? deep_ctz64(sm2) : 64;
-						LANE(uint32_t, v_rk); LANE(uint32_t, v_rc); LANE(uint32_t, v_inf); LANE(uint32_t, v_g); LANE(uint32_t, v_rec);
+						LANE(uint32_t, v_rk); LANE(uint32_t, v_el); LANE(uint32_t, v_rc); LANE(uint32_t, v_cl); LANE(uint32_t, v_inf); LANE(uint32_t, v_g); LANE(uint32_t, v_rec);
 						LANE(uint32_t, v_a0); LANE(uint32_t, v_a1); LANE(uint32_t, v_a2); LANE(uint32_t, v_ng);
 						LANE(uint32_t, x_g); LANE(uint32_t, x_f); LANE(uint32_t, x_0); LANE(uint32_t, x_1); LANE(uint32_t, x_2);
 						while (cm) {
@@ -632,6 +644,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							if (PROF) ++st_coop;
 							// the chain: its entry (popped, past its pop's checks), its text position, its counts so far
 							LANES { L(tu) = L(e).k; } const uint32_t ck = WUNI(WBCAST(tu, j));
+							LANES { L(tu) = L(e).l; } const uint32_t cl0 = WUNI(WBCAST(tu, j));
+							// the chain stands on one row (its levels come out of the text) or in key form (out of the interval table: level d's string is the
+							// entry's and the read's next d symbols, its four possible extensions 32 bytes of the next table level -- down to the table's depth)
+							const bool ckf = cl0 >= DEEP_KEYL;
+							const uint32_t kt0 = cl0 & 0xffu;
+							const uint32_t zlast = ckf ? (KT - 1u - kt0 < 63u ? KT - 1u - kt0 : 63u) : 63u;
 							LANES { L(tu) = (uint32_t)L(e).i; } const int ci = (int)WUNI(WBCAST(tu, j));
 							LANES { L(tu) = (uint32_t)L(e).mm | (uint32_t)L(e).go << 8 | (uint32_t)L(e).ge << 16 | (uint32_t)L(e).state << 24 | (uint32_t)L(e).a << 26; }
 							const uint32_t cinfo = WUNI(WBCAST(tu, j));
@@ -641,6 +659,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							const int cmm = (int)(cinfo & 0xffu), cgo = (int)(cinfo >> 8 & 0xffu), cge = (int)(cinfo >> 16 & 0xffu), cst = (int)(cinfo >> 24 & 3u);
 							const uint32_t ca = cinfo >> 26 & 1u;
 							const bool cq1 = ca == 0u;
+							const uint2 *const ctab = deep_table_of(s_bc, ca);
 							const uint32_t *const isa = cq1 ? S.bwt[1].isa : S.bwt[0].isa, *const txt = cq1 ? S.bwt[1].text : S.bwt[0].text;
 							const int m = max_diff - cmm - cgo - (gape_mode ? cge : 0), m_seed = S.max_seed_diff - cmm - cgo - (gape_mode ? cge : 0);
 							int tmp = cgo + cge;
@@ -648,11 +667,15 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							// ---- lane d: level d.  kind: 0 expanded and matched on, 1 expanded and the chain ends, 2 dropped at the pop, 3 a hit, 4 an exact tail, 5 no such level
 							LANES {
 								const uint32_t d = (uint32_t)ln;
-								uint32_t kind = 5u, rk = 0u, rc = 0u, g = 0u, a0 = 0u, a1 = 0u, a2 = 0u, ng = 0u, rcd = 0u, inf = 0u;
-								if ((int)d <= ci && d <= ctp) {
+								uint32_t kind = 5u, rk = 0u, el = 0u, rc = 0u, cl = 0u, g = 0u, a0 = 0u, a1 = 0u, a2 = 0u, ng = 0u, rcd = 0u, inf = 0u;
+								if ((int)d <= ci && (ckf ? d <= zlast : d <= ctp)) {
 									const int Ei = ci - (int)d;
-									const uint32_t tq = ctp - d;
-									rk = d == 0u ? ck : isa[tq];
+									const uint32_t tq = ckf ? 0u : ctp - d;
+									if (ckf) {
+										uint32_t key = ck;
+										for (uint32_t u = 0; u < d; ++u) key = key << 2 | (DEEP_RD(ca, ci - 1 - (int)u) & 3u);
+										rk = key; el = DEEP_KEYL | (kt0 + d);
+									} else { rk = d == 0u ? ck : isa[tq]; el = rk; }
 									const int st = d == 0u ? cst : DST_M;
 									bool go_on = true, hit = false, tail = false;
 									if (d > 0u) {
@@ -663,19 +686,32 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 									if (!go_on) kind = 2u; else if (hit) kind = 3u; else if (tail) kind = 4u;
 									else {
 										const int p = Ei - 1;
-										const bool have = tq >= 1u;
-										uint32_t x = 0u;
-										if (have) { x = txt[(tq - 1u) >> 4] >> (((tq - 1u) & 15u) << 1) & 3u; rc = isa[tq - 1u]; }
+										const uint32_t c = DEEP_RD(ca, p);
+										uint32_t vm, occ = 1u;
+										if (ckf) {
+											const uint4 *const ch = (const uint4*)(ctab + ((size_t)DEEP_LVO(kt0 + d + 1u) + (size_t)rk * 4u));
+											const uint4 c01 = deep_ld_global16(ch), c23 = deep_ld_global16(ch + 1);
+											vm = (c01.x <= c01.y ? 1u : 0u) | (c01.z <= c01.w ? 2u : 0u) | (c23.x <= c23.y ? 4u : 0u) | (c23.z <= c23.w ? 8u : 0u);
+											occ = 0xffffffffu;
+											if (st == DST_D && cge + cgo >= max_diff && kt0 + d) { const uint2 own = deep_ld_global8(ctab + ((size_t)DEEP_LVO(kt0 + d) + rk)); occ = own.y - own.x + 1u; }
+											if (kt0 + d + 1u < KT) { rc = rk << 2 | (c & 3u); cl = DEEP_KEYL | (kt0 + d + 1u); }
+											else { rc = c == 0u ? c01.x : (c == 1u ? c01.z : (c == 2u ? c23.x : c23.z)); cl = c == 0u ? c01.y : (c == 1u ? c01.w : (c == 2u ? c23.y : c23.w)); }
+										} else {
+											const bool have = tq >= 1u;
+											uint32_t x = 0u;
+											if (have) { x = txt[(tq - 1u) >> 4] >> (((tq - 1u) & 15u) << 1) & 3u; rc = isa[tq - 1u]; }
+											cl = rc;
+											vm = have ? 1u << x : 0u;
+										}
+										const uint32_t nv = (uint32_t)__popc(vm);
 										bool allow_diff, allow_M;
 										DEEP_BOUNDS(ca, p, m, m_seed, allow_diff, allow_M);
-										const uint32_t vm = have ? 1u << x : 0u, nv = have ? 1u : 0u;
 										uint32_t grp = 0u, n_gap = 0u, gcls = DCL_GO;
 										if (allow_diff && p >= S.indel_end_skip + tmp && len - p >= S.indel_end_skip + tmp) {
 											if (st == DST_M) { if (cgo < MG) { grp = DRG_OPEN; n_gap = 1u + nv; } }
 											else if (st == DST_I) { if (cge < S.max_gape) { grp = DRG_EXT_I; n_gap = 1u; gcls = DCL_GE; } }
-											else if (cge < S.max_gape && (cge + cgo < max_diff || 1u < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
+											else if (cge < S.max_gape && (cge + cgo < max_diff || occ < (uint32_t)S.max_del_occ)) { grp = DRG_EXT_D; n_gap = nv; gcls = DCL_GE; }
 										}
-										const uint32_t c = DEEP_RD(ca, p);
 										uint32_t mmv = 0u; bool match = false;
 										if (allow_diff && allow_M) { mmv = c > 3u ? vm : vm & ~(1u << c); match = c <= 3u && (vm >> c & 1u); }
 										else if (c < 4u) match = (vm >> c & 1u) != 0u;
@@ -693,11 +729,12 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 										kind = match ? 0u : 1u;
 									}
 								}
-								L(v_rk) = rk; L(v_rc) = rc; L(v_inf) = inf | kind << 17; L(v_g) = g; L(v_rec) = rcd; L(v_a0) = a0; L(v_a1) = a1; L(v_a2) = a2; L(v_ng) = ng;
+								L(v_rk) = rk; L(v_el) = el; L(v_rc) = rc; L(v_cl) = cl; L(v_inf) = inf | kind << 17; L(v_g) = g; L(v_rec) = rcd; L(v_a0) = a0; L(v_a1) = a1; L(v_a2) = a2; L(v_ng) = ng;
 							}
 							// ---- how far the chain gets: every level before it matched on; no further than its record room (or, careful, one pop)
 							const uint64_t contm = WBALLOT((L(v_inf) >> 17 & 7u) == 0u);
-							const uint32_t z = ~contm ? (uint32_t)deep_ctz64(~contm) : 63u;
+							uint32_t z = ~contm ? (uint32_t)deep_ctz64(~contm) : 63u;
+							if (z > zlast) z = zlast;                          // (the table ends there: a chain that got through goes on as rows, in chain steps)
 							LANES { if ((uint32_t)ln > z) { L(v_g) = 0u; L(v_rec) = 0u; L(v_a0) = L(v_a1) = L(v_a2) = 0u; } }
 							uint32_t tot_ = 0;
 							WEXSCAN_U32(L(x_g), L(v_g), tot_); WEXSCAN_U32(L(x_f), L(v_rec), tot_);
@@ -715,20 +752,27 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 							LANES {
 								if ((uint32_t)ln <= le && L(v_rec)) {
 									const uint32_t inf = L(v_inf), vm = inf & 15u, grp = inf >> 4 & 3u, mmv = inf >> 8 & 15u, gcn = inf >> 12 & 3u, c = inf >> 14 & 7u;
-									const uint32_t rc = L(v_rc), rk = L(v_rk);
+									const uint32_t rc = L(v_rc), rk = L(v_rk), el = L(v_el);
 									const uint32_t at_gap = gcn == 0u ? c0 + L(x_0) : (gcn == 1u ? c1 + L(x_1) : c2 + L(x_2));
 									const uint32_t at_mm = c0 + L(x_0) + (gcn == 0u ? L(v_ng) : 0u);
 									const uint32_t p = (uint32_t)(ci - ln - 1);
 									uint4 *const rp = stage + ((size_t)j * K + cnr + L(x_f)) * 4u;
-									rp[0] = make_uint4(vm & 1u ? rc : 1u, vm & 2u ? rc : 1u, vm & 4u ? rc : 1u, vm & 8u ? rc : 1u);
-									rp[1] = make_uint4(vm & 1u ? rc : 0u, vm & 2u ? rc : 0u, vm & 4u ? rc : 0u, vm & 8u ? rc : 0u);
-									rp[2] = make_uint4(rk, rk, p | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
+									if (ckf) {                                          // the four intervals once more (they were not kept over the sums: eight registers a lane)
+										const uint4 *const ch = (const uint4*)(ctab + ((size_t)DEEP_LVO((el & 0xffu) + 1u) + (size_t)rk * 4u));
+										const uint4 c01 = deep_ld_global16(ch), c23 = deep_ld_global16(ch + 1);
+										rp[0] = make_uint4(c01.x, c01.z, c23.x, c23.z);
+										rp[1] = make_uint4(c01.y, c01.w, c23.y, c23.w);
+									} else {
+										rp[0] = make_uint4(vm & 1u ? rc : 1u, vm & 2u ? rc : 1u, vm & 4u ? rc : 1u, vm & 8u ? rc : 1u);
+										rp[1] = make_uint4(vm & 1u ? rc : 0u, vm & 2u ? rc : 0u, vm & 4u ? rc : 0u, vm & 8u ? rc : 0u);
+									}
+									rp[2] = make_uint4(rk, el, p | vm << 16 | grp << 20 | mmv << 24 | gcn << 28,
 													   (uint32_t)cmm | (uint32_t)cgo << 8 | (uint32_t)cge << 16 | ca << 26 | c << 27);
 									rp[3] = make_uint4(at_gap, at_mm, 0u, 0u);
 								}
 							}
 							// ---- the chain's lane: where the chain step would have left it
-							const uint32_t e_kind = WUNI(WBCAST(v_inf, le)) >> 17 & 7u, e_rk = WUNI(WBCAST(v_rk, le)), e_rc = WUNI(WBCAST(v_rc, le));
+							const uint32_t e_kind = WUNI(WBCAST(v_inf, le)) >> 17 & 7u, e_rk = WUNI(WBCAST(v_rk, le)), e_rc = WUNI(WBCAST(v_rc, le)), e_el = WUNI(WBCAST(v_el, le)), e_cl = WUNI(WBCAST(v_cl, le));
 							const uint32_t e_g = WUNI(WBCAST(v_g, le)), e_xg = WUNI(WBCAST(x_g, le)), e_nr = cnr + WUNI(WBCAST(x_f, le)) + WUNI(WBCAST(v_rec, le));
 							const uint32_t n0 = c0 + WUNI(WBCAST(x_0, le)) + WUNI(WBCAST(v_a0, le)), n1 = c1 + WUNI(WBCAST(x_1, le)) + WUNI(WBCAST(v_a1, le)), n2 = c2 + WUNI(WBCAST(x_2, le)) + WUNI(WBCAST(v_a2, le));
 							const int nrel = crel + (int)e_xg + (e_kind <= 1u ? (int)e_g : 0) + (e_kind == 0u ? 1 : 0);
@@ -736,10 +780,10 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 								DeepLane &E = L(e);
 								L(rel) = nrel; L(peak) = (int)mxr; L(cc0) = n0; L(cc1) = n1; L(cc2) = n2; L(nrec) = e_nr; L(ts) = -1; L(flag) = DF_NONE;
 								if (e_kind == 0u) {                                       // its matching child is the next pop: out of room / careful (to be continued), or on it goes
-									E.k = E.l = e_rc; E.i = (uint32_t)(ci - (int)le - 1); E.ldp = 0; E.state = DST_M;
+									E.k = e_rc; E.l = e_cl; E.i = (uint32_t)(ci - (int)le - 1); E.ldp = 0; E.state = DST_M;
 									if (cut) L(flag) = DF_CONT; else L(act) = true;
 								} else if (e_kind == 3u || e_kind == 4u) {
-									E.k = E.l = e_rk; E.i = (uint32_t)(ci - (int)le); E.ldp = 0; E.state = DST_M;
+									E.k = e_rk; E.l = e_el; E.i = (uint32_t)(ci - (int)le); E.ldp = 0; E.state = DST_M;
 									L(flag) = e_kind == 3u ? DF_HIT : DF_TAIL;
 								}
 							} }
@@ -748,7 +792,7 @@ DEEP_FN void deep_wave_body(const DeepParams &P_, uint32_t *lds, uint32_t wave
 						}
 					}
 				}
-				if (WBALLOT(L(act) || L(flag) == DF_TAIL) == 0ull) break;
+				if (WBALLOT(L(act) || L(flag) == DF_TAIL || (L(flag) == DF_HIT && L(e).l >= DEEP_KEYL)) == 0ull) break;      // (a hit found here in key form still takes its rows from the table: the tails' loop once more)
 				if (prof) { pc1 = DEEP_CLOCK(); ph_tail += pc1 - pc2; }
 				}
 

@@ -892,7 +892,7 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 		if (D.max_lanes > 64) D.max_lanes = 64;
 
 		D.stats = timing || getenv("NABWA_DEEP_STATS") ? b->d_deep_ctr : 0;
-		D.hist = getenv("NABWA_DEEP_HIST") ? 1 : 0;
+		D.hist = env_int("NABWA_DEEP_HIST", 0);
 		/* the wave-wide expansion of one-row chains pays where chains are long: reads of 100 bases and more (PE D -24 %); on reads of 50-76 bases
 		 * its chains end after a level or two, and the kernel built without it is the faster one (profiles/r03_deep_variants.txt) */
 		D.coop_lanes = (uint32_t)env_int("NABWA_DEEP_COOP", b->max_len >= 90 ? 4 : 0);
@@ -944,7 +944,14 @@ extern "C" int nabwa_batch_sync(nabwa_batch_t *b, int *n_second_pass)
 						st[16] * 1e-8, st[17] * 1e-8, st[18] * 1e-8, st[21], st[19] * 1e-8, st[20] * 1e-8, st[3] ? (double)st[22] / (double)st[3] : 0.0);
 				fprintf(stderr, "[nabwa] kernel D lane-steps %llu: pruned at the pop %llu, expansions %llu (in key form %llu, on two buckets %llu), records %llu, children stored %llu; key-form tails / hits %llu; expansions without a difference allowed: %llu in key form, %llu on one row, %llu on several\n",
 						st[22], st[27], st[28], st[23], st[29], st[25], st[26], st[24], st[30], st[31], st[9]);
-				if (getenv("NABWA_DEEP_HIST")) for (int h = 0; h < 3; ++h) {
+				if (env_int("NABWA_DEEP_HIST", 0) == 2) {
+					fprintf(stderr, "[nabwa] kernel D rounds by width (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64 entries):");
+					for (int d = 0; d < 7; ++d) fprintf(stderr, " %llu", st[32 + d]);
+					fprintf(stderr, "; their wave-steps:");
+					for (int d = 0; d < 7; ++d) fprintf(stderr, " %llu", st[64 + d]);
+					fprintf(stderr, "\n");
+				}
+				if (env_int("NABWA_DEEP_HIST", 0) == 1) for (int h = 0; h < 3; ++h) {
 					fprintf(stderr, "[nabwa] kernel D expansions by depth (read symbols consumed), %s:", h == 0 ? "rows, several" : (h == 1 ? "rows, one" : "key form"));
 					for (int d = 0; d < 32; ++d) fprintf(stderr, " %llu", st[32 + 32 * h + d]);
 					fprintf(stderr, "\n");
